@@ -1,0 +1,328 @@
+"""Generate golden vectors by running the REAL reference (build container only).
+
+    cd /root/repo && PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (/root/reference, miguelmartin75/txt2vid) is imported read-only with the two runtime
+shims of SURVEY.md §8(c); nothing of it is copied. Weights are NOT stored: every state_dict entry
+is regenerated from its key by `oracle.tganv2_oracle.recipe_tensor`, here (poured into the reference
+modules) and in the tests (poured into the oracle / the HIP modules). The fixtures hold inputs,
+outputs, losses, per-key gradient norms and a few small full gradients.
+"""
+import os
+import sys
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.nn.parallel as TP
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+
+TP.data_parallel = lambda m, x, *a, **k: m(x)                                  # shim 1
+import txt2vid.gan.losses as RL                                                # noqa: E402
+RL.get_labels_for = lambda x, l: torch.full(x.size(), float(l), device=x.device)   # shim 2
+
+from txt2vid.models.layers import (Attention, Attention3d, DownBlock, DownSample, UpBlock,   # noqa: E402
+                                   RenderBlock, Subsample)
+from txt2vid.models.conv_lstm import ConvLSTM                                   # noqa: E402
+from txt2vid.models.resnet3d import Resnet3D                                    # noqa: E402
+from txt2vid.models.tganv2.gen import MultiScaleGen as GenU                     # noqa: E402
+from txt2vid.models.tganv2.discrim import MultiScaleDiscrim as DisU             # noqa: E402
+from txt2vid.models.tganv2_cond.gen import MultiScaleGen as GenC                # noqa: E402
+from txt2vid.models.tganv2_cond.discrim import MultiScaleDiscrim as DisC        # noqa: E402
+from txt2vid.models.txt.basic import Seq2Seq                                    # noqa: E402
+from txt2vid.gan.cond_gan import CondGan                                        # noqa: E402
+from txt2vid.gan.losses import MixedGanLoss, RSGANLoss, _gradient_penalty       # noqa: E402
+from txt2vid.util.torch.init import init as ref_init                            # noqa: E402
+
+from oracle.tganv2_oracle import recipe_tensor                                  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def pour(module, base_seed=0, attn_gamma=0.5):
+    """Overwrite every state_dict entry of a reference module by the key recipe."""
+    sd = module.state_dict()
+    new = {k: recipe_tensor(k, v.shape, base_seed, attn_gamma) for k, v in sd.items()}
+    module.load_state_dict(new)
+    return module
+
+
+def rnd(seed, *shape):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def grad_norms(module):
+    return {k: float(p.grad.norm()) if p.grad is not None else -1.0 for k, p in module.named_parameters()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024.0))
+
+
+def pack_norms(prefix, d, out):
+    keys = sorted(d.keys())
+    out[prefix + '_keys'] = np.array(keys)
+    out[prefix + '_vals'] = np.array([d[k] for k in keys], dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------------------------
+def golden_layers():
+    out = {}
+    # DownSample incl. odd sizes (layers.py:202-217)
+    ds = DownSample()
+    for tag, shape in (('a', (2, 3, 4, 6, 6)), ('b', (2, 3, 3, 5, 7)), ('c', (1, 2, 1, 4, 1))):
+        x = rnd(1, *shape)
+        out['ds_%s_x' % tag] = npy(x)
+        out['ds_%s_y' % tag] = npy(ds(x))
+    # DownBlock (layers.py:219-243)
+    db = pour(DownBlock(in_channels=16, out_channels=32, wide=False))
+    x = rnd(2, 2, 16, 4, 6, 6).requires_grad_(True)
+    y = db(x)
+    gy = rnd(3, *y.shape)
+    (y * gy).sum().backward()
+    out['db_x'], out['db_y'], out['db_gy'], out['db_gx'] = npy(x), npy(y), npy(gy), npy(x.grad)
+    for k, p in db.named_parameters():
+        out['db_g_' + k] = npy(p.grad)
+    # Attention3d with gamma != 0 (layers.py:39-68) incl. double backward
+    at = pour(Attention3d(32))
+    x = rnd(4, 2, 32, 2, 4, 4).requires_grad_(True)
+    y = at(x)
+    gy = rnd(5, *y.shape)
+    gx, = torch.autograd.grad((y * gy).sum(), x, create_graph=True)
+    r = (gx ** 2).sum()
+    r.backward()
+    out['at3_x'], out['at3_y'], out['at3_gy'], out['at3_gx'] = npy(x), npy(y), npy(gy), npy(gx)
+    out['at3_r'] = np.float64(r.item())
+    out['at3_ggx'] = npy(x.grad)
+    for k, p in at.named_parameters():
+        out['at3_gg_' + k] = npy(p.grad)
+    # Attention (2-D) (layers.py:10-36)
+    a2 = pour(Attention(32))
+    x = rnd(6, 3, 32, 8, 8).requires_grad_(True)
+    y = a2(x)
+    gy = rnd(7, *y.shape)
+    (y * gy).sum().backward()
+    out['at2_x'], out['at2_y'], out['at2_gy'], out['at2_gx'] = npy(x), npy(y), npy(gy), npy(x.grad)
+    for k, p in a2.named_parameters():
+        out['at2_g_' + k] = npy(p.grad)
+    # UpBlock (train mode BN) (layers.py:152-195)
+    for tag, cin, cout in (('ub', 16, 8), ('ub_same', 8, 8)):
+        ub = pour(UpBlock(in_channels=cin, out_channels=cout))
+        ub.train()
+        x = rnd(8, 4, cin, 4, 4).requires_grad_(True)
+        y = ub(x)
+        gy = rnd(9, *y.shape)
+        (y * gy).sum().backward()
+        out[tag + '_x'], out[tag + '_y'], out[tag + '_gy'], out[tag + '_gx'] = npy(x), npy(y), npy(gy), npy(x.grad)
+        for k, p in ub.named_parameters():
+            out[tag + '_g_' + k] = npy(p.grad)
+        for k, v in ub.state_dict().items():
+            if 'running' in k:
+                out[tag + '_buf_' + k] = npy(v)
+    # RenderBlock (layers.py:245-259)
+    rb = pour(RenderBlock(in_channels=8, out_channels=3))
+    rb.train()
+    x = rnd(10, 4, 8, 8, 8).requires_grad_(True)
+    y = rb(x)
+    gy = rnd(11, *y.shape)
+    (y * gy).sum().backward()
+    out['rb_x'], out['rb_y'], out['rb_gy'], out['rb_gx'] = npy(x), npy(y), npy(gy), npy(x.grad)
+    for k, p in rb.named_parameters():
+        out['rb_g_' + k] = npy(p.grad)
+    # ConvLSTM, h=w=1 and 2 (conv_lstm.py:57-97); keys get the generator's prefix
+    for tag, hw in (('cl1', 1), ('cl2', 2)):
+        cl = ConvLSTM(input_channels=8, hidden_channels=[8], kernel_size=3, step=5, effective_step=range(5))
+        sd = {k: recipe_tensor('clstm.' + k, v.shape) for k, v in cl.state_dict().items()}
+        cl.load_state_dict(sd)
+        x = rnd(12, 3, 8, hw, hw).requires_grad_(True)
+        ys, _ = cl(x)
+        y = torch.stack(ys)
+        gy = rnd(13, *y.shape)
+        (y * gy).sum().backward()
+        out[tag + '_x'], out[tag + '_y'], out[tag + '_gy'], out[tag + '_gx'] = npy(x), npy(y), npy(gy), npy(x.grad)
+        for k, p in cl.named_parameters():
+            out[tag + '_g_' + k] = npy(p.grad)
+    # Subsample (layers.py:98-111)
+    x = rnd(14, 5, 2, 6, 3, 3)
+    ss = Subsample()
+    out['ss_x'] = npy(x)
+    out['ss_y0'] = npy(ss(x, bt=0)[0])
+    out['ss_y1'] = npy(ss(x, bt=1)[0])
+    save('layers', **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def golden_resnet3d():
+    """Resnet3D heads, first-order grads and the GP double backward (resnet3d.py:38-57,
+    losses.py:135-186) on a small video, full-size channels."""
+    out = {}
+    for tag, cond_dim in (('u', 0), ('c', 24)):
+        net = pour(Resnet3D(num_channels=1, cond_dim=cond_dim))
+        x = rnd(20, 2, 1, 4, 16, 16).requires_grad_(True)
+        cond = rnd(21, 2, cond_dim) if cond_dim else None
+        u, c, feat = net(x, cond=cond)
+        loss = (u * rnd(22, 2, 1)).sum() + (feat * rnd(23, 2, 1024)).sum() * 1e-2
+        if c is not None:
+            loss = loss + (c * rnd(24, 2, 1)).sum()
+        loss.backward()
+        out[tag + '_x'] = npy(x)
+        if cond is not None:
+            out[tag + '_cond'] = npy(cond)
+            out[tag + '_c'] = npy(c)
+        out[tag + '_u'], out[tag + '_feat'], out[tag + '_gx'] = npy(u), npy(feat), npy(x.grad)
+        pack_norms(tag + '_gn', grad_norms(net), out)
+        out[tag + '_g_fc_uncond.weight'] = npy(net.fc_uncond.weight.grad)
+        out[tag + '_g_res_block.inner_module.0.weight'] = npy(net.res_block.inner_module[0].weight.grad)
+        # gradient penalty: zero-centred, sum-combined (losses.py:203)
+        net.zero_grad()
+        xr, xf = rnd(25, 2, 1, 4, 16, 16), rnd(26, 2, 1, 4, 16, 16)
+        cr = rnd(27, 2, cond_dim) if cond_dim else None
+        cf = rnd(28, 2, cond_dim) if cond_dim else None
+        torch.manual_seed(77)
+        gp = _gradient_penalty(net, real_x=xr, fake_x=xf, real_cond=cr, fake_cond=cf, zero_center=True,
+                               combine=torch.sum)
+        gp.backward()
+        out[tag + '_gp_xr'], out[tag + '_gp_xf'] = npy(xr), npy(xf)
+        if cond_dim:
+            out[tag + '_gp_cr'], out[tag + '_gp_cf'] = npy(cr), npy(cf)
+        out[tag + '_gp'] = np.float64(gp.item())
+        pack_norms(tag + '_gp_gn', grad_norms(net), out)
+        out[tag + '_gp_g_down.1.gamma'] = npy(net.down[1].gamma.grad)
+        out[tag + '_gp_g_down.1.theta.weight'] = npy(net.down[1].theta.weight.grad)
+        out[tag + '_gp_g_res_block.inner_module.0.weight'] = npy(net.res_block.inner_module[0].weight.grad)
+        out[tag + '_gp_g_fc_uncond.weight'] = npy(net.fc_uncond.weight.grad)
+    save('resnet3d', **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def golden_gen():
+    """MultiScaleGen train-mode pyramid + eval-mode video (tganv2/gen.py:62-119,
+    tganv2_cond/gen.py:64-124)."""
+    out = {}
+    for tag, cls, cond_dim in (('u', GenU, 0), ('c', GenC, 16)):
+        g = pour(cls(width=64, height=64, num_channels=1, cond_dim=cond_dim))
+        g.train()
+        B = 8
+        z = rnd(30, B, 256)
+        cond = rnd(31, B, cond_dim) if cond_dim else None
+        torch.manual_seed(5)
+        bts = [int(torch.randint(2, (1,))) for _ in range(3)]
+        torch.manual_seed(5)
+        fake = g(z, cond=cond)
+        loss = sum((f * rnd(40 + i, *f.shape)).sum() for i, f in enumerate(fake))
+        loss.backward()
+        out[tag + '_z'] = npy(z)
+        if cond is not None:
+            out[tag + '_cond'] = npy(cond)
+        out[tag + '_bts'] = np.array(bts)
+        for i, f in enumerate(fake):
+            out[tag + '_fake%d' % i] = npy(f)
+        pack_norms(tag + '_gn', grad_norms(g), out)
+        out[tag + '_g_fc.bias'] = npy(g.fc.bias.grad)
+        out[tag + '_g_render_blocks.3.conv.weight'] = npy(g.render_blocks[3].conv.weight.grad)
+        for k, v in g.state_dict().items():
+            if k.endswith('render_blocks.3.bn.running_mean') or k.endswith('render_blocks.3.bn.running_var') \
+                    or k.endswith('up0.main.inner_module.0.running_var'):
+                out[tag + '_buf_' + k] = npy(v)
+        g.eval()
+        with torch.no_grad():
+            vid = g(z[:2], cond=None if cond is None else cond[:2])
+        assert len(vid) == 1
+        out[tag + '_eval'] = npy(vid[0])
+    save('gen', **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def golden_steps():
+    """Losses of training iterations 0..2, reference loop body restated from trainer.py:199-267
+    (SURVEY Appendix B), uncond TGANv2 64x64x1, B=4, recipe weights, RSGAN + GP 0.5, Adam 2e-4."""
+    out = {}
+    B = 4
+    g = pour(GenU(width=64, height=64, num_channels=1))
+    d = pour(DisU(num_channels=1))
+    seed = 100                       # seeded AFTER construction: module ctors consume the global RNG
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    g.train()
+    d.train()
+    gan = CondGan(gen=g, discrims=[d], discrim_names=['video'])
+    losses = MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss())
+    optD = torch.optim.Adam([{'params': d.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = torch.optim.Adam([{'params': g.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    ss = Subsample()
+    fs = [8, 16, 32, 64]
+    lD_all, lG_all = [], []
+    for it in range(3):
+        x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
+        xs = []
+        for i in range(4):
+            xs.append(F.interpolate(x, size=(x.size(2), fs[i], fs[i])) if i != 3 else x)
+            x, _ = ss(x)
+        z = torch.randn(B, g.latent_size)
+        fake = gan(z, cond=None)
+        lD = gan.discrim_step(real=xs, fake=[f.detach() for f in fake], cond=None,
+                              loss=losses.discrim_loss, gp_lambda=0.5)
+        lD.backward()
+        if it == 0:
+            pack_norms('it0_D_gn', grad_norms(d), out)
+        optD.step()
+        _, _, real_pred = gan.all_discrim_forward(real=xs, cond=None, fake=None, loss=None)
+        g.zero_grad()
+        fc = d(x=fake, cond=None, xbar=None)
+        lG = torch.stack([losses.gen_loss(fake=ff[0], real=rr) for ff, rr in zip(fc, real_pred[0])]).mean()
+        lG.backward()
+        if it == 0:
+            pack_norms('it0_G_gn', grad_norms(g), out)
+        optG.step()
+        lD_all.append(float(lD))
+        lG_all.append(float(lG))
+        print('uncond it', it, float(lD), float(lG))
+    out['lossD'] = np.array(lD_all, dtype=np.float64)
+    out['lossG'] = np.array(lG_all, dtype=np.float64)
+    save('steps_uncond', **out)
+
+
+def golden_init():
+    """Checksums of `init(model, 'xavier')` after seeding 100 and constructing G then D
+    (train/setup.py:7-14, train/gan.py:60-70, util/torch/init.py:4-39)."""
+    out = {}
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    g = GenU(width=64, height=64, num_channels=1)
+    d = DisU(num_channels=1)
+    ref_init(g, 'xavier')
+    ref_init(d, 'xavier')
+    for tag, m in (('G', g), ('D', d)):
+        sd = m.state_dict()
+        keys = sorted(k for k, v in sd.items() if v.dtype.is_floating_point)
+        out[tag + '_keys'] = np.array(keys)
+        out[tag + '_sum'] = np.array([float(sd[k].double().sum()) for k in keys])
+        out[tag + '_abs'] = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    save('init_xavier', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init']
+    if 'layers' in which:
+        golden_layers()
+    if 'resnet3d' in which:
+        golden_resnet3d()
+    if 'gen' in which:
+        golden_gen()
+    if 'init' in which:
+        golden_init()
+    if 'steps' in which:
+        golden_steps()
