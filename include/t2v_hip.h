@@ -1,0 +1,159 @@
+/* t2v_hip.h — C ABI of libt2v_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the TGANv2
+ * training hot path of miguelmartin75/txt2vid.
+ *
+ * The reference has NO native layer (100 % Python on PyTorch); every entry point below
+ * replaces a *PyTorch operator call site* of the reference, cited as  <file>:<line>  relative to the
+ * reference root.  Conventions:
+ *   - plain pointers to DEVICE memory + sizes; no torch types; the caller owns every buffer
+ *     (kernels never allocate; workspaces are passed in);
+ *   - all tensors fp32, contiguous, NCDHW (2-D tensors are the D=1 case, Linear is D=H=W=1);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), nothing synchronises;
+ *   - return 0 on success, a negative T2V_E* code on a bad argument, the (negated) hipError_t
+ *     if the launch itself failed.  Nothing throws across the boundary.  No global state.
+ */
+#ifndef T2V_HIP_H
+#define T2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2V_OK 0
+#define T2V_EINVAL (-1)
+#define T2V_ELAUNCH (-2)
+
+#define T2V_MAX_TAPS 27
+
+/* Geometry of a stride-1, "same"-padded convolution (k in {1,3} per dim) — the only kind on the hot
+ * path: nn.Conv3d / nn.Conv2d call sites txt2vid/models/resnet3d.py:13-18, layers.py:174-183,231-238,
+ * 251, conv_lstm.py:19-26; nn.Linear (resnet3d.py:33-35, tganv2_cond/gen.py:39) is D=H=W=1,k=1.
+ * Only the `ntaps` kernel taps that can touch a non-padding voxel are listed (a dim of extent 1
+ * keeps its centre tap only): tap j has spatial offset (dz,dy,dx)[j] and sits at position j of the
+ * packed weight (see t2v_pack_weight). */
+typedef struct {
+    int32_t N, Cin, D, H, W, Cout;
+    int32_t ntaps;
+    int8_t dz[T2V_MAX_TAPS], dy[T2V_MAX_TAPS], dx[T2V_MAX_TAPS];
+    int8_t pad_[3];
+} t2v_conv_geom;
+
+#define T2V_CONV_BIAS 1      /* add bias[Cout] in the epilogue                                   */
+#define T2V_CONV_RELU_IN 2   /* apply max(.,0) to the input while gathering (ReLU->conv fusion)  */
+#define T2V_CONV_ACCUM 4     /* y += result instead of y = result                                */
+
+/* w[Cout][Cin][T] (PyTorch layout, T = kD*kH*kW) -> wp[ntaps][Cin][Cout] for the forward GEMM
+ * (mode 0: wp[j][ci][co] = w[co][ci][taps[j]]) or wp[ntaps][Cout][Cin] for the data-gradient GEMM
+ * (mode 1: wp[j][co][ci] = w[co][ci][T-1-taps[j]], i.e. the spatially mirrored kernel).
+ * `taps` is a HOST array of the ntaps original tap indices. */
+int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
+                    int mode, void* stream);
+
+/* y[N,Cout,D,H,W] = conv(x[N,Cin,D,H,W], wp) (+bias).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
+ * M = N*D*H*W voxels, N = Cout, K = ntaps*Cin.  The same entry point computes the data gradient
+ * when given the mode-1 packed weight (x := dL/dy, Cin := Cout_fwd, Cout := Cin_fwd).
+ * Replaces F.conv3d / F.conv2d / F.linear forward and their input-gradient
+ * (autograd of the call sites above; double backward for losses.py:178). */
+int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const t2v_conv_geom* g,
+                 int flags, void* stream);
+
+/* dw[Cout][Cin][T] = sum_m gy[m][co] * x[m + off(tap)][ci]   (weight gradient; PyTorch layout out).
+ * `slab` is a workspace of t2v_conv_wgrad_slab_floats(g, T) floats (split-K partial sums, reduced
+ * deterministically by a second kernel).  `taps`: HOST array, original tap index of geom tap j.
+ * flags: T2V_CONV_RELU_IN applies max(.,0) to x; T2V_CONV_ACCUM adds into dw. */
+int64_t t2v_conv_wgrad_slab_floats(const t2v_conv_geom* g);
+int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float* slab, const t2v_conv_geom* g,
+                   const int32_t* taps, int T, int flags, void* stream);
+
+/* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
+int t2v_channel_sum(const float* x, float* out, int N, int C, int64_t S, int accum, void* stream);
+
+/* ---- pointwise / pooling (txt2vid/models/layers.py, resnet3d.py) ------------------------------ */
+int t2v_relu(const float* x, float* y, int64_t n, void* stream);                 /* layers.py:172,230 */
+int t2v_relu_mask(const float* g, const float* x, float* gx, int64_t n, void* stream); /* g*(x>0)   */
+int t2v_add(const float* a, const float* b, float* y, int64_t n, void* stream);  /* layers.py:96     */
+int t2v_axpby(float alpha, const float* a, float beta, const float* b, float* y, int64_t n, void* stream);
+int t2v_scale_dev(const float* s, float mul, const float* a, float* y, int64_t n, void* stream); /* y = (*s*mul)*a */
+int t2v_dot(const float* a, const float* b, float* out, int64_t n, int accum, void* stream);
+int t2v_fill(float* y, float v, int64_t n, void* stream);
+int t2v_tanh(const float* x, float* y, int64_t n, void* stream);                 /* layers.py:258    */
+int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n, void* stream);
+
+/* avg_pool3d with per-dim kernel/stride/pad, count_include_pad=True (layers.py:217, resnet3d.py:16).
+ * bwd scatters g/(kd*kh*kw) back (windows never overlap on this path: stride >= kernel). */
+int t2v_avgpool3d(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+                  const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
+int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+                      const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
+
+/* max_pool [1,2,2] / [2,2] (layers.py:26-27,57-58): y + flat argmax index inside the (H,W) plane.
+ * `_scatter`: gx = 0 except gx[idx] = g;  `_gather`: y = x[idx]. */
+int t2v_maxpool2x2(const float* x, float* y, int32_t* idx, int64_t planes, int H, int W, void* stream);
+int t2v_maxpool2x2_scatter(const float* g, const int32_t* idx, float* gx, int64_t planes, int H, int W, void* stream);
+int t2v_maxpool2x2_gather(const float* x, const int32_t* idx, float* y, int64_t planes, int H, int W, void* stream);
+
+/* sum over the S = T*H*W voxels of each (n,c) row (resnet3d.py:48) and its broadcast adjoint. */
+int t2v_rowsum(const float* x, float* y, int64_t rows, int64_t S, void* stream);
+int t2v_rowbcast(const float* g, float* gx, int64_t rows, int64_t S, void* stream);
+
+/* nearest x2 up-sampling of (H,W) planes (nn.Upsample, layers.py:168,180) and its adjoint. */
+int t2v_upsample2x(const float* x, float* y, int64_t planes, int H, int W, void* stream);
+int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream);
+
+/* BatchNorm2d, training mode (layers.py:171,175,249): per-channel batch statistics over (N,H,W),
+ * running stats updated with `momentum` (unbiased variance), y = relu?((x-mean)*invstd*gamma+beta).
+ * stats[0:C] = mean, stats[C:2C] = invstd (saved for backward). */
+int t2v_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, int N, int C,
+                 int64_t S, float momentum, float eps, void* stream);
+int t2v_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
+                 int N, int C, int64_t S, int relu, void* stream);
+/* backward of bn_apply(+relu): needs y (for the relu mask) ; writes gx, ggamma[C], gbeta[C] */
+int t2v_bn_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma,
+               float* gx, float* ggamma, float* gbeta, float* ws /*2C floats*/, int N, int C, int64_t S,
+               int relu, void* stream);
+/* eval-mode affine: y = relu?((x-rm)*rsqrt(rv+eps)*gamma+beta) */
+int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta,
+                float* y, int N, int C, int64_t S, float eps, int relu, void* stream);
+
+/* ConvLSTM gate math (conv_lstm.py:32-38, peepholes are constant zeros):
+ * pre[4,B,C,S] (gate-major, order i,f,c,o) ; c_prev[B,C,S] -> h, c_new; act saved [4,B,C,S]
+ * (i,f,g,o after the non-linearities) for the backward; gpre likewise [4,B,C,S]. */
+int t2v_lstm_gates(const float* pre, const float* c_prev, float* h, float* c_new, float* act,
+                   int B, int64_t CS, void* stream);
+int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const float* act, const float* c_prev,
+                       const float* c_new, float* gpre, float* gc_prev, int B, int64_t CS, void* stream);
+
+/* ---- non-local block (layers.py:23-36, 52-68) -------------------------------------------------- */
+/* C[b] = alpha * op(A[b]) x op(B[b]); row-major A[b]: (ta? K x M : M x K), B[b]: (tb? N x K : K x N). */
+int t2v_bmm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int ta, int tb,
+            int accum, void* stream);
+int t2v_softmax(const float* x, float* y, int64_t rows, int n, void* stream);            /* layers.py:33 */
+int t2v_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, int n, void* stream);
+/* adjoint of softmax_bwd w.r.t. y: gyv = gg*(gy - s) - gy*sum(gg*y), s = sum(gy*y) */
+int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, float* out, int64_t rows, int n, void* stream);
+
+/* ---- losses (txt2vid/gan/losses.py) ------------------------------------------------------------ */
+/* RSGAN (losses.py:79-85): loss = mean softplus(-(a-b)) ; ga = -sigmoid(-(a-b))/n * gscale, gb = -ga. */
+int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* stream);
+int t2v_rsgan_bwd(const float* a, const float* b, const float* gloss, float* ga, float* gb, int n, void* stream);
+/* GP (losses.py:135-186): xhat = alpha[b]*xr + (1-alpha[b])*xf ; sq[b] = sum g^2 ; scale rows. */
+int t2v_lerp_rows(const float* alpha, const float* xr, const float* xf, float* y, int rows, int64_t S, void* stream);
+int t2v_row_sqnorm(const float* g, float* out, int rows, int64_t S, void* stream);
+int t2v_row_scale(const float* s, float mul, const float* g, float* y, int rows, int64_t S, void* stream);
+
+/* ---- optimiser (torch.optim.Adam call site txt2vid/train/gan.py:93-94) ------------------------- */
+int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+             float eps, float bc1, float bc2, float gscale, void* stream);
+
+/* ---- pyramid (trainer.py:131-165, layers.py:106-111) ------------------------------------------- */
+/* y[b,c,t,h,w] = x[b*sb, c, t*st+bt, (h*H)/Ho, (w*W)/Wo]  — Subsample + nearest F.interpolate. */
+int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
+                       int sb, int st, int bt, void* stream);
+
+const char* t2v_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,263 @@
+"""GPU: every C-ABI kernel (through txt2vid_amd.functional) against plain fp32 PyTorch CPU ops.
+Tolerances: fp32 MFMA is an exact fp32 fma chain; differences come from summation order only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(seed, *shape):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    scale = max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale)
+
+
+def ref_conv(x, w, b):
+    if x.dim() == 5:
+        return F.conv3d(x, w, b, padding=tuple(k // 2 for k in w.shape[2:]))
+    if x.dim() == 4:
+        return F.conv2d(x, w, b, padding=tuple(k // 2 for k in w.shape[2:]))
+    return F.linear(x, w, b)
+
+
+CONV_CASES = [
+    # (x shape, Cout, kernel)
+    ((2, 16, 4, 6, 6), 32, (3, 3, 3)),
+    ((3, 1, 4, 8, 8), 64, (3, 3, 3)),        # Cin=1: generic-K path
+    ((2, 3, 2, 5, 7), 8, (3, 3, 3)),         # Cin=3, odd sizes
+    ((2, 32, 1, 8, 8), 16, (3, 3, 3)),       # D=1: centre plane of taps only
+    ((5, 64, 1, 1, 1), 48, (3, 3, 3)),       # 1x1x1 map: centre tap only
+    ((2, 16, 3, 4, 4), 24, (1, 1, 1)),       # 1x1x1 kernel
+    ((4, 32, 6, 6), 1, (3, 3)),              # 2-D, Cout=1 (render block)
+    ((3, 64, 2, 2), 128, (3, 3)),            # 2-D tiny map
+    ((7, 80), 33, ()),                       # Linear
+    ((2, 64, 4, 32, 32), 64, (3, 3, 3)),     # bigger: 128x64 / 64x64 tiles
+    ((8, 32, 8, 64, 64), 128, (1, 1, 1)),    # M=262144, Cout=128 -> 128x128 tile
+]
+
+
+@pytest.mark.parametrize('xs,cout,k', CONV_CASES)
+def test_conv_fwd_bwd(xs, cout, k):
+    from txt2vid_amd import functional as TF
+    x = rnd(1, *xs)
+    w = rnd(2, cout, xs[1], *k) * 0.1
+    b = rnd(3, cout)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv(xr, wr, br)
+    gy = rnd(4, *yr.shape)
+    (yr * gy).sum().backward()
+    xd = x.to(dev()).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(dev()))
+    bd = torch.nn.Parameter(b.to(dev()))
+    yd = TF.conv(xd, wd, bd)
+    close(yd, yr)
+    (yd * gy.to(dev())).sum().backward()
+    close(xd.grad, xr.grad)
+    close(wd.grad, wr.grad, rtol=2e-4, atol=2e-4)
+    close(bd.grad, br.grad, rtol=2e-4, atol=2e-4)
+
+
+def test_conv_double_backward():
+    """R = || d(sum y*gy)/dx ||^2 differentiated w.r.t. w and gy-side input — the GP pattern."""
+    from txt2vid_amd import functional as TF
+    x = rnd(1, 2, 8, 3, 5, 5)
+    w1 = rnd(2, 16, 8, 3, 3, 3) * 0.2
+    w2 = rnd(3, 4, 16, 3, 3, 3) * 0.2
+
+    def run(x, w1, w2, conv, relu):
+        h = relu(conv(x, w1, None))
+        y = conv(h, w2, None)
+        gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
+        r = (gx ** 2).sum()
+        r.backward()
+        return r
+    xr, w1r, w2r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    rr = run(xr, w1r, w2r, lambda a, b, c: F.conv3d(a, b, c, padding=1), F.relu)
+    xd = x.to(dev()).requires_grad_(True)
+    w1d, w2d = torch.nn.Parameter(w1.to(dev())), torch.nn.Parameter(w2.to(dev()))
+    rd = run(xd, w1d, w2d, TF.conv, TF.relu)
+    close(rd, rr)
+    close(w1d.grad, w1r.grad, rtol=1e-3, atol=1e-3)
+    close(w2d.grad, w2r.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_avgpool():
+    from txt2vid_amd import functional as TF
+    for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),
+                           ((2, 3, 3, 5, 7), (2, 2, 2), (2, 2, 2), (1, 1, 1)),
+                           ((1, 2, 1, 4, 1), (1, 2, 1), (1, 2, 1), (0, 0, 0))):
+        x = rnd(1, *shape)
+        xr = x.clone().requires_grad_(True)
+        yr = F.avg_pool3d(xr, k, s, p)
+        gy = rnd(2, *yr.shape)
+        (yr * gy).sum().backward()
+        xd = x.to(dev()).requires_grad_(True)
+        yd = TF.avg_pool3d(xd, k, s, p)
+        close(yd, yr)
+        (yd * gy.to(dev())).sum().backward()
+        close(xd.grad, xr.grad)
+
+
+def test_maxpool_softmax_bmm_double_backward():
+    from txt2vid_amd import functional as TF
+    th, ph, gg = rnd(1, 2, 4, 16), rnd(2, 2, 4, 2, 4, 4), rnd(3, 2, 8, 2, 4, 4)
+
+    def run(th, ph, gv, mp, bmm, sm):
+        p = mp(ph).reshape(2, 4, -1)
+        g = mp(gv).reshape(2, 8, -1)
+        beta = sm(bmm(th, p, True, False))                 # [2,16,8]
+        o = bmm(g, beta, False, True)                      # [2,8,16]
+        go, = torch.autograd.grad((o ** 2).sum(), th, create_graph=True)
+        r = (go ** 2).sum() + o.sum()
+        r.backward()
+        return o, r
+
+    def ref_bmm(a, b, ta, tb):
+        return torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b)
+    a = [t.clone().requires_grad_(True) for t in (th, ph, gg)]
+    o_r, r_r = run(a[0], a[1], a[2], lambda t: F.max_pool3d(t, [1, 2, 2]), ref_bmm, lambda t: F.softmax(t, -1))
+    d = [t.to(dev()).requires_grad_(True) for t in (th, ph, gg)]
+    o_d, r_d = run(d[0], d[1], d[2], TF.max_pool2x2, TF.bmm, TF.softmax_lastdim)
+    close(o_d, o_r)
+    close(r_d, r_r)
+    for td, tr in zip(d, a):
+        close(td.grad, tr.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_scale_add_rowsum_double_backward():
+    from txt2vid_amd import functional as TF
+    gam, o, x = torch.tensor(0.7), rnd(1, 2, 3, 2, 2, 2), rnd(2, 2, 3, 2, 2, 2)
+
+    def run(gam, o, x, scale_add, ssum):
+        y = scale_add(gam, o * o, x)
+        f = ssum(y * y)
+        g, = torch.autograd.grad(f.sum(), o, create_graph=True)
+        r = (g ** 2).sum()
+        r.backward()
+        return f, r
+    a = [t.clone().requires_grad_(True) for t in (gam, o, x)]
+    f_r, r_r = run(a[0], a[1], a[2], lambda g, o, x: g * o + x, lambda t: t.sum([2, 3, 4]))
+    d = [t.to(dev()).requires_grad_(True) for t in (gam, o, x)]
+    f_d, r_d = run(d[0], d[1], d[2], TF.scale_add, TF.sum_spatial)
+    close(f_d, f_r)
+    close(r_d, r_r)
+    for td, tr in zip(d, a):
+        close(td.grad, tr.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_batchnorm_tanh_upsample():
+    from txt2vid_amd import functional as TF
+    x = rnd(1, 4, 6, 5, 5)
+    gamma, beta = 1 + 0.1 * rnd(2, 6), 0.1 * rnd(3, 6)
+    rm, rv = 0.1 * rnd(4, 6), 1 + 0.1 * torch.rand(6)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = torch.tanh(F.interpolate(F.relu(F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)), scale_factor=2))
+    gy = rnd(5, *yr.shape)
+    (yr * gy).sum().backward()
+    xd = x.to(dev()).requires_grad_(True)
+    gd, bd = torch.nn.Parameter(gamma.to(dev())), torch.nn.Parameter(beta.to(dev()))
+    rmd, rvd = rm.to(dev()), rv.to(dev())
+    yd = TF.tanh(TF.upsample2x(TF.batch_norm_act(xd, gd, bd, rmd, rvd, True, 0.1, 1e-5, True)))
+    close(yd, yr)
+    (yd * gy.to(dev())).sum().backward()
+    close(xd.grad, xr.grad, rtol=1e-3, atol=1e-4)
+    close(gd.grad, gr.grad, rtol=1e-3, atol=1e-4)
+    close(bd.grad, br.grad, rtol=1e-3, atol=1e-4)
+    close(rmd, rmr)
+    close(rvd, rvr)
+    # eval mode
+    ye = TF.batch_norm_act(x.to(dev()), gd, bd, rmd, rvd, False, 0.1, 1e-5, False)
+    close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
+
+
+@pytest.mark.parametrize('hw', [1, 2])
+def test_conv_lstm(hw):
+    from txt2vid_amd import functional as TF
+    from oracle import tganv2_oracle as O
+    C, B, steps = 16, 3, 5
+    shapes = {}
+    for gate in 'ifco':
+        shapes['Wx%s.weight' % gate] = (C, C, 3, 3)
+        shapes['Wx%s.bias' % gate] = (C,)
+        shapes['Wh%s.weight' % gate] = (C, C, 3, 3)
+    P = O.recipe_state(shapes)
+    for v in P.values():
+        v.mul_(3.0).requires_grad_(True)
+    x = rnd(1, B, C, hw, hw)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.stack(O.conv_lstm(P, '', xr, steps))
+    gy = rnd(2, *yr.shape)
+    (yr * gy).sum().backward()
+    Pd = {k: torch.nn.Parameter(v.detach().to(dev())) for k, v in P.items()}
+    xd = x.to(dev()).requires_grad_(True)
+    yd = TF.conv_lstm(xd, steps, [Pd['Wx%s.weight' % g] for g in 'ifco'], [Pd['Wx%s.bias' % g] for g in 'ifco'],
+                      [Pd['Wh%s.weight' % g] for g in 'ifco'])
+    close(yd, yr)
+    (yd * gy.to(dev())).sum().backward()
+    close(xd.grad, xr.grad, rtol=1e-3, atol=1e-4)
+    for k in P:
+        close(Pd[k].grad, P[k].grad, rtol=1e-3, atol=1e-4)
+
+
+def test_losses_and_gp_helpers():
+    from txt2vid_amd import functional as TF
+    a, b = rnd(1, 6, 1), rnd(2, 6, 1)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr = F.binary_cross_entropy_with_logits(ar - br, torch.ones_like(ar))
+    (lr * 1.7).backward()
+    ad, bd = a.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    ld = TF.rsgan(ad, bd)
+    close(ld, lr)
+    (ld * 1.7).backward()
+    close(ad.grad, ar.grad)
+    close(bd.grad, br.grad)
+    al, xr_, xf_ = torch.rand(3), rnd(3, 3, 2, 4, 4, 4), rnd(4, 3, 2, 4, 4, 4)
+    xh = TF.lerp_rows(al.to(dev()), xr_.to(dev()), xf_.to(dev()))
+    a5 = al.view(3, 1, 1, 1, 1)
+    close(xh, a5 * xr_ + (1 - a5) * xf_)
+    g = rnd(5, 3, 40)
+    gr_ = g.clone().requires_grad_(True)
+    (gr_.norm(2, dim=1) ** 2).sum().backward()
+    gd_ = g.to(dev()).requires_grad_(True)
+    sq = TF.row_sqnorm(gd_)
+    close(sq, g.norm(2, dim=1) ** 2)
+    sq.sum().backward()
+    close(gd_.grad, gr_.grad)
+
+
+def test_adam_matches_torch():
+    from txt2vid_amd import functional as TF
+    p, g1, g2 = rnd(1, 1000), rnd(2, 1000), rnd(3, 1000)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999))
+    pd = p.to(dev())
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step, g in enumerate((g1, g2), 1):
+        pr.grad = g.clone()
+        opt.step()
+        TF.adam_step(pd, g.to(dev()), m, v, 2e-4, 0.5, 0.999, 1e-8, step)
+        close(pd, pr, rtol=1e-6, atol=1e-7)
+
+
+def test_pyramid_gather():
+    from txt2vid_amd import functional as TF
+    x = rnd(1, 5, 2, 8, 16, 16)
+    for bt in (0, 1):
+        y = TF.pyramid_gather(x.to(dev()), 3, 4, 16, 16, 2, 2, bt)
+        close(y, x[::2, :, bt::2])
+    y = TF.pyramid_gather(x.to(dev()), 5, 8, 4, 4, 1, 1, 0)
+    close(y, F.interpolate(x, size=(8, 4, 4)))

@@ -1,0 +1,102 @@
+"""ctypes binding of libt2v_hip.so (C ABI declared in include/t2v_hip.h).
+
+The library holds every hand-written gfx950 kernel of the hot path. There is NO fallback: if the
+shared object is missing the import of this module raises, and every product op that reaches
+`lib()` on a machine without it fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libt2v_hip.so')
+
+MAX_TAPS = 27
+
+
+class ConvGeom(C.Structure):
+    """Mirror of `t2v_conv_geom` (include/t2v_hip.h)."""
+    _fields_ = [('N', C.c_int32), ('Cin', C.c_int32), ('D', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Cout', C.c_int32), ('ntaps', C.c_int32),
+                ('dz', C.c_int8 * MAX_TAPS), ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS),
+                ('pad_', C.c_int8 * 3)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_I3 = C.POINTER(C.c_int32)
+_G = C.POINTER(ConvGeom)
+
+# name -> argtypes (restype is int unless stated); must list EVERY symbol of include/t2v_hip.h
+SIGNATURES = {
+    't2v_pack_weight': [_P, _P, _I, _I, _I, _I3, _I, _I, _P],
+    't2v_conv_fwd': [_P, _P, _P, _P, _G, _I, _P],
+    't2v_conv_wgrad_slab_floats': [_G],
+    't2v_conv_wgrad': [_P, _P, _P, _P, _G, _I3, _I, _I, _P],
+    't2v_channel_sum': [_P, _P, _I, _I, _L, _I, _P],
+    't2v_relu': [_P, _P, _L, _P],
+    't2v_relu_mask': [_P, _P, _P, _L, _P],
+    't2v_add': [_P, _P, _P, _L, _P],
+    't2v_axpby': [_F, _P, _F, _P, _P, _L, _P],
+    't2v_scale_dev': [_P, _F, _P, _P, _L, _P],
+    't2v_dot': [_P, _P, _P, _L, _I, _P],
+    't2v_fill': [_P, _F, _L, _P],
+    't2v_tanh': [_P, _P, _L, _P],
+    't2v_tanh_bwd': [_P, _P, _P, _L, _P],
+    't2v_avgpool3d': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
+    't2v_avgpool3d_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
+    't2v_maxpool2x2': [_P, _P, _P, _L, _I, _I, _P],
+    't2v_maxpool2x2_scatter': [_P, _P, _P, _L, _I, _I, _P],
+    't2v_maxpool2x2_gather': [_P, _P, _P, _L, _I, _I, _P],
+    't2v_rowsum': [_P, _P, _L, _L, _P],
+    't2v_rowbcast': [_P, _P, _L, _L, _P],
+    't2v_upsample2x': [_P, _P, _L, _I, _I, _P],
+    't2v_upsample2x_bwd': [_P, _P, _L, _I, _I, _P],
+    't2v_bn_stats': [_P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
+    't2v_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
+    't2v_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
+    't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
+    't2v_lstm_gates': [_P, _P, _P, _P, _P, _I, _L, _P],
+    't2v_lstm_gates_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P],
+    't2v_bmm': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    't2v_softmax': [_P, _P, _L, _I, _P],
+    't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],
+    't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
+    't2v_rsgan': [_P, _P, _P, _I, _P],
+    't2v_rsgan_bwd': [_P, _P, _P, _P, _P, _I, _P],
+    't2v_lerp_rows': [_P, _P, _P, _P, _I, _L, _P],
+    't2v_row_sqnorm': [_P, _P, _I, _L, _P],
+    't2v_row_scale': [_P, _F, _P, _P, _I, _L, _P],
+    't2v_adam': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P],
+    't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    't2v_version': [],
+}
+_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_version': C.c_char_p}
+
+_lib = None
+
+
+class T2VError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if libt2v_hip.so has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise T2VError('libt2v_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C txt2vid_amd/csrc`. There is no CPU/PyTorch fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if a declared symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise T2VError('%s failed with status %d' % (what, status))

@@ -1,0 +1,661 @@
+// pointwise.hip — HBM-bound element-wise, pooling, normalisation, reduction, loss and optimiser
+// kernels of the TGANv2 hot path (gfx950). Lane-contiguous 4-/16-byte accesses, grid-stride loops
+// capped at 2048 workgroups (256 CUs x 8), wave64 shuffles for the row reductions.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/t2v_hip.h"
+
+static inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? T2V_OK : -(int)e - 1000;
+}
+static inline unsigned nblocks(long n, int per = 256) {
+    long b = (n + per - 1) / per;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+#define S_(stream) ((hipStream_t)(stream))
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for 256 threads; every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* red /*4 floats*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------- element-wise
+__global__ void relu_k(const float* x, float* y, long n) { GRID_STRIDE(i, n) y[i] = fmaxf(x[i], 0.f); }
+__global__ void relu_mask_k(const float* g, const float* x, float* gx, long n) { GRID_STRIDE(i, n) gx[i] = x[i] > 0.f ? g[i] : 0.f; }
+__global__ void add_k(const float* a, const float* b, float* y, long n) { GRID_STRIDE(i, n) y[i] = a[i] + b[i]; }
+__global__ void axpby_k(float al, const float* a, float be, const float* b, float* y, long n) {
+    GRID_STRIDE(i, n) y[i] = al * a[i] + (b ? be * b[i] : 0.f);
+}
+__global__ void scale_dev_k(const float* s, float mul, const float* a, float* y, long n) {
+    const float f = s[0] * mul;
+    GRID_STRIDE(i, n) y[i] = f * a[i];
+}
+__global__ void fill_k(float* y, float v, long n) { GRID_STRIDE(i, n) y[i] = v; }
+__global__ void tanh_k(const float* x, float* y, long n) { GRID_STRIDE(i, n) y[i] = tanhf(x[i]); }
+__global__ void tanh_bwd_k(const float* g, const float* y, float* gx, long n) { GRID_STRIDE(i, n) gx[i] = g[i] * (1.f - y[i] * y[i]); }
+
+extern "C" int t2v_relu(const float* x, float* y, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(relu_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_relu_mask(const float* g, const float* x, float* gx, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(relu_mask_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, x, gx, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_add(const float* a, const float* b, float* y, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(add_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, y, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_axpby(float al, const float* a, float be, const float* b, float* y, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(axpby_k, dim3(nblocks(n)), dim3(256), 0, S_(st), al, a, be, b, y, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_scale_dev(const float* s, float mul, const float* a, float* y, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(scale_dev_k, dim3(nblocks(n)), dim3(256), 0, S_(st), s, mul, a, y, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_fill(float* y, float v, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(fill_k, dim3(nblocks(n)), dim3(256), 0, S_(st), y, v, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_tanh(const float* x, float* y, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(tanh_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
+    return launch_status();
+}
+extern "C" int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n, void* st) {
+    if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
+    hipLaunchKernelGGL(tanh_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, y, gx, (long)n);
+    return launch_status();
+}
+
+// dot product: single workgroup chain (deterministic). n is small on this path (<= a few M).
+__global__ __launch_bounds__(256) void dot_k(const float* a, const float* b, float* out, long n, int accum) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = accum ? out[0] + s : s;
+}
+extern "C" int t2v_dot(const float* a, const float* b, float* out, int64_t n, int accum, void* st) {
+    if (n <= 0) return T2V_EINVAL;
+    hipLaunchKernelGGL(dot_k, dim3(1), dim3(256), 0, S_(st), a, b, out, (long)n, accum);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- avg-pool (count_include_pad)
+struct Pool3 { int k[3], s[3], p[3]; };
+
+__global__ void avgpool3d_k(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo, Pool3 q) {
+    const long n = (long)NC * Do * Ho * Wo;
+    const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
+    GRID_STRIDE(i, n) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; r /= Ho;
+        int d_o = r % Do; long nc = r / Do;
+        const float* px = x + nc * (long)D * H * W;
+        float acc = 0.f;
+        for (int a = 0; a < q.k[0]; ++a) {
+            int d = d_o * q.s[0] - q.p[0] + a;
+            if ((unsigned)d >= (unsigned)D) continue;
+            for (int b = 0; b < q.k[1]; ++b) {
+                int h = ho * q.s[1] - q.p[1] + b;
+                if ((unsigned)h >= (unsigned)H) continue;
+                for (int c = 0; c < q.k[2]; ++c) {
+                    int w = wo * q.s[2] - q.p[2] + c;
+                    if ((unsigned)w >= (unsigned)W) continue;
+                    acc += px[((long)d * H + h) * W + w];
+                }
+            }
+        }
+        y[i] = acc * inv;
+    }
+}
+// adjoint (gather form): gx[d,h,w] = sum over windows containing it of gy/vol. stride >= kernel on this
+// path, but the general overlap case is handled as well.
+__global__ void avgpool3d_bwd_k(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo, Pool3 q) {
+    const long n = (long)NC * D * H * W;
+    const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
+    GRID_STRIDE(i, n) {
+        int w = i % W; long r = i / W;
+        int h = r % H; r /= H;
+        int d = r % D; long nc = r / D;
+        const float* pg = gy + nc * (long)Do * Ho * Wo;
+        float acc = 0.f;
+        for (int a = 0; a < q.k[0]; ++a) {
+            int td = d + q.p[0] - a;
+            if (td < 0 || td % q.s[0]) continue;
+            int d_o = td / q.s[0];
+            if (d_o >= Do) continue;
+            for (int b = 0; b < q.k[1]; ++b) {
+                int th = h + q.p[1] - b;
+                if (th < 0 || th % q.s[1]) continue;
+                int ho = th / q.s[1];
+                if (ho >= Ho) continue;
+                for (int c = 0; c < q.k[2]; ++c) {
+                    int tw = w + q.p[2] - c;
+                    if (tw < 0 || tw % q.s[2]) continue;
+                    int wo = tw / q.s[2];
+                    if (wo >= Wo) continue;
+                    acc += pg[((long)d_o * Ho + ho) * Wo + wo];
+                }
+            }
+        }
+        gx[i] = acc * inv;
+    }
+}
+static bool pool_ok(const int32_t* k, const int32_t* s, const int32_t* p) {
+    for (int i = 0; i < 3; ++i)
+        if (k[i] < 1 || k[i] > 4 || s[i] < 1 || p[i] < 0) return false;
+    return true;
+}
+extern "C" int t2v_avgpool3d(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+                             const int32_t k[3], const int32_t s[3], const int32_t p[3], void* st) {
+    if (!x || !y || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
+    Pool3 q;
+    for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
+    hipLaunchKernelGGL(avgpool3d_k, dim3(nblocks((long)NC * Do * Ho * Wo)), dim3(256), 0, S_(st), x, y, NC, D, H, W, Do, Ho, Wo, q);
+    return launch_status();
+}
+extern "C" int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+                                 const int32_t k[3], const int32_t s[3], const int32_t p[3], void* st) {
+    if (!gy || !gx || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
+    Pool3 q;
+    for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
+    hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- 2x2 max-pool over (H,W) planes (floor)
+__global__ void maxpool2x2_k(const float* x, float* y, int32_t* idx, long planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = planes * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; long pl = r / Ho;
+        const float* px = x + pl * (long)H * W;
+        int best = (2 * ho) * W + 2 * wo;
+        float bv = px[best];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                int id = (2 * ho + a) * W + 2 * wo + b;
+                float v = px[id];
+                if (v > bv || (v != v && bv == bv)) { bv = v; best = id; }   // first max wins; NaN propagates
+            }
+        y[i] = bv;
+        idx[i] = best;
+    }
+}
+__global__ void maxpool2x2_scatter_k(const float* g, const int32_t* idx, float* gx, long planes, int H, int W) {
+    // every input element belongs to at most one window -> gather form, no atomics
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = planes * H * W;
+    GRID_STRIDE(i, n) {
+        int w = i % W; long r = i / W;
+        int h = r % H; long pl = r / H;
+        int ho = h >> 1, wo = w >> 1;
+        float v = 0.f;
+        if (ho < Ho && wo < Wo) {
+            long o = (pl * Ho + ho) * Wo + wo;
+            if (idx[o] == h * W + w) v = g[o];
+        }
+        gx[i] = v;
+    }
+}
+__global__ void maxpool2x2_gather_k(const float* x, const int32_t* idx, float* y, long planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = planes * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        long pl = i / ((long)Ho * Wo);
+        y[i] = x[pl * (long)H * W + idx[i]];
+    }
+}
+extern "C" int t2v_maxpool2x2(const float* x, float* y, int32_t* idx, int64_t planes, int H, int W, void* st) {
+    if (!x || !y || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
+    hipLaunchKernelGGL(maxpool2x2_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, y, idx, (long)planes, H, W);
+    return launch_status();
+}
+extern "C" int t2v_maxpool2x2_scatter(const float* g, const int32_t* idx, float* gx, int64_t planes, int H, int W, void* st) {
+    if (!g || !gx || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
+    hipLaunchKernelGGL(maxpool2x2_scatter_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), g, idx, gx, (long)planes, H, W);
+    return launch_status();
+}
+extern "C" int t2v_maxpool2x2_gather(const float* x, const int32_t* idx, float* y, int64_t planes, int H, int W, void* st) {
+    if (!x || !y || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
+    hipLaunchKernelGGL(maxpool2x2_gather_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, idx, y, (long)planes, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- row reductions (one wave per row)
+__global__ __launch_bounds__(256) void rowsum_k(const float* x, float* y, long rows, long S) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + row * S;
+    float acc = 0.f;
+    for (long i = threadIdx.x & 63; i < S; i += 64) acc += p[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) y[row] = acc;
+}
+__global__ void rowbcast_k(const float* g, float* gx, long rows, long S) {
+    const long n = rows * S;
+    GRID_STRIDE(i, n) gx[i] = g[i / S];
+}
+extern "C" int t2v_rowsum(const float* x, float* y, int64_t rows, int64_t S, void* st) {
+    if (!x || !y || rows < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, (long)S);
+    return launch_status();
+}
+extern "C" int t2v_rowbcast(const float* g, float* gx, int64_t rows, int64_t S, void* st) {
+    if (!g || !gx || rows < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(rowbcast_k, dim3(nblocks(rows * S)), dim3(256), 0, S_(st), g, gx, (long)rows, (long)S);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- nearest x2 up-sampling
+__global__ void upsample2x_k(const float* x, float* y, long planes, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long n = planes * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; long pl = r / Ho;
+        y[i] = x[(pl * H + (ho >> 1)) * W + (wo >> 1)];
+    }
+}
+__global__ void upsample2x_bwd_k(const float* gy, float* gx, long planes, int H, int W) {
+    const int Wo = 2 * W;
+    const long n = planes * H * W;
+    GRID_STRIDE(i, n) {
+        int w = i % W; long r = i / W;
+        int h = r % H; long pl = r / H;
+        const float* p = gy + ((pl * 2 * H + 2 * h) * Wo + 2 * w);
+        gx[i] = (p[0] + p[1]) + (p[Wo] + p[Wo + 1]);
+    }
+}
+extern "C" int t2v_upsample2x(const float* x, float* y, int64_t planes, int H, int W, void* st) {
+    if (!x || !y || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, y, (long)planes, H, W);
+    return launch_status();
+}
+extern "C" int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* st) {
+    if (!gy || !gx || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(upsample2x_bwd_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), gy, gx, (long)planes, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- BatchNorm2d (training)
+// one workgroup per channel; two-pass (mean, then centred second moment) for accuracy.
+__global__ __launch_bounds__(256) void bn_stats_k(const float* x, float* stats, float* rmean, float* rvar, int N, int C,
+                                                  long S, float momentum, float eps) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const long cnt = (long)N * S;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + ((long)n * C + c) * S;
+        for (long i = threadIdx.x; i < S; i += 256) acc += p[i];
+    }
+    const float mean = block_sum(acc, red) / (float)cnt;
+    acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + ((long)n * C + c) * S;
+        for (long i = threadIdx.x; i < S; i += 256) { float d = p[i] - mean; acc += d * d; }
+    }
+    const float m2 = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float var = m2 / (float)cnt;
+        stats[c] = mean;
+        stats[C + c] = 1.f / sqrtf(var + eps);
+        if (rmean) {
+            const float unb = cnt > 1 ? m2 / (float)(cnt - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
+    }
+}
+__global__ void bn_apply_k(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int N, int C,
+                           long S, int relu) {
+    const long n = (long)N * C * S;
+    GRID_STRIDE(i, n) {
+        const int c = (i / S) % C;
+        float v = (x[i] - stats[c]) * stats[C + c] * gamma[c] + beta[c];
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+// pass 1: per channel sums  ws[c] = sum g', ws[C+c] = sum g' * xhat   (g' = gy masked by relu)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* gy, const float* x, const float* y, const float* stats,
+                                                       float* ws, float* ggamma, float* gbeta, int N, int C, long S, int relu) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const float mean = stats[c], istd = stats[C + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + c) * S;
+        for (long i = threadIdx.x; i < S; i += 256) {
+            float g = gy[base + i];
+            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            s1 += g;
+            s2 += g * (x[base + i] - mean) * istd;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        ws[c] = s1; ws[C + c] = s2;
+        gbeta[c] = s1; ggamma[c] = s2;
+    }
+}
+__global__ void bn_bwd_apply_k(const float* gy, const float* x, const float* y, const float* stats, const float* gamma,
+                               const float* ws, float* gx, int N, int C, long S, int relu) {
+    const long n = (long)N * C * S;
+    const float invcnt = 1.f / (float)((long)N * S);
+    GRID_STRIDE(i, n) {
+        const int c = (i / S) % C;
+        float g = gy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        const float istd = stats[C + c];
+        const float xh = (x[i] - stats[c]) * istd;
+        gx[i] = gamma[c] * istd * (g - ws[c] * invcnt - xh * ws[C + c] * invcnt);
+    }
+}
+__global__ void bn_eval_k(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,
+                          int N, int C, long S, float eps, int relu) {
+    const long n = (long)N * C * S;
+    GRID_STRIDE(i, n) {
+        const int c = (i / S) % C;
+        float v = (x[i] - rm[c]) * (1.f / sqrtf(rv[c] + eps)) * gamma[c] + beta[c];
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+extern "C" int t2v_bn_stats(const float* x, float* stats, float* rm, float* rv, int N, int C, int64_t S, float momentum,
+                            float eps, void* st) {
+    if (!x || !stats || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(bn_stats_k, dim3(C), dim3(256), 0, S_(st), x, stats, rm, rv, N, C, (long)S, momentum, eps);
+    return launch_status();
+}
+extern "C" int t2v_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int N, int C,
+                            int64_t S, int relu, void* st) {
+    if (!x || !stats || !gamma || !beta || !y || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(bn_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, stats, gamma, beta, y, N, C, (long)S, relu);
+    return launch_status();
+}
+extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
+                          float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* st) {
+    if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    if (relu && !y) return T2V_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C), dim3(256), 0, S_(st), gy, x, y, stats, ws, ggamma, gbeta, N, C, (long)S, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
+    return launch_status();
+}
+extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,
+                           int N, int C, int64_t S, float eps, int relu, void* st) {
+    if (!x || !rm || !rv || !gamma || !beta || !y || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(bn_eval_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, rm, rv, gamma, beta, y, N, C, (long)S, eps, relu);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- ConvLSTM gates
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+// gate-major layout: pre/act/gpre are [4][B*CS] (i,f,c,o) so that each gate's convolution writes a
+// dense [B,C,h,w] block.
+__global__ void lstm_gates_k(const float* pre, const float* c_prev, float* h, float* c_new, float* act, int B, long CS) {
+    const long n = (long)B * CS;
+    GRID_STRIDE(i, n) {
+        const float gi = sigm(pre[i]), gf = sigm(pre[n + i]), gg = tanhf(pre[2 * n + i]), go = sigm(pre[3 * n + i]);
+        const float cc = gf * c_prev[i] + gi * gg;
+        c_new[i] = cc;
+        h[i] = go * tanhf(cc);
+        act[i] = gi; act[n + i] = gf; act[2 * n + i] = gg; act[3 * n + i] = go;
+    }
+}
+__global__ void lstm_gates_bwd_k(const float* gh, const float* gc_in, const float* act, const float* c_prev, const float* c_new,
+                                 float* gpre, float* gc_prev, int B, long CS) {
+    const long n = (long)B * CS;
+    GRID_STRIDE(i, n) {
+        const float gi = act[i], gf = act[n + i], gg = act[2 * n + i], go = act[3 * n + i];
+        const float tc = tanhf(c_new[i]);
+        const float dh = gh[i];
+        const float dc = dh * go * (1.f - tc * tc) + (gc_in ? gc_in[i] : 0.f);
+        gpre[i] = dc * gg * gi * (1.f - gi);
+        gpre[n + i] = dc * c_prev[i] * gf * (1.f - gf);
+        gpre[2 * n + i] = dc * gi * (1.f - gg * gg);
+        gpre[3 * n + i] = dh * tc * go * (1.f - go);
+        gc_prev[i] = dc * gf;
+    }
+}
+extern "C" int t2v_lstm_gates(const float* pre, const float* c_prev, float* h, float* c_new, float* act, int B, int64_t CS, void* st) {
+    if (!pre || !c_prev || !h || !c_new || !act || B < 1 || CS < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(lstm_gates_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), pre, c_prev, h, c_new, act, B, (long)CS);
+    return launch_status();
+}
+extern "C" int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const float* act, const float* c_prev, const float* c_new,
+                                  float* gpre, float* gc_prev, int B, int64_t CS, void* st) {
+    if (!gh || !act || !c_prev || !c_new || !gpre || !gc_prev || B < 1 || CS < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(lstm_gates_bwd_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), gh, gc_in, act, c_prev, c_new, gpre, gc_prev, B, (long)CS);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- non-local block
+// Batched thin GEMM: head dims are 4..64, so no MFMA tile fits; 16x16 output tile per workgroup,
+// K staged through LDS in 16-wide slabs.
+__global__ __launch_bounds__(256) void bmm_k(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, int accum) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int b = blockIdx.z;
+    const float* a = A + (long)b * M * K;
+    const float* bb = B + (long)b * K * N;
+    float* c = C + (long)b * M * N;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        {   // A tile: As[ty][tx] = opA[row0+ty][k0+tx]
+            int r = blockIdx.y * 16 + ty, k = k0 + tx;
+            As[ty][tx] = (r < M && k < K) ? (ta ? a[(long)k * M + r] : a[(long)r * K + k]) : 0.f;
+            int kk = k0 + ty, cc = blockIdx.x * 16 + tx;
+            Bs[ty][tx] = (kk < K && cc < N) ? (tb ? bb[(long)cc * K + kk] : bb[(long)kk * N + cc]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    if (row < M && col < N) c[(long)row * N + col] = accum ? c[(long)row * N + col] + acc : acc;
+}
+extern "C" int t2v_bmm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int ta, int tb, int accum, void* st) {
+    if (!A || !B || !C || batch < 1 || M < 1 || N < 1 || K < 1 || batch > 65535) return T2V_EINVAL;
+    dim3 grid((N + 15) / 16, (M + 15) / 16, batch);
+    hipLaunchKernelGGL(bmm_k, grid, dim3(256), 0, S_(st), A, B, C, M, N, K, ta, tb, accum);
+    return launch_status();
+}
+
+// softmax over the last dim: one wave per row, wavefront reductions
+__global__ __launch_bounds__(256) void softmax_k(const float* x, float* y, long rows, int n) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + row * n;
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, p[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(p[i] - mx);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int i = lane; i < n; i += 64) y[row * n + i] = expf(p[i] - mx) * inv;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_k(const float* y, const float* gy, float* gx, long rows, int n) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* py = y + row * n;
+    const float* pg = gy + row * n;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += pg[i] * py[i];
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) gx[row * n + i] = py[i] * (pg[i] - s);
+}
+__global__ __launch_bounds__(256) void softmax_bwd_bwd_y_k(const float* y, const float* gy, const float* gg, float* out, long rows, int n) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* py = y + row * n;
+    const float* pg = gy + row * n;
+    const float* pq = gg + row * n;
+    float s = 0.f, u = 0.f;
+    for (int i = lane; i < n; i += 64) { s += pg[i] * py[i]; u += pq[i] * py[i]; }
+    s = wave_sum(s);
+    u = wave_sum(u);
+    for (int i = lane; i < n; i += 64) out[row * n + i] = pq[i] * (pg[i] - s) - pg[i] * u;
+}
+extern "C" int t2v_softmax(const float* x, float* y, int64_t rows, int n, void* st) {
+    if (!x || !y || rows < 1 || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(softmax_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, n);
+    return launch_status();
+}
+extern "C" int t2v_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, int n, void* st) {
+    if (!y || !gy || !gx || rows < 1 || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(softmax_bwd_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gx, (long)rows, n);
+    return launch_status();
+}
+extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, float* out, int64_t rows, int n, void* st) {
+    if (!y || !gy || !gg || !out || rows < 1 || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(softmax_bwd_bwd_y_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gg, out, (long)rows, n);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- losses
+__device__ __forceinline__ float softplus(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
+
+__global__ __launch_bounds__(256) void rsgan_k(const float* a, const float* b, float* loss, int n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += softplus(-(a[i] - b[i]));   // BCEWithLogits(a-b, 1)
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+__global__ void rsgan_bwd_k(const float* a, const float* b, const float* gl, float* ga, float* gb, int n) {
+    const float sc = gl[0] / (float)n;
+    GRID_STRIDE(i, n) {
+        const float d = a[i] - b[i];
+        const float g = -sc / (1.f + expf(d));          // d/dd softplus(-d) = -sigmoid(-d)
+        if (ga) ga[i] = g;
+        if (gb) gb[i] = -g;
+    }
+}
+extern "C" int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* st) {
+    if (!a || !b || !loss || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(rsgan_k, dim3(1), dim3(256), 0, S_(st), a, b, loss, n);
+    return launch_status();
+}
+extern "C" int t2v_rsgan_bwd(const float* a, const float* b, const float* gl, float* ga, float* gb, int n, void* st) {
+    if (!a || !b || !gl || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(rsgan_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, gl, ga, gb, n);
+    return launch_status();
+}
+
+__global__ void lerp_rows_k(const float* alpha, const float* xr, const float* xf, float* y, int rows, long S) {
+    const long n = (long)rows * S;
+    GRID_STRIDE(i, n) {
+        const float a = alpha[i / S];
+        y[i] = a * xr[i] + (1.f - a) * xf[i];
+    }
+}
+__global__ __launch_bounds__(256) void row_sqnorm_k(const float* g, float* out, int rows, long S) {
+    __shared__ float red[4];
+    const float* p = g + (long)blockIdx.x * S;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < S; i += 256) acc += p[i] * p[i];
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ void row_scale_k(const float* s, float mul, const float* g, float* y, int rows, long S) {
+    const long n = (long)rows * S;
+    GRID_STRIDE(i, n) y[i] = s[i / S] * mul * g[i];
+}
+extern "C" int t2v_lerp_rows(const float* alpha, const float* xr, const float* xf, float* y, int rows, int64_t S, void* st) {
+    if (!alpha || !xr || !xf || !y || rows < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(lerp_rows_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), alpha, xr, xf, y, rows, (long)S);
+    return launch_status();
+}
+extern "C" int t2v_row_sqnorm(const float* g, float* out, int rows, int64_t S, void* st) {
+    if (!g || !out || rows < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(row_sqnorm_k, dim3(rows), dim3(256), 0, S_(st), g, out, rows, (long)S);
+    return launch_status();
+}
+extern "C" int t2v_row_scale(const float* s, float mul, const float* g, float* y, int rows, int64_t S, void* st) {
+    if (!s || !g || !y || rows < 1 || S < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(row_scale_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), s, mul, g, y, rows, (long)S);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam semantics)
+__global__ void adam_k(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2, float gscale) {
+    const float step = lr / bc1;
+    const float isq = 1.f / sqrtf(bc2);
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;          // exp_avg.lerp_(grad, 1-b1)
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;     // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * isq + eps;             // (sqrt(v)/sqrt(bc2)).add_(eps)
+        p[i] = p[i] - step * (mi / denom);                     // addcdiv_(m, denom, -lr/bc1)
+    }
+}
+extern "C" int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                        float bc1, float bc2, float gscale, void* st) {
+    if (!p || !g || !m || !v || n < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------- pyramid gather
+__global__ void pyramid_gather_k(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
+                                 int sb, int stt, int bt) {
+    const long n = (long)Bo * C * To * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; r /= Ho;
+        int to = r % To; r /= To;
+        int c = r % C; int bo = r / C;
+        // nearest: src = floor(dst * in / out)  (F.interpolate default mode)
+        const int h = (int)(((long)ho * H) / Ho), w = (int)(((long)wo * W) / Wo);
+        y[i] = x[((((long)bo * sb) * C + c) * T + (to * stt + bt)) * (long)H * W + (long)h * W + w];
+    }
+}
+extern "C" int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
+                                  int sb, int stt, int bt, void* st) {
+    if (!x || !y || B < 1 || C < 1 || T < 1 || Bo < 1 || To < 1 || Ho < 1 || Wo < 1) return T2V_EINVAL;
+    if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + bt >= T) return T2V_EINVAL;
+    hipLaunchKernelGGL(pyramid_gather_k, dim3(nblocks((long)Bo * C * To * Ho * Wo)), dim3(256), 0, S_(st), x, y, B, C, T, H, W, Bo, To, Ho, Wo, sb, stt, bt);
+    return launch_status();
+}
+
+extern "C" const char* t2v_version(void) { return "t2v_hip 0.1 (gfx950, fp32 MFMA)"; }

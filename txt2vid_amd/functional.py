@@ -1,0 +1,916 @@
+"""Autograd surface over the C-ABI kernels (include/t2v_hip.h).
+
+Every op on the TGANv2 hot path is a `torch.autograd.Function` whose forward AND backward launch
+hand-written gfx950 kernels through ctypes on torch's current HIP stream. torch is used only for
+device memory (torch.empty), the stream and the autograd graph bookkeeping.
+
+The discriminator ops are *closed under differentiation*: the backward of each Function is itself
+written with Functions of this module, so `torch.autograd.grad(..., create_graph=True)` — the
+gradient penalty of txt2vid/gan/losses.py:178 — yields a graph whose own backward again runs only
+these kernels (conv fwd <-> dgrad <-> wgrad form a closed triple).
+"""
+import contextlib
+import ctypes as C
+import weakref
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import lib, check, ConvGeom, MAX_TAPS
+
+FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM = 1, 2, 4
+
+# ------------------------------------------------------------------------------------------------
+# small helpers
+# ------------------------------------------------------------------------------------------------
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _c(t):
+    """contiguous fp32 device tensor (kernels assume dense NCDHW)."""
+    if t.dtype != torch.float32:
+        raise TypeError('t2v kernels are fp32, got %s' % t.dtype)
+    if not t.is_cuda:
+        raise RuntimeError('t2v kernels need device tensors: the HIP path has no CPU fallback')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_param_grads_enabled = True
+WEIGHT_EPOCH = 0     # bumped by the optimiser after each in-place update (invalidates packed weights)
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Inside this context the backward of conv/linear ops computes only the data gradient.
+    Used around the `autograd.grad(outputs, inputs=[x_hat])` sweep of the gradient penalty, where
+    torch would otherwise make every custom Function produce (and record a graph for) weight
+    gradients nobody asked for (`ctx.needs_input_grad` is static for Python Functions)."""
+    global _param_grads_enabled
+    old = _param_grads_enabled
+    _param_grads_enabled = False
+    try:
+        yield
+    finally:
+        _param_grads_enabled = old
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution geometry + packed-weight cache
+# ------------------------------------------------------------------------------------------------
+
+class _Geom(object):
+    __slots__ = ('cg', 'taps', 'taps_c', 'T', 'mask', 'kshape')
+
+
+_geom_cache = {}
+
+
+def conv_geom(N, Cin, D, H, W, Cout, kD, kH, kW):
+    key = (N, Cin, D, H, W, Cout, kD, kH, kW)
+    g = _geom_cache.get(key)
+    if g is not None:
+        return g
+    for k in (kD, kH, kW):
+        if k not in (1, 3):
+            raise ValueError('only 1- and 3-wide stride-1 same-padded kernels are on the hot path')
+    cg = ConvGeom()
+    cg.N, cg.Cin, cg.D, cg.H, cg.W, cg.Cout = N, Cin, D, H, W, Cout
+    taps = []
+    for a in range(kD):
+        for b in range(kH):
+            for c in range(kW):
+                dz, dy, dx = a - kD // 2, b - kH // 2, c - kW // 2
+                if (D == 1 and dz != 0) or (H == 1 and dy != 0) or (W == 1 and dx != 0):
+                    continue                          # this tap only ever multiplies padding
+                j = len(taps)
+                cg.dz[j], cg.dy[j], cg.dx[j] = dz, dy, dx
+                taps.append((a * kH + b) * kW + c)
+    cg.ntaps = len(taps)
+    g = _Geom()
+    g.cg, g.taps, g.T, g.kshape = cg, taps, kD * kH * kW, (kD, kH, kW)
+    g.taps_c = (C.c_int32 * len(taps))(*taps)
+    g.mask = sum(1 << t for t in taps)
+    _geom_cache[key] = g
+    return g
+
+
+_pack_cache = {}
+
+
+def packed_weight(w5, geom, mode):
+    """wp[ntaps][Cin][Cout] (mode 0) / wp[ntaps][Cout][Cin] mirrored (mode 1), cached per
+    (parameter, tap set, mode) until the weight changes."""
+    Cout, Cin = w5.shape[0], w5.shape[1]
+    base = w5._base if w5._base is not None else w5          # 2-D convs / Linear arrive as 5-D views
+    cacheable = isinstance(base, torch.nn.Parameter)
+    key = (id(base), tuple(w5.shape), geom.mask, mode)
+    tag = (base._version, WEIGHT_EPOCH, w5.data_ptr())
+    if cacheable:
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[0]() is base and hit[1] == tag:
+            return hit[2]
+    wp = torch.empty((len(geom.taps), Cin * Cout), device=w5.device, dtype=torch.float32)
+    check(lib().t2v_pack_weight(_p(w5), _p(wp), Cout, Cin, geom.T, geom.taps_c, len(geom.taps), mode, _stream()),
+          't2v_pack_weight')
+    if cacheable:
+        _pack_cache[key] = (weakref.ref(base), tag, wp)
+    return wp
+
+
+def _as5(t):
+    """view [N,C] / [N,C,H,W] / [N,C,D,H,W] as 5-D."""
+    if t.dim() == 5:
+        return t
+    if t.dim() == 4:
+        return t.unsqueeze(2)
+    if t.dim() == 2:
+        return t.view(t.size(0), t.size(1), 1, 1, 1)
+    raise ValueError('expected a 2-, 4- or 5-D tensor')
+
+
+def _geom_for(x5, w5):
+    return conv_geom(x5.shape[0], w5.shape[1], x5.shape[2], x5.shape[3], x5.shape[4], w5.shape[0],
+                     w5.shape[2], w5.shape[3], w5.shape[4])
+
+
+def conv_fwd_raw(x5, w5, bias=None, relu_in=False, out=None, accum=False):
+    x5, w5 = _c(x5), _c(w5)
+    g = _geom_for(x5, w5)
+    wp = packed_weight(w5, g, 0)
+    y = out if out is not None else torch.empty((x5.shape[0], w5.shape[0]) + tuple(x5.shape[2:]), device=x5.device,
+                                                dtype=torch.float32)
+    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0)
+    check(lib().t2v_conv_fwd(_p(x5), _p(wp), _p(bias), _p(y), C.byref(g.cg), flags, _stream()), 't2v_conv_fwd')
+    return y
+
+
+def conv_dgrad_raw(gy5, w5, out=None, accum=False):
+    """gx[N,Cin,...] = sum_taps,co gy * w (mirrored): the forward kernel on the mode-1 packed weight."""
+    gy5, w5 = _c(gy5), _c(w5)
+    Cout, Cin = w5.shape[0], w5.shape[1]
+    # geometry of the transposed problem: input channels = Cout, output channels = Cin
+    gt = conv_geom(gy5.shape[0], Cout, gy5.shape[2], gy5.shape[3], gy5.shape[4], Cin, w5.shape[2], w5.shape[3], w5.shape[4])
+    wp = packed_weight(w5, gt, 1)
+    gx = out if out is not None else torch.empty((gy5.shape[0], Cin) + tuple(gy5.shape[2:]), device=gy5.device,
+                                                 dtype=torch.float32)
+    check(lib().t2v_conv_fwd(_p(gy5), _p(wp), None, _p(gx), C.byref(gt.cg), FLAG_ACCUM if accum else 0, _stream()),
+          't2v_conv_fwd(dgrad)')
+    return gx
+
+
+def conv_wgrad_raw(x5, gy5, wshape, relu_in=False):
+    x5, gy5 = _c(x5), _c(gy5)
+    g = conv_geom(x5.shape[0], wshape[1], x5.shape[2], x5.shape[3], x5.shape[4], wshape[0], wshape[2], wshape[3], wshape[4])
+    n = lib().t2v_conv_wgrad_slab_floats(C.byref(g.cg))
+    if n <= 0:
+        raise RuntimeError('bad wgrad geometry')
+    slab = torch.empty((n,), device=x5.device, dtype=torch.float32)
+    dw = torch.empty(tuple(wshape), device=x5.device, dtype=torch.float32)
+    check(lib().t2v_conv_wgrad(_p(x5), _p(gy5), _p(dw), _p(slab), C.byref(g.cg), g.taps_c, g.T,
+                               FLAG_RELU_IN if relu_in else 0, _stream()), 't2v_conv_wgrad')
+    return dw
+
+
+def channel_sum_raw(t5):
+    t5 = _c(t5)
+    N, Cc = t5.shape[0], t5.shape[1]
+    S = t5.numel() // (N * Cc)
+    out = torch.empty((Cc,), device=t5.device, dtype=torch.float32)
+    check(lib().t2v_channel_sum(_p(t5), _p(out), N, Cc, S, 0, _stream()), 't2v_channel_sum')
+    return out
+
+
+class Conv(Function):
+    """y = conv(x, w) + b  (stride 1, same padding; 5-D tensors). nn.Conv3d/Conv2d/Linear forward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return conv_fwd_raw(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvDgrad.apply(gy, w)
+        if _param_grads_enabled:
+            if ctx.needs_input_grad[1]:
+                gw = ConvWgrad.apply(x, gy, tuple(w.shape))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ChannelSum.apply(gy)
+        return gx, gw, gb
+
+
+class ConvDgrad(Function):
+    """gx = conv_transpose(gy, w): the data gradient as a first-class differentiable op."""
+
+    @staticmethod
+    def forward(ctx, gy, w):
+        ctx.save_for_backward(gy, w)
+        return conv_dgrad_raw(gy, w)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        d_gy = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_gy = Conv.apply(ggx, w, None)
+        if ctx.needs_input_grad[1] and _param_grads_enabled:
+            d_w = ConvWgrad.apply(ggx, gy, tuple(w.shape))
+        return d_gy, d_w
+
+
+class ConvWgrad(Function):
+    """gw = sum_m gy (x) x_shifted: the weight gradient as a differentiable op."""
+
+    @staticmethod
+    def forward(ctx, x, gy, wshape):
+        ctx.save_for_backward(x, gy)
+        ctx.wshape = wshape
+        return conv_wgrad_raw(x, gy, wshape)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        d_x = d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_x = ConvDgrad.apply(gy, ggw)
+        if ctx.needs_input_grad[1]:
+            d_gy = Conv.apply(x, ggw, None)
+        return d_x, d_gy, None
+
+
+class ChannelSum(Function):
+    @staticmethod
+    def forward(ctx, t):
+        ctx.shape = tuple(t.shape)
+        return channel_sum_raw(t)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        shp = ctx.shape
+        rows = shp[0] * shp[1]
+        S = 1
+        for s in shp[2:]:
+            S *= s
+        gg = g.unsqueeze(0).expand(shp[0], shp[1]).contiguous()
+        out = torch.empty(shp, device=g.device, dtype=torch.float32)
+        check(lib().t2v_rowbcast(_p(gg), _p(out), rows, S, _stream()), 't2v_rowbcast')
+        return out
+
+
+def conv(x, w, b=None):
+    """Differentiable stride-1 same-padded convolution for [N,C,D,H,W], [N,C,H,W] or [N,C] inputs."""
+    dim = x.dim()
+    y = Conv.apply(_as5(x), _as5(w), b)
+    if dim == 4:
+        return y.squeeze(2)
+    if dim == 2:
+        return y.view(y.size(0), y.size(1))
+    return y
+
+
+def linear(x, w, b=None):
+    """F.linear for [B,Cin] inputs == 1x1x1 convolution on a single voxel."""
+    return conv(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise / pooling Functions (closed under differentiation)
+# ------------------------------------------------------------------------------------------------
+
+def _ew(fn, name, *tensors):
+    n = tensors[0].numel()
+    ts = [_c(t) for t in tensors]
+    out = torch.empty_like(ts[0])
+    check(fn(*[_p(t) for t in ts], _p(out), n, _stream()), name)
+    return out
+
+
+class Relu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return _ew(lib().t2v_relu, 't2v_relu', x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return ReluMask.apply(g, x)
+
+
+class ReluMask(Function):
+    """g * [x > 0] — linear in g; its adjoint is itself."""
+
+    @staticmethod
+    def forward(ctx, g, x):
+        ctx.save_for_backward(x)
+        return _ew(lib().t2v_relu_mask, 't2v_relu_mask', g, x)
+
+    @staticmethod
+    def backward(ctx, gg):
+        x, = ctx.saved_tensors
+        return ReluMask.apply(gg, x), None
+
+
+class Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _ew(lib().t2v_add, 't2v_add', a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def relu(x):
+    return Relu.apply(x)
+
+
+def add(a, b):
+    return Add.apply(a, b)
+
+
+def _pool_args(k, s, p):
+    A = C.c_int32 * 3
+    return A(*k), A(*s), A(*p)
+
+
+def _pool_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class AvgPool3d(Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = _c(x)
+        N, Cc, D, H, W = x.shape
+        Do, Ho, Wo = _pool_out(D, k[0], s[0], p[0]), _pool_out(H, k[1], s[1], p[1]), _pool_out(W, k[2], s[2], p[2])
+        ctx.cfg = (k, s, p, (D, H, W))
+        y = torch.empty((N, Cc, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+        ka, sa, pa = _pool_args(k, s, p)
+        check(lib().t2v_avgpool3d(_p(x), _p(y), N * Cc, D, H, W, Do, Ho, Wo, ka, sa, pa, _stream()), 't2v_avgpool3d')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        k, s, p, in_sp = ctx.cfg
+        return AvgPool3dBwd.apply(g, k, s, p, in_sp), None, None, None
+
+
+class AvgPool3dBwd(Function):
+    @staticmethod
+    def forward(ctx, g, k, s, p, in_sp):
+        g = _c(g)
+        N, Cc, Do, Ho, Wo = g.shape
+        D, H, W = in_sp
+        ctx.cfg = (k, s, p)
+        gx = torch.empty((N, Cc, D, H, W), device=g.device, dtype=torch.float32)
+        ka, sa, pa = _pool_args(k, s, p)
+        check(lib().t2v_avgpool3d_bwd(_p(g), _p(gx), N * Cc, D, H, W, Do, Ho, Wo, ka, sa, pa, _stream()),
+              't2v_avgpool3d_bwd')
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        k, s, p = ctx.cfg
+        return AvgPool3d.apply(gg, k, s, p), None, None, None, None
+
+
+def avg_pool3d(x, k, s, p=(0, 0, 0)):
+    return AvgPool3d.apply(x, tuple(k), tuple(s), tuple(p))
+
+
+class MaxPool2x2(Function):
+    """2x2 max-pool over the trailing (H,W) plane of any tensor (F.max_pool2d [2,2] / max_pool3d [1,2,2])."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        H, W = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (H * W)
+        y = torch.empty(tuple(x.shape[:-2]) + (H // 2, W // 2), device=x.device, dtype=torch.float32)
+        idx = torch.empty(y.shape, device=x.device, dtype=torch.int32)
+        check(lib().t2v_maxpool2x2(_p(x), _p(y), _p(idx), planes, H, W, _stream()), 't2v_maxpool2x2')
+        ctx.save_for_backward(idx)
+        ctx.in_shape = tuple(x.shape)
+        ctx.mark_non_differentiable(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        return MaxScatter.apply(g, idx, ctx.in_shape)
+
+
+class MaxScatter(Function):
+    @staticmethod
+    def forward(ctx, g, idx, in_shape):
+        g = _c(g)
+        H, W = in_shape[-2], in_shape[-1]
+        planes = g.numel() // ((H // 2) * (W // 2))
+        gx = torch.empty(in_shape, device=g.device, dtype=torch.float32)
+        check(lib().t2v_maxpool2x2_scatter(_p(g), _p(idx), _p(gx), planes, H, W, _stream()), 't2v_maxpool2x2_scatter')
+        ctx.save_for_backward(idx)
+        ctx.in_shape = in_shape
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        idx, = ctx.saved_tensors
+        return MaxGather.apply(gg, idx, ctx.in_shape), None, None
+
+
+class MaxGather(Function):
+    @staticmethod
+    def forward(ctx, x, idx, in_shape):
+        x = _c(x)
+        H, W = in_shape[-2], in_shape[-1]
+        planes = x.numel() // (H * W)
+        y = torch.empty(tuple(in_shape[:-2]) + (H // 2, W // 2), device=x.device, dtype=torch.float32)
+        check(lib().t2v_maxpool2x2_gather(_p(x), _p(idx), _p(y), planes, H, W, _stream()), 't2v_maxpool2x2_gather')
+        ctx.save_for_backward(idx)
+        ctx.in_shape = in_shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        return MaxScatter.apply(g, idx, ctx.in_shape), None, None
+
+
+def max_pool2x2(x):
+    return MaxPool2x2.apply(x)
+
+
+class RowSum(Function):
+    """[..., S] -> [...] : sum over the trailing flattened voxels (torch.sum(x,[2,3,4]))."""
+
+    @staticmethod
+    def forward(ctx, x, lead):
+        x = _c(x)
+        shp = tuple(x.shape)
+        rows = 1
+        for s in shp[:lead]:
+            rows *= s
+        S = x.numel() // rows
+        ctx.shape = shp
+        ctx.lead = lead
+        y = torch.empty(shp[:lead], device=x.device, dtype=torch.float32)
+        check(lib().t2v_rowsum(_p(x), _p(y), rows, S, _stream()), 't2v_rowsum')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return RowBcast.apply(g, ctx.shape, ctx.lead), None
+
+
+class RowBcast(Function):
+    @staticmethod
+    def forward(ctx, g, shape, lead):
+        g = _c(g)
+        rows = g.numel()
+        S = 1
+        for s in shape[lead:]:
+            S *= s
+        ctx.lead = lead
+        out = torch.empty(shape, device=g.device, dtype=torch.float32)
+        check(lib().t2v_rowbcast(_p(g), _p(out), rows, S, _stream()), 't2v_rowbcast')
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        return RowSum.apply(gg, ctx.lead), None, None
+
+
+def sum_spatial(x):
+    """[b,C,T,H,W] -> [b,C]."""
+    return RowSum.apply(x, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# non-local block pieces
+# ------------------------------------------------------------------------------------------------
+
+def _bmm_raw(A, B, M, N, K, ta, tb):
+    A, B = _c(A), _c(B)
+    batch = A.shape[0]
+    out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
+    check(lib().t2v_bmm(_p(A), _p(B), _p(out), batch, M, N, K, int(ta), int(tb), 0, _stream()), 't2v_bmm')
+    return out
+
+
+class Bmm(Function):
+    """C[b] = op(A[b]) @ op(B[b]); A stored [b,M,K] (ta=0) or [b,K,M] (ta=1); B [b,K,N] / [b,N,K]."""
+
+    @staticmethod
+    def forward(ctx, A, B, ta, tb):
+        M = A.shape[2] if ta else A.shape[1]
+        K = A.shape[1] if ta else A.shape[2]
+        N = B.shape[1] if tb else B.shape[2]
+        ctx.save_for_backward(A, B)
+        ctx.cfg = (ta, tb)
+        return _bmm_raw(A, B, M, N, K, ta, tb)
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        ta, tb = ctx.cfg
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                dA = Bmm.apply(G, B, False, not tb)          # [M,N] x B'^T
+            else:
+                dA = Bmm.apply(B, G, tb, True)               # B' x G^T  -> [K,M]
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                dB = Bmm.apply(A, G, not ta, False)          # A'^T x G -> [K,N]
+            else:
+                dB = Bmm.apply(G, A, True, ta)               # G^T x A' -> [N,K]
+        return dA, dB, None, None
+
+
+def bmm(A, B, ta=False, tb=False):
+    return Bmm.apply(A, B, ta, tb)
+
+
+class Softmax(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        n = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().t2v_softmax(_p(x), _p(y), x.numel() // n, n, _stream()), 't2v_softmax')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        return SoftmaxBwd.apply(y, g)
+
+
+class SoftmaxBwd(Function):
+    @staticmethod
+    def forward(ctx, y, gy):
+        y, gy = _c(y), _c(gy)
+        n = y.shape[-1]
+        gx = torch.empty_like(y)
+        check(lib().t2v_softmax_bwd(_p(y), _p(gy), _p(gx), y.numel() // n, n, _stream()), 't2v_softmax_bwd')
+        ctx.save_for_backward(y, gy)
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        y, gy = ctx.saved_tensors
+        gg = _c(gg)
+        n = y.shape[-1]
+        d_y = d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_y = torch.empty_like(y)
+            check(lib().t2v_softmax_bwd_bwd_y(_p(y), _p(gy), _p(gg), _p(d_y), y.numel() // n, n, _stream()),
+                  't2v_softmax_bwd_bwd_y')
+        if ctx.needs_input_grad[1]:
+            d_gy = SoftmaxBwd.apply(y, gg)
+        return d_y, d_gy
+
+
+def softmax_lastdim(x):
+    return Softmax.apply(x)
+
+
+class Dot(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        check(lib().t2v_dot(_p(a), _p(b), _p(out), a.numel(), 0, _stream()), 't2v_dot')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ScaleDev.apply(g, b), ScaleDev.apply(g, a)
+
+
+class ScaleDev(Function):
+    """y = s * a with s a 0-d device tensor (the non-local gain `gamma`)."""
+
+    @staticmethod
+    def forward(ctx, s, a):
+        a = _c(a)
+        ctx.save_for_backward(s, a)
+        y = torch.empty_like(a)
+        check(lib().t2v_scale_dev(_p(s), 1.0, _p(a), _p(y), a.numel(), _stream()), 't2v_scale_dev')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        s, a = ctx.saved_tensors
+        gs = ga = None
+        if ctx.needs_input_grad[0]:
+            gs = Dot.apply(g, a)
+        if ctx.needs_input_grad[1]:
+            ga = ScaleDev.apply(s, g)
+        return gs, ga
+
+
+def scale_add(gamma, o, x):
+    """gamma * o + x  (layers.py:36,68)."""
+    return Add.apply(ScaleDev.apply(gamma, o), x)
+
+
+# ------------------------------------------------------------------------------------------------
+# generator-side ops (first-order only)
+# ------------------------------------------------------------------------------------------------
+
+class Tanh(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = _ew(lib().t2v_tanh, 't2v_tanh', x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        return _ew(lib().t2v_tanh_bwd, 't2v_tanh_bwd', g, y)
+
+
+def tanh(x):
+    return Tanh.apply(x)
+
+
+class Upsample2x(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        H, W = x.shape[-2], x.shape[-1]
+        planes = x.numel() // (H * W)
+        y = torch.empty(tuple(x.shape[:-2]) + (2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        check(lib().t2v_upsample2x(_p(x), _p(y), planes, H, W, _stream()), 't2v_upsample2x')
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g)
+        shp = ctx.in_shape
+        H, W = shp[-2], shp[-1]
+        gx = torch.empty(shp, device=g.device, dtype=torch.float32)
+        check(lib().t2v_upsample2x_bwd(_p(g), _p(gx), gx.numel() // (H * W), H, W, _stream()), 't2v_upsample2x_bwd')
+        return gx
+
+
+def upsample2x(x):
+    return Upsample2x.apply(x)
+
+
+class BatchNormAct(Function):
+    """BatchNorm2d (+ optional fused ReLU). Training: batch statistics, running stats updated in place
+    (momentum 0.1, unbiased variance); eval: running statistics (no grad support needed)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu):
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        y = torch.empty_like(x)
+        if training:
+            stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
+            check(lib().t2v_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), N, Cc, S, momentum, eps, _stream()), 't2v_bn_stats')
+            check(lib().t2v_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, Cc, S, int(relu), _stream()), 't2v_bn_apply')
+            ctx.save_for_backward(x, y, stats, gamma)
+            ctx.relu = relu
+        else:
+            check(lib().t2v_bn_eval(_p(x), _p(rmean), _p(rvar), _p(gamma), _p(beta), _p(y), N, Cc, S, eps, int(relu), _stream()),
+                  't2v_bn_eval')
+        ctx.training = training
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if not ctx.training:
+            raise RuntimeError('eval-mode BatchNorm backward is not on the hot path')
+        x, y, stats, gamma = ctx.saved_tensors
+        g = _c(g)
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        gx = torch.empty_like(x)
+        gg = torch.empty_like(gamma)
+        gb = torch.empty_like(gamma)
+        ws = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
+        check(lib().t2v_bn_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
+                               int(ctx.relu), _stream()), 't2v_bn_bwd')
+        return gx, gg, gb, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False):
+    return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu)
+
+
+class ConvLSTMFn(Function):
+    """16-step single-cell ConvLSTM (conv_lstm.py:75-97). x is the input at step 0 and zero afterwards,
+    so the Wx convolutions run once; from step 1 on their contribution is the bias. Each gate's
+    convolution writes one dense block of the gate-major pre-activation buffer [4,B,C,h,w].
+    Back-propagation through time is done here explicitly with the dgrad / wgrad kernels.
+    args: x, steps, then Wx{i,f,c,o}, bx{i,f,c,o}, Wh{i,f,c,o}  (4-D conv weights [C,C,3,3]).
+    Returns the stacked hidden states [steps, B, C, h, w]."""
+
+    @staticmethod
+    def forward(ctx, x, steps, *params):
+        wx, bx, wh = params[0:4], params[4:8], params[8:12]
+        x = _c(x)
+        B, Cc, h, w = x.shape
+        CS = Cc * h * w
+        x5 = x.unsqueeze(2)
+        dev = x.device
+        hs = torch.empty((steps, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+        cs = torch.empty((steps + 1, B, Cc, h, w), device=dev, dtype=torch.float32)
+        acts = torch.empty((steps, 4, B, Cc, h, w), device=dev, dtype=torch.float32)
+        pre = torch.empty((4, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+        check(lib().t2v_fill(_p(cs[0]), 0.0, B * CS, _stream()), 't2v_fill')
+        for t in range(steps):
+            for g in range(4):
+                if t == 0:
+                    conv_fwd_raw(x5, wx[g].unsqueeze(2), bx[g], out=pre[g])      # h0 = 0: the Wh term vanishes
+                else:
+                    conv_fwd_raw(hs[t - 1], wh[g].unsqueeze(2), bx[g], out=pre[g])  # x_t = 0: Wx(x_t) is its bias
+            check(lib().t2v_lstm_gates(_p(pre), _p(cs[t]), _p(hs[t]), _p(cs[t + 1]), _p(acts[t]), B, CS, _stream()),
+                  't2v_lstm_gates')
+        ctx.save_for_backward(x, hs, cs, acts, *params)
+        ctx.steps = steps
+        return hs.squeeze(3)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ghs):
+        saved = ctx.saved_tensors
+        x, hs, cs, acts = saved[0:4]
+        params = saved[4:]
+        wx, bx, wh = params[0:4], params[4:8], params[8:12]
+        steps = ctx.steps
+        ghs = _c(ghs)
+        B, Cc, h, w = x.shape
+        CS = Cc * h * w
+        dev = x.device
+        x5 = x.unsqueeze(2)
+        gpre = torch.empty((steps, 4, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+        gh_next = None           # dL/dh_t arriving from step t+1
+        gc = None
+        for t in range(steps - 1, -1, -1):
+            if gh_next is None:
+                gh = ghs[t]
+            else:
+                gh = torch.empty_like(gh_next)
+                check(lib().t2v_add(_p(ghs[t]), _p(gh_next), _p(gh), B * CS, _stream()), 't2v_add')
+            gcp = torch.empty((B, Cc, h, w), device=dev, dtype=torch.float32)
+            check(lib().t2v_lstm_gates_bwd(_p(gh), _p(gc), _p(acts[t]), _p(cs[t]), _p(cs[t + 1]), _p(gpre[t]), _p(gcp),
+                                           B, CS, _stream()), 't2v_lstm_gates_bwd')
+            gc = gcp
+            if t > 0:
+                gh_next = torch.empty((B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+                for g in range(4):
+                    conv_dgrad_raw(gpre[t, g], wh[g].unsqueeze(2), out=gh_next, accum=(g > 0))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+            for g in range(4):
+                conv_dgrad_raw(gpre[0, g], wx[g].unsqueeze(2), out=gx, accum=(g > 0))
+            gx = gx.squeeze(2)
+        gwx, gbx, gwh = [], [], []
+        for g in range(4):
+            gwx.append(conv_wgrad_raw(x5, gpre[0, g], tuple(wx[g].unsqueeze(2).shape)).squeeze(2))
+            # bias: every step contributes -> fold the time axis into the batch
+            gt = gpre[:, g]                                         # [steps,B,C,1,h,w] (strided over gates)
+            gtc = gt.contiguous().view(steps * B, Cc, 1, h, w)
+            gbx.append(channel_sum_raw(gtc))
+            if steps > 1:
+                hin = hs[:steps - 1].reshape((steps - 1) * B, Cc, 1, h, w)
+                gin = gtc[B:]
+                gwh.append(conv_wgrad_raw(hin, gin, tuple(wh[g].unsqueeze(2).shape)).squeeze(2))
+            else:
+                gwh.append(torch.zeros_like(wh[g]))
+        return (gx, None) + tuple(gwx) + tuple(gbx) + tuple(gwh)
+
+
+def conv_lstm(x, steps, wx, bx, wh):
+    return ConvLSTMFn.apply(x, steps, *(list(wx) + list(bx) + list(wh)))
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+
+class RSGan(Function):
+    """mean softplus(-(a - b)) == BCEWithLogits(a - b, ones)  (losses.py:79-85)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        check(lib().t2v_rsgan(_p(a), _p(b), _p(out), a.numel(), _stream()), 't2v_rsgan')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        check(lib().t2v_rsgan_bwd(_p(a), _p(b), _p(g), _p(ga), _p(gb), a.numel(), _stream()), 't2v_rsgan_bwd')
+        return ga, gb
+
+
+def rsgan(a, b):
+    return RSGan.apply(a, b)
+
+
+def lerp_rows(alpha, xr, xf):
+    """alpha[b]*xr[b] + (1-alpha[b])*xf[b]  (losses.py:146); no autograd (inputs are detached)."""
+    xr, xf, alpha = _c(xr), _c(xf), _c(alpha)
+    rows = xr.shape[0]
+    out = torch.empty_like(xr)
+    check(lib().t2v_lerp_rows(_p(alpha), _p(xr), _p(xf), _p(out), rows, xr.numel() // rows, _stream()), 't2v_lerp_rows')
+    return out
+
+
+class RowSqNorm(Function):
+    """[b, ...] -> [b]: squared L2 norm per sample (losses.py:182)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _c(g)
+        rows = g.shape[0]
+        ctx.save_for_backward(g)
+        out = torch.empty((rows,), device=g.device, dtype=torch.float32)
+        check(lib().t2v_row_sqnorm(_p(g), _p(out), rows, g.numel() // rows, _stream()), 't2v_row_sqnorm')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        g, = ctx.saved_tensors
+        go = _c(go)
+        rows = g.shape[0]
+        out = torch.empty_like(g)
+        check(lib().t2v_row_scale(_p(go), 2.0, _p(g), _p(out), rows, g.numel() // rows, _stream()), 't2v_row_scale')
+        return out
+
+
+def row_sqnorm(g):
+    return RowSqNorm.apply(g)
+
+
+def pyramid_gather(x, Bo, To, Ho, Wo, sb, st, bt):
+    """y[b,c,t,h,w] = x[b*sb, c, t*st+bt, nearest(h), nearest(w)] — Subsample + F.interpolate(nearest)."""
+    x = _c(x)
+    B, Cc, T, H, W = x.shape
+    y = torch.empty((Bo, Cc, To, Ho, Wo), device=x.device, dtype=torch.float32)
+    check(lib().t2v_pyramid_gather(_p(x), _p(y), B, Cc, T, H, W, Bo, To, Ho, Wo, sb, st, bt, _stream()), 't2v_pyramid_gather')
+    return y
+
+
+class PyramidGather(Function):
+    """Differentiable batch/time sub-sampling `x[::2, :, bt::2]` (layers.py:110) for the generator."""
+
+    @staticmethod
+    def forward(ctx, x, bt):
+        B, Cc, T, H, W = x.shape
+        ctx.cfg = (tuple(x.shape), bt)
+        return pyramid_gather(x, (B + 1) // 2, (T - bt + 1) // 2, H, W, 2, 2, bt)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        shp, bt = ctx.cfg
+        gx = torch.zeros(shp, device=g.device, dtype=torch.float32)
+        gx[::2, :, bt::2] = g
+        return gx, None
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    check(lib().t2v_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, bc1, bc2, gscale, _stream()), 't2v_adam')
