@@ -151,6 +151,26 @@ int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
                        int sb, int st, int bt, void* stream);
 
+
+/* ---- layout glue: the permutes / slices between the reference's tensor layouts --------------------
+ * (torch.stack/permute/view of models/tganv2/gen.py:75-119, torch.cat of resnet3d.py:53) */
+int t2v_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int64_t cols, void* stream);
+int t2v_permute01(const float* x, float* y, int64_t A, int64_t B, int64_t inner, void* stream);   /* [A,B,i]->[B,A,i]   */
+int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int64_t C, int64_t inner, void* stream); /* [A,B,C,i]->[A,C,B,i] */
+/* merged-frames [b*T, inner]: keep samples ::2 and frames bt::2 (gen.py:98-109); adjoint=1 scatters y into x */
+int t2v_subsample_frames(float* x, float* y, int64_t b, int64_t T, int64_t inner, int64_t bo, int64_t To, int bt,
+                         int adjoint, void* stream);
+/* adjoint of t2v_pyramid_gather for Ho=H, Wo=W: gx[b*sb, c, t*st+bt, :] = g[b, c, t, :] (gx pre-zeroed) */
+int t2v_pyramid_scatter(const float* g, float* gx, int B, int C, int T, int64_t HW, int Bo, int To, int sb, int st,
+                        int bt, void* stream);
+
+
+/* out = sum_i w[i] * *ptrs[i] over n <= 16 device scalars (torch.stack(...).mean()/.sum() of
+ * cond_gan.py:51-61,106-118, losses.py:207). ptrs / weights are HOST arrays. */
+int t2v_scalar_combine(const void* const* ptrs, const float* weights, int n, float* out, void* stream);
+/* out[r,:] = x[perm[r],:] (inverse=1: out[perm[r],:] = x[r,:]) — cond[gen_perm(B)] of cond_gan.py:133 */
+int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* stream);
+
 const char* t2v_version(void);
 
 #ifdef __cplusplus

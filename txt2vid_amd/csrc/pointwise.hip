@@ -658,4 +658,114 @@ extern "C" int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T,
     return launch_status();
 }
 
+
+// ---------------------------------------------------------------- layout glue (dense strided copies)
+__global__ void copy2d_k(const float* src, long src_ld, float* dst, long dst_ld, long rows, long cols) {
+    const long n = rows * cols;
+    GRID_STRIDE(i, n) {
+        const long r = i / cols, c = i - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+extern "C" int t2v_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int64_t cols, void* st) {
+    if (!src || !dst || rows < 1 || cols < 1 || src_ld < cols || dst_ld < cols) return T2V_EINVAL;
+    hipLaunchKernelGGL(copy2d_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), src, (long)src_ld, dst, (long)dst_ld, (long)rows, (long)cols);
+    return launch_status();
+}
+// x[A][B][inner] -> y[B][A][inner]
+__global__ void permute01_k(const float* x, float* y, long A, long B, long inner) {
+    const long n = A * B * inner;
+    GRID_STRIDE(i, n) {
+        const long in = i % inner; long r = i / inner;
+        const long a = r % A, b = r / A;
+        y[i] = x[(a * B + b) * inner + in];
+    }
+}
+extern "C" int t2v_permute01(const float* x, float* y, int64_t A, int64_t B, int64_t inner, void* st) {
+    if (!x || !y || A < 1 || B < 1 || inner < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(permute01_k, dim3(nblocks(A * B * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)inner);
+    return launch_status();
+}
+// x[A][B][C][inner] -> y[A][C][B][inner]
+__global__ void permute12_k(const float* x, float* y, long A, long B, long Cc, long inner) {
+    const long n = A * B * Cc * inner;
+    GRID_STRIDE(i, n) {
+        const long in = i % inner; long r = i / inner;
+        const long b = r % B; r /= B;
+        const long c = r % Cc, a = r / Cc;
+        y[i] = x[((a * B + b) * Cc + c) * inner + in];
+    }
+}
+extern "C" int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int64_t Cc, int64_t inner, void* st) {
+    if (!x || !y || A < 1 || B < 1 || Cc < 1 || inner < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(permute12_k, dim3(nblocks(A * B * Cc * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)Cc, (long)inner);
+    return launch_status();
+}
+// merged-frames layout [b*T][inner]: keep samples ::2, frames bt::2. adjoint=1 writes y back into x.
+__global__ void subsample_frames_k(float* x, float* y, long T, long inner, long bo, long To, int bt, int adjoint) {
+    const long n = bo * To * inner;
+    GRID_STRIDE(i, n) {
+        const long in = i % inner; long r = i / inner;
+        const long to = r % To, b2 = r / To;
+        const long src = ((2 * b2) * T + (2 * to + bt)) * inner + in;
+        if (adjoint) x[src] = y[i]; else y[i] = x[src];
+    }
+}
+extern "C" int t2v_subsample_frames(float* x, float* y, int64_t b, int64_t T, int64_t inner, int64_t bo, int64_t To, int bt,
+                                    int adjoint, void* st) {
+    if (!x || !y || b < 1 || T < 1 || inner < 1 || bo < 1 || To < 1 || bt < 0 || bt > 1) return T2V_EINVAL;
+    if (2 * (bo - 1) >= b || 2 * (To - 1) + bt >= T) return T2V_EINVAL;
+    hipLaunchKernelGGL(subsample_frames_k, dim3(nblocks(bo * To * inner)), dim3(256), 0, S_(st), x, y, (long)T, (long)inner, (long)bo, (long)To, bt, adjoint);
+    return launch_status();
+}
+// adjoint of pyramid_gather without spatial resampling: gx[b*sb, c, t*st+bt, :] = g[b, c, t, :]
+__global__ void pyramid_scatter_k(const float* g, float* gx, long Cc, long T, long HW, long Bo, long To, int sb, int stt, int bt) {
+    const long n = Bo * Cc * To * HW;
+    GRID_STRIDE(i, n) {
+        const long in = i % HW; long r = i / HW;
+        const long to = r % To; r /= To;
+        const long c = r % Cc, bo = r / Cc;
+        gx[(((bo * sb) * Cc + c) * T + (to * stt + bt)) * HW + in] = g[i];
+    }
+}
+extern "C" int t2v_pyramid_scatter(const float* g, float* gx, int B, int Cc, int T, int64_t HW, int Bo, int To, int sb, int stt,
+                                   int bt, void* st) {
+    if (!g || !gx || B < 1 || Cc < 1 || T < 1 || HW < 1 || Bo < 1 || To < 1) return T2V_EINVAL;
+    if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + bt >= T) return T2V_EINVAL;
+    hipLaunchKernelGGL(pyramid_scatter_k, dim3(nblocks((long)Bo * Cc * To * HW)), dim3(256), 0, S_(st), g, gx, (long)Cc, (long)T, (long)HW, (long)Bo, (long)To, sb, stt, bt);
+    return launch_status();
+}
+
+
+// ---------------------------------------------------------------- scalar / row glue
+struct ScalarList { const float* p[16]; float w[16]; int n; };
+__global__ void scalar_combine_k(ScalarList l, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float acc = 0.f;
+        for (int i = 0; i < l.n; ++i) acc += l.w[i] * l.p[i][0];
+        out[0] = acc;
+    }
+}
+extern "C" int t2v_scalar_combine(const void* const* ptrs, const float* weights, int n, float* out, void* st) {
+    if (!ptrs || !weights || !out || n < 1 || n > 16) return T2V_EINVAL;
+    ScalarList l;
+    l.n = n;
+    for (int i = 0; i < n; ++i) { l.p[i] = (const float*)ptrs[i]; l.w[i] = weights[i]; if (!l.p[i]) return T2V_EINVAL; }
+    hipLaunchKernelGGL(scalar_combine_k, dim3(1), dim3(64), 0, S_(st), l, out);
+    return launch_status();
+}
+// out[r] = x[perm[r]]  (inverse: out[perm[r]] = x[r])
+__global__ void gather_rows_k(const float* x, const int32_t* perm, float* out, long rows, long cols, int inverse) {
+    const long n = rows * cols;
+    GRID_STRIDE(i, n) {
+        const long r = i / cols, c = i - r * cols;
+        if (inverse) out[(long)perm[r] * cols + c] = x[i]; else out[i] = x[(long)perm[r] * cols + c];
+    }
+}
+extern "C" int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* st) {
+    if (!x || !perm || !out || rows < 1 || cols < 1) return T2V_EINVAL;
+    hipLaunchKernelGGL(gather_rows_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), x, perm, out, (long)rows, (long)cols, inverse);
+    return launch_status();
+}
+
 extern "C" const char* t2v_version(void) { return "t2v_hip 0.1 (gfx950, fp32 MFMA)"; }

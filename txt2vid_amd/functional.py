@@ -905,8 +905,12 @@ class PyramidGather(Function):
     @once_differentiable
     def backward(ctx, g):
         shp, bt = ctx.cfg
-        gx = torch.zeros(shp, device=g.device, dtype=torch.float32)
-        gx[::2, :, bt::2] = g
+        g = _c(g)
+        gx = torch.empty(shp, device=g.device, dtype=torch.float32)
+        check(lib().t2v_fill(_p(gx), 0.0, gx.numel(), _stream()), 't2v_fill')
+        B, Cc, T, H, W = shp
+        check(lib().t2v_pyramid_scatter(_p(g), _p(gx), B, Cc, T, H * W, g.shape[0], g.shape[2], 2, 2, bt, _stream()),
+              't2v_pyramid_scatter')
         return gx, None
 
 
@@ -914,3 +918,291 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
     bc1 = 1.0 - b1 ** step
     bc2 = 1.0 - b2 ** step
     check(lib().t2v_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, bc1, bc2, gscale, _stream()), 't2v_adam')
+
+
+# ------------------------------------------------------------------------------------------------
+# layout glue (strided copies done by t2v_pyramid_gather / t2v_copy2d — no ATen kernels)
+# ------------------------------------------------------------------------------------------------
+
+def _copy2d(src, src_off, src_ld, dst, dst_off, dst_ld, rows, cols):
+    check(lib().t2v_copy2d(C.c_void_p(src.data_ptr() + 4 * src_off), src_ld, C.c_void_p(dst.data_ptr() + 4 * dst_off), dst_ld,
+                           rows, cols, _stream()), 't2v_copy2d')
+
+
+class SliceCols(Function):
+    """x[:, off:off+n] of a 2-D tensor (adjoint: EmbedCols)."""
+
+    @staticmethod
+    def forward(ctx, x, off, n):
+        x = _c(x)
+        ctx.cfg = (off, x.shape[1])
+        out = torch.empty((x.shape[0], n), device=x.device, dtype=torch.float32)
+        _copy2d(x, off, x.shape[1], out, 0, n, x.shape[0], n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        off, total = ctx.cfg
+        return EmbedCols.apply(g, off, total), None, None
+
+
+class EmbedCols(Function):
+    @staticmethod
+    def forward(ctx, g, off, total):
+        g = _c(g)
+        ctx.cfg = (off, g.shape[1])
+        out = torch.empty((g.shape[0], total), device=g.device, dtype=torch.float32)
+        check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
+        _copy2d(g, 0, g.shape[1], out, off, total, g.shape[0], g.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        off, n = ctx.cfg
+        return SliceCols.apply(gg, off, n), None, None
+
+
+class CatFeatures(Function):
+    """torch.cat((a, b), dim=1) for 2-D tensors (resnet3d.py:53, tganv2_cond/gen.py:68)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        na, nb = a.shape[1], b.shape[1]
+        ctx.cfg = (na, nb)
+        out = torch.empty((a.shape[0], na + nb), device=a.device, dtype=torch.float32)
+        _copy2d(a, 0, na, out, 0, na + nb, a.shape[0], na)
+        _copy2d(b, 0, nb, out, na, na + nb, a.shape[0], nb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        na, nb = ctx.cfg
+        ga = SliceCols.apply(g, 0, na) if ctx.needs_input_grad[0] else None
+        gb = SliceCols.apply(g, na, nb) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def cat_features(a, b):
+    return CatFeatures.apply(a, b)
+
+
+def _permute_01(x, A, Bd, inner):
+    """[A,B,inner] -> [B,A,inner] dense copy."""
+    out = torch.empty((Bd, A, inner), device=x.device, dtype=torch.float32)
+    check(lib().t2v_permute01(_p(x), _p(out), A, Bd, inner, _stream()), 't2v_permute01')
+    return out
+
+
+class Permute01(Function):
+    """Swap the two leading axes of a contiguous tensor viewed as [A,B,inner]."""
+
+    @staticmethod
+    def forward(ctx, x, A, Bd):
+        x = _c(x)
+        inner = x.numel() // (A * Bd)
+        ctx.cfg = (A, Bd, tuple(x.shape))
+        return _permute_01(x, A, Bd, inner)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        A, Bd, shp = ctx.cfg
+        g = _c(g)
+        return _permute_01(g, Bd, A, g.numel() // (A * Bd)).view(shp), None, None
+
+
+def time_to_batch(hs):
+    """[T,B,C,h,w] -> [B*T,C,h,w]  (torch.stack(x).permute(1,0,2,3,4) + merge_frames, gen.py:75-96)."""
+    T, B = hs.shape[0], hs.shape[1]
+    return Permute01.apply(hs, T, B).view((B * T,) + tuple(hs.shape[2:]))
+
+
+def frames_to_video(r, T):
+    """[b*T,C,H,W] -> [b,C,T,H,W]  (split_frames + time_first, gen.py:117-118)."""
+    return _FramesToVideo.apply(r, T)
+
+
+class _FramesToVideo(Function):
+    @staticmethod
+    def forward(ctx, r, T):
+        r = _c(r)
+        bT, Cc, H, W = r.shape
+        b = bT // T
+        ctx.cfg = (b, T, Cc, H, W)
+        out = torch.empty((b, Cc, T, H, W), device=r.device, dtype=torch.float32)
+        check(lib().t2v_permute12(_p(r), _p(out), b, T, Cc, H * W, _stream()), 't2v_permute12')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        b, T, Cc, H, W = ctx.cfg
+        g = _c(g)
+        out = torch.empty((b * T, Cc, H, W), device=g.device, dtype=torch.float32)
+        check(lib().t2v_permute12(_p(g), _p(out), b, Cc, T, H * W, _stream()), 't2v_permute12')
+        return out, None
+
+
+class _SubsampleFrames(Function):
+    """[b*T,C,h,w] -> keep samples ::2 and frames bt::2 -> [ceil(b/2)*(T/2),C,h,w] (gen.py:98-109)."""
+
+    @staticmethod
+    def forward(ctx, x, T, bt):
+        x = _c(x)
+        bT, Cc, H, W = x.shape
+        b = bT // T
+        bo, To = (b + 1) // 2, (T - bt + 1) // 2
+        ctx.cfg = (tuple(x.shape), b, T, bt, bo, To)
+        out = torch.empty((bo * To, Cc, H, W), device=x.device, dtype=torch.float32)
+        check(lib().t2v_subsample_frames(_p(x), _p(out), b, T, Cc * H * W, bo, To, bt, 0, _stream()), 't2v_subsample_frames')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        shp, b, T, bt, bo, To = ctx.cfg
+        g = _c(g)
+        gx = torch.empty(shp, device=g.device, dtype=torch.float32)
+        check(lib().t2v_fill(_p(gx), 0.0, gx.numel(), _stream()), 't2v_fill')
+        check(lib().t2v_subsample_frames(_p(gx), _p(g), b, T, shp[1] * shp[2] * shp[3], bo, To, bt, 1, _stream()),
+              't2v_subsample_frames(adjoint)')
+        return gx, None, None
+
+
+def subsample_frames(x, T, bt):
+    return _SubsampleFrames.apply(x, T, bt)
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar glue: combining per-level / per-head losses (cond_gan.py:51-61,106-118, losses.py:207)
+# ------------------------------------------------------------------------------------------------
+
+def ones_like(t):
+    out = torch.empty_like(t)
+    check(lib().t2v_fill(_p(out), 1.0, out.numel(), _stream()), 't2v_fill')
+    return out
+
+
+class ScalarCombine(Function):
+    """sum_i w_i * s_i over 0-d device tensors (one kernel; torch.stack(...).mean()/sum() in the reference)."""
+
+    @staticmethod
+    def forward(ctx, weights, *scalars):
+        n = len(scalars)
+        ctx.weights = weights
+        ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in scalars])
+        w = (C.c_float * n)(*weights)
+        out = torch.empty((), device=scalars[0].device, dtype=torch.float32)
+        check(lib().t2v_scalar_combine(ptrs, w, n, _p(out), _stream()), 't2v_scalar_combine')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(ScaleConst.apply(g, w) for w in ctx.weights)
+
+
+class ScaleConst(Function):
+    """y = c * a for a host constant c."""
+
+    @staticmethod
+    def forward(ctx, a, c):
+        a = _c(a)
+        ctx.c = c
+        out = torch.empty_like(a)
+        check(lib().t2v_axpby(c, _p(a), 0.0, None, _p(out), a.numel(), _stream()), 't2v_axpby')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ScaleConst.apply(g, ctx.c), None
+
+
+def scalar_sum(scalars, weights=None):
+    scalars = list(scalars)
+    if weights is None:
+        weights = [1.0] * len(scalars)
+    return ScalarCombine.apply(tuple(float(w) for w in weights), *scalars)
+
+
+def scalar_mean(scalars):
+    scalars = list(scalars)
+    return scalar_sum(scalars, [1.0 / len(scalars)] * len(scalars))
+
+
+class VecSum(Function):
+    """scale * sum(v) for a small 1-D device vector -> 0-d (losses.py:203 combine=torch.sum)."""
+
+    @staticmethod
+    def forward(ctx, v, scale):
+        v = _c(v)
+        ctx.n, ctx.scale = v.numel(), scale
+        out = torch.empty((), device=v.device, dtype=torch.float32)
+        check(lib().t2v_rowsum(_p(v), _p(out), 1, v.numel(), _stream()), 't2v_rowsum')
+        if scale != 1.0:
+            check(lib().t2v_axpby(scale, _p(out), 0.0, None, _p(out), 1, _stream()), 't2v_axpby')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        out = torch.empty((ctx.n,), device=g.device, dtype=torch.float32)
+        gg = _c(g).view(1)
+        check(lib().t2v_rowbcast(_p(gg), _p(out), 1, ctx.n, _stream()), 't2v_rowbcast')
+        if ctx.scale != 1.0:
+            check(lib().t2v_axpby(ctx.scale, _p(out), 0.0, None, _p(out), ctx.n, _stream()), 't2v_axpby')
+        return out, None
+
+
+def vec_sum(v, scale=1.0):
+    return VecSum.apply(v, float(scale))
+
+
+class GatherRows(Function):
+    """x[perm] for a 2-D tensor (mismatched captions, cond_gan.py:133)."""
+
+    @staticmethod
+    def forward(ctx, x, perm_dev, inverse=False):
+        x = _c(x)
+        ctx.save_for_backward(perm_dev)
+        ctx.inverse = inverse
+        out = torch.empty_like(x)
+        check(lib().t2v_gather_rows(_p(x), _p(perm_dev), _p(out), x.shape[0], x.shape[1], int(inverse), _stream()), 't2v_gather_rows')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        perm_dev, = ctx.saved_tensors
+        return GatherRows.apply(g, perm_dev, not ctx.inverse), None, None
+
+
+def gather_rows(x, perm):
+    import numpy as _np
+    perm_dev = torch.from_numpy(_np.ascontiguousarray(perm, dtype=_np.int32)).to(x.device)
+    return GatherRows.apply(x, perm_dev, False)
+
+
+def head_rows(x, n):
+    """x[0:n] — a leading-rows slice of a contiguous tensor is a view (no kernel, no copy)."""
+    return x[0:n]
+
+
+def stride_rows(x, step):
+    """x[::step] as a dense tensor (cond[::2], trainer.py:160)."""
+    x = _c(x)
+    rows = (x.shape[0] + step - 1) // step
+    cols = x.numel() // x.shape[0]
+    out = torch.empty((rows,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    _copy2d(x, 0, cols * step, out, 0, cols, rows, cols)
+    return out
+
+
+def video_to_channel_first(x):
+    """[B,T,C,H,W] -> [B,C,T,H,W] dense (x.permute(0,2,1,3,4), trainer.py:204)."""
+    x = _c(x)
+    B, T, Cc, H, W = x.shape
+    if Cc == 1 or T == 1:
+        return x.view(B, Cc, T, H, W)
+    out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=torch.float32)
+    check(lib().t2v_permute12(_p(x), _p(out), B, T, Cc, H * W, _stream()), 't2v_permute12')
+    return out

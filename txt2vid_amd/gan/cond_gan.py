@@ -1,0 +1,164 @@
+"""The GAN operator surface: D / G step losses with matched / mismatched captions — same methods and
+kwargs as txt2vid/gan/cond_gan.py:7-217. Scalar combinations of the per-level losses are done by the
+`scalar_*` kernels, not by ATen."""
+import numpy as np
+import torch
+
+from .. import functional as TF
+from ..util.misc import gen_perm
+from .losses import gradient_penalty
+
+
+class CondGan(object):
+    def __init__(self, gen=None, discrims=None, cond_encoder=None, discrim_names=None, sample_mapping=None,
+                 discrim_lambdas=None, gp_scale=1.0):
+        assert gen is not None
+        assert discrims is not None and len(discrims) >= 1
+        if discrim_names is None:
+            discrim_names = ['discrim-%d' % i for i in range(len(discrims))]
+        if sample_mapping is not None:
+            raise NotImplementedError('sample mappings (TCWYT baseline, cond_gan.py:23-24) are outside the hot path')
+        self.gen, self.discrims = gen, discrims
+        self.sample_mapping = None
+        self.cond_encoder = cond_encoder
+        self.discrim_names = discrim_names
+        self.discrim_lambdas = discrim_lambdas
+        self.gp_scale = gp_scale          # data-parallel: world_size, else 1
+
+    def _discrim_weighted_sum(self, losses):
+        """cond_gan.py:26-31: mean over discriminators, or lambda-weighted sum."""
+        if self.discrim_lambdas is None:
+            return TF.scalar_mean(losses)
+        return TF.scalar_sum(losses, weights=self.discrim_lambdas)
+
+    def discrim_forward(self, name=None, discrim=None, real=None, real_mapping=None, fake=None, fake_mapping=None,
+                        real_cond=None, fake_cond=None, loss=None, gp_lambda=-1):
+        """cond_gan.py:34-87."""
+        fake_pred = real_pred = l = None
+        if real_cond is not None and fake_cond is not None:
+            real_cc = discrim(x=real, cond=real_cond, xbar=None)
+            real_pred = real_cc
+            if loss is not None:
+                # D(real, mismatched captions): only the conditional head differs from real_cc, so its
+                # trunk features are reused (the reference *means* to — it passes computed_features,
+                # cond_gan.py:45-48 — but recomputes them, tganv2_cond/discrim.py:35,40-41; same values).
+                real_ic = [discrim.sub_discrims[i](cond=fake_cond[i], computed_features=real_cc[i][2])
+                           for i in range(len(real))] if hasattr(discrim, 'sub_discrims') else \
+                    discrim(x=real, cond=fake_cond, xbar=None)
+                fake_cc = discrim(x=fake, cond=real_cond, xbar=None)
+                lu = TF.scalar_mean([loss(fake=f[0], real=r[0]) for f, r in zip(fake_cc, real_cc)])
+                l1 = TF.scalar_mean([loss(fake=f[1], real=r[1]) for f, r in zip(fake_cc, real_cc)])
+                l2 = TF.scalar_mean([loss(fake=f[1], real=r[1]) for f, r in zip(real_ic, real_cc)])
+                # (lu + (l1 + l2)/2) / 2
+                l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
+        else:
+            if real is not None:
+                real_pred = [r[0] for r in discrim(x=real, cond=None, xbar=None)]
+            if fake is not None:
+                fake_pred = [f[0] for f in discrim(x=fake, cond=None, xbar=None)]
+            if loss is not None and fake_pred is not None and real_pred is not None:
+                l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(fake_pred, real_pred)])
+        if l is not None and gp_lambda > 0:
+            gp = gradient_penalty(discrim, real_x=real, fake_x=fake, real_cond=real_cond, fake_cond=fake_cond,
+                                  scale=self.gp_scale)
+            l = TF.scalar_sum([l, gp], weights=[1.0, gp_lambda])
+        return l, fake_pred, real_pred
+
+    def gen_step(self, fake=None, real_pred=None, cond=None, loss=None):
+        """cond_gan.py:90-118. The uncond branch uses `ff[0]` (the intended semantics; the reference
+        passes the whole tuple and crashes, SURVEY §8a defect 1). D's parameters are frozen for this
+        forward: the reference computes their gradients here and zeroes them before they are ever used
+        (cond_gan.py:157-158), so skipping the D weight-gradient kernels leaves every result identical."""
+        self.gen.zero_grad()
+        if self.cond_encoder is not None:
+            self.cond_encoder.zero_grad()
+        losses = []
+        for r, name, discrim in zip(real_pred, self.discrim_names, self.discrims):
+            frozen = [p for p in discrim.parameters() if p.requires_grad]
+            for p in frozen:
+                p.requires_grad_(False)
+            try:
+                fake_cc = discrim(x=fake, cond=cond, xbar=None)
+            finally:
+                for p in frozen:
+                    p.requires_grad_(True)
+            if cond is None:
+                losses.append(TF.scalar_mean([loss(fake=ff[0], real=rr) for ff, rr in zip(fake_cc, r)]))
+            else:
+                lu = TF.scalar_mean([loss(fake=ff[0], real=rr[0]) for ff, rr in zip(fake_cc, r)])
+                lc = TF.scalar_mean([loss(fake=ff[1], real=rr[1]) for ff, rr in zip(fake_cc, r)])
+                losses.append(TF.scalar_sum([lc, lu], weights=[0.5, 0.5]))
+        return self._discrim_weighted_sum(losses)
+
+    def all_discrim_forward(self, fake=None, real=None, cond=None, loss=None, gp_lambda=-1):
+        """cond_gan.py:121-154."""
+        losses, real_pred, fake_pred = [], [], []
+        for name, discrim in zip(self.discrim_names, self.discrims):
+            real_cond, fake_cond = cond, None
+            if cond is not None:
+                perm = gen_perm(real_cond[0].size(0))                     # numpy global RNG, like the reference
+                fc0 = TF.gather_rows(real_cond[0], perm)
+                fake_cond = [TF.head_rows(fc0, r.size(0)) for r in real_cond]
+            l, f, r = self.discrim_forward(name=name, discrim=discrim, real=real, real_cond=real_cond, fake=fake,
+                                           fake_cond=fake_cond, loss=loss, gp_lambda=gp_lambda)
+            losses.append(l)
+            fake_pred.append(f)
+            real_pred.append(r)
+        return losses, fake_pred, real_pred
+
+    def discrim_step(self, real=None, fake=None, cond=None, loss=None, gp_lambda=-1):
+        """cond_gan.py:156-164."""
+        for d in self.discrims:
+            d.zero_grad()
+        if self.cond_encoder is not None:
+            self.cond_encoder.zero_grad()
+        losses, _, _ = self.all_discrim_forward(real=real, fake=fake, cond=cond, loss=loss, gp_lambda=gp_lambda)
+        return self._discrim_weighted_sum(losses)
+
+    def count_params(self):
+        from ..util.misc import count_params
+        n = int(np.sum([count_params(d) for d in self.discrims])) + count_params(self.gen)
+        if self.cond_encoder is not None:
+            n += count_params(self.cond_encoder)
+        return n
+
+    def __call__(self, *args, **kwargs):
+        return self.gen(*args, **kwargs)
+
+    @property
+    def discrims_params(self):
+        return [d.parameters() for d in self.discrims]
+
+    def save_dict(self):
+        """cond_gan.py:186-196: {'gen', 'cond'?, <D name>...}."""
+        res = {'gen': self.gen.state_dict()}
+        if self.cond_encoder is not None:
+            res['cond'] = self.cond_encoder.state_dict()
+        for name, d in zip(self.discrim_names, self.discrims):
+            res[name] = d.state_dict()
+        return res
+
+    def load_from_dict(self, to_load):
+        """cond_gan.py:198-217. Accepts both `single_discrim.*` and `single_discrim.module.*` key styles."""
+        self.gen.load_state_dict(to_load['gen'])
+        if 'cond' in to_load:
+            assert self.cond_encoder is not None
+            self.cond_encoder.load_state_dict(to_load['cond'])
+        for name, d in zip(self.discrim_names, self.discrims):
+            if name in to_load:
+                d.load_state_dict(_match_keys(to_load[name], d.state_dict().keys()))
+
+
+def _match_keys(sd, want):
+    want = list(want)
+    if set(sd.keys()) == set(want):
+        return sd
+    def strip(k):
+        return k.replace('single_discrim.module.', 'single_discrim.').replace('sub_discrims.', 'sub_discrims.')
+    by = {strip(k): v for k, v in sd.items()}
+    out = {}
+    for k in want:
+        if strip(k) not in by:
+            return sd
+        out[k] = by[strip(k)]
+    return out

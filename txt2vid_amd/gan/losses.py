@@ -1,0 +1,113 @@
+"""GAN losses of the hot path — same classes / call signatures as txt2vid/gan/losses.py.
+
+RSGANLoss (losses.py:74-85) and the gradient penalty (losses.py:135-209) run on the HIP kernels.
+The remaining zoo (Vanilla/Hinge/Wasserstein/RaLS) is off the north-star path and is
+kept as small compositions of the same kernels where one exists, else as tiny tensor expressions.
+"""
+import torch
+
+from .. import functional as TF
+
+
+def get_labels_for(x, label):
+    return torch.full(x.size(), float(label), device=x.device)
+
+
+class MixedGanLoss(object):
+    """Separate G / D loss objects — losses.py:8-17."""
+
+    def __init__(self, g_loss=None, d_loss=None):
+        self.g_loss, self.d_loss = g_loss, d_loss
+
+    def discrim_loss(self, fake=None, real=None):
+        return self.d_loss.discrim_loss(fake=fake, real=real)
+
+    def gen_loss(self, fake=None, real=None):
+        return self.g_loss.gen_loss(fake=fake, real=real)
+
+
+class RSGANLoss(object):
+    """Relativistic standard GAN: BCEWithLogits(real - fake, 1) / BCEWithLogits(fake - real, 1)."""
+
+    def __init__(self, bce_loss=True):
+        if not bce_loss:
+            raise NotImplementedError('only the BCE form is used by the reference scripts')
+
+    def discrim_loss(self, fake=None, real=None):
+        return TF.rsgan(real, fake)
+
+    def gen_loss(self, fake=None, real=None):
+        return TF.rsgan(fake, real)
+
+
+class WassersteinGanLoss(object):
+    """losses.py:55-68 (off the hot path; plain tensor means)."""
+
+    def discrim_loss(self, fake=None, real=None):
+        return -(real.mean() - fake.mean())
+
+    def gen_loss(self, fake=None, real=None):
+        return -fake.mean()
+
+
+class RaLSGANLoss(object):
+    """losses.py:113-133 (off the hot path)."""
+
+    def discrim_loss(self, fake=None, real=None):
+        return (torch.mean((real - torch.mean(fake) - 1) ** 2) + torch.mean((fake - torch.mean(real) + 1) ** 2)) / 2
+
+    def gen_loss(self, fake=None, real=None):
+        return (torch.mean((real - torch.mean(fake) + 1) ** 2) + torch.mean((fake - torch.mean(real) - 1) ** 2)) / 2
+
+
+def _gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xbar=None, real_cond=None, fake_cond=None,
+                      zero_center=False, combine=torch.mean, alpha=None, scale=1.0):
+    """losses.py:135-186. alpha ~ U[0,1)^b is drawn on the CPU generator (like the reference) unless
+    given. The interpolation, the D forward, the data-gradient sweep (create_graph) and the per-sample
+    squared norms all run on the HIP kernels; `input_grads_only` keeps that sweep from computing
+    weight gradients nobody asked for."""
+    if real_xbar is not None or fake_xbar is not None:
+        raise NotImplementedError('sample mappings (TCWYT baseline) are outside the hot path')
+    b = real_x.size(0)
+    if alpha is None:
+        alpha = torch.rand(b, *([1] * (real_x.dim() - 1)))
+    a_dev = alpha.reshape(b).to(device=real_x.device, dtype=torch.float32)
+    xh = TF.lerp_rows(a_dev, real_x.detach(), fake_x.detach()).requires_grad_(True)
+    ch = None
+    if real_cond is not None and fake_cond is not None:
+        if real_cond.requires_grad or fake_cond.requires_grad:
+            a2 = a_dev.view(b, 1)
+            ch = a2 * real_cond + (1 - a2) * fake_cond           # --end2end: keep the text-encoder graph
+        else:
+            ch = TF.lerp_rows(a_dev, real_cond, fake_cond)
+    u, c, _ = discrim(x=xh, cond=ch, xbar=None)
+    outs = [u] + ([c] if c is not None else [])
+    ones = [TF.ones_like(o) for o in outs]
+    with TF.input_grads_only():
+        g = torch.autograd.grad(outputs=outs, inputs=[xh], grad_outputs=ones, create_graph=True, retain_graph=True,
+                                only_inputs=True)[0]
+    sq = TF.row_sqnorm(g)                                        # ||g_b||^2
+    if zero_center:
+        per = sq
+    else:
+        per = (torch.sqrt(sq) - 1) ** 2
+    if combine is torch.sum:
+        return TF.vec_sum(per, scale)
+    return combine(per) * scale
+
+
+def gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xbar=None, real_cond=None, fake_cond=None,
+                     alphas=None, scale=1.0):
+    """losses.py:188-209: multi-scale discriminators use the zero-centred, sum-combined penalty per
+    level, summed over levels. `scale` multiplies the result (data-parallel ranks pass world_size so
+    that gradient *averaging* reproduces the global-batch SUM)."""
+    if hasattr(discrim, 'sub_discrims'):
+        gps = []
+        for i in range(len(real_x)):
+            rc = real_cond[i] if real_cond is not None else None
+            fc = fake_cond[i] if real_cond is not None else None
+            a = None if alphas is None else alphas[i]
+            gps.append(_gradient_penalty(discrim.sub_discrims[i], real_x=real_x[i], fake_x=fake_x[i], real_cond=rc,
+                                         fake_cond=fc, zero_center=True, combine=torch.sum, alpha=a, scale=scale))
+        return TF.scalar_sum(gps)
+    return _gradient_penalty(discrim, real_x=real_x, fake_x=fake_x, real_cond=real_cond, fake_cond=fake_cond, scale=scale)

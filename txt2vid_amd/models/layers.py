@@ -1,0 +1,266 @@
+"""Building blocks of the TGANv2 generator / discriminator, same class names, constructor
+signatures, `forward` signatures and `state_dict` layout as txt2vid/models/layers.py — but every
+tensor op is a hand-written gfx950 kernel reached through `txt2vid_amd.functional`.
+
+Leaf layers subclass the torch layer they stand in for ONLY to inherit parameter creation (so that
+seeding + `init()` reproduce the reference's initial weights and checkpoints interchange); their
+`forward` never calls into ATen.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import Parameter as P
+
+from .. import functional as TF
+
+
+def _check_same_conv(m):
+    k = m.kernel_size
+    if any(s != 1 for s in m.stride) or any(d != 1 for d in m.dilation) or m.groups != 1 or \
+            any(p != kk // 2 for p, kk in zip(m.padding, k)) or any(kk not in (1, 3) for kk in k):
+        raise NotImplementedError('HIP conv path covers stride-1 same-padded 1/3-wide kernels (all the hot path uses)')
+
+
+class Conv3d(nn.Conv3d):
+    """nn.Conv3d call sites: resnet3d.py:13-18, layers.py:231-238 (via which_conv)."""
+
+    def forward(self, x):
+        _check_same_conv(self)
+        return TF.conv(x, self.weight, self.bias)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d call sites: layers.py:174-183,251, conv_lstm.py:19-26."""
+
+    def forward(self, x):
+        _check_same_conv(self)
+        return TF.conv(x, self.weight, self.bias)
+
+
+class Linear(nn.Linear):
+    """nn.Linear call sites: resnet3d.py:33-35, tganv2*/gen.py fc."""
+
+    def forward(self, x):
+        return TF.linear(x, self.weight, self.bias)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """Training-mode batch statistics / eval-mode running statistics, optional fused ReLU."""
+
+    def forward(self, x, relu=False):
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError('only the default BatchNorm2d configuration is on the hot path')
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.momentum, self.eps, relu)
+
+
+class ReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return TF.relu(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, scale_factor=2):
+        super().__init__()
+        assert scale_factor == 2
+        self.scale_factor = scale_factor
+
+    def forward(self, x):
+        return TF.upsample2x(x)
+
+
+class Tanh(nn.Module):
+    def forward(self, x):
+        return TF.tanh(x)
+
+
+class AvgPool3d(nn.Module):
+    """nn.AvgPool3d((1,2,2), 2) of resnet3d.py:16,18 — the int stride applies to T as well."""
+
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        t3 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+        self.kernel_size = t3(kernel_size)
+        self.stride = t3(stride if stride is not None else kernel_size)
+        self.padding = t3(padding)
+
+    def forward(self, x):
+        return TF.avg_pool3d(x, self.kernel_size, self.stride, self.padding)
+
+
+def _nonlocal(self, x, pooled_planes):
+    """Shared body of Attention / Attention3d (layers.py:23-36, 52-68)."""
+    b = x.size(0)
+    theta = self.theta(x)
+    phi = TF.max_pool2x2(self.phi(x))
+    g = TF.max_pool2x2(self.g(x))
+    theta = theta.reshape(b, self.ch // 8, -1)
+    phi = phi.reshape(b, self.ch // 8, -1)
+    g = g.reshape(b, self.ch // 2, -1)
+    beta = TF.softmax_lastdim(TF.bmm(theta, phi, True, False))          # [b, N, N/4]
+    o = TF.bmm(g, beta, False, True).reshape((b, self.ch // 2) + tuple(x.shape[2:]))
+    o = self.o(o)
+    return TF.scale_add(self.gamma, o, x)
+
+
+class Attention(nn.Module):
+    """2-D non-local block (SA-GAN style) — layers.py:10-36."""
+
+    def __init__(self, ch, which_conv=None, name='attention'):
+        super().__init__()
+        which_conv = which_conv or Conv2d
+        self.ch = ch
+        self.which_conv = which_conv
+        self.theta = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.phi = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.g = which_conv(ch, ch // 2, kernel_size=1, padding=0, bias=False)
+        self.o = which_conv(ch // 2, ch, kernel_size=1, padding=0, bias=False)
+        self.gamma = P(torch.tensor(0.), requires_grad=True)
+
+    def forward(self, x, y=None):
+        return _nonlocal(self, x, 2)
+
+
+class Attention3d(nn.Module):
+    """3-D non-local block, max-pool [1,2,2] on phi/g — layers.py:39-68."""
+
+    def __init__(self, ch, which_conv=None, name='attention'):
+        super().__init__()
+        which_conv = which_conv or Conv3d
+        self.ch = ch
+        self.which_conv = which_conv
+        self.theta = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.phi = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.g = which_conv(ch, ch // 2, kernel_size=1, padding=0, bias=False)
+        self.o = which_conv(ch // 2, ch, kernel_size=1, padding=0, bias=False)
+        self.gamma = P(torch.tensor(0.), requires_grad=True)
+
+    def forward(self, x, y=None):
+        return _nonlocal(self, x, 3)
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class ResidualBlock(nn.Module):
+    """identity_map(x) + inner_module(x); tags the inner path `is_residual` so that `init` applies the
+    sqrt(2) gain — layers.py:77-96."""
+
+    def __init__(self, inner_module=None, identity_map=None):
+        super().__init__()
+        self.inner_module = inner_module
+        self.identity_map = identity_map if identity_map is not None else Identity()
+
+        def tag(m):
+            m.is_residual = True
+        self.inner_module.apply(tag)
+
+    def forward(self, x):
+        return TF.add(self.identity_map(x), self.inner_module(x))
+
+
+class Subsample(nn.Module):
+    """`x[::sn, :, bt::st]`, bt ~ randint(st) on the CPU generator — layers.py:98-111."""
+
+    def __init__(self, sn=2, st=2):
+        super().__init__()
+        self.sn, self.st = sn, st
+
+    def forward(self, x, bt=None):
+        if bt is None:
+            bt = torch.randint(self.st, (1,))
+        bt_i = int(bt)
+        if x.is_cuda and x.dim() == 5 and self.sn == 2 and self.st == 2:
+            return TF.PyramidGather.apply(x, bt_i), bt
+        return x[::self.sn, :, bt_i::self.st], bt
+
+
+class UpBlock(nn.Module):
+    """BN-ReLU-Up-conv3x3-BN-ReLU-conv3x3 (+) Up-[conv1x1] — layers.py:152-195."""
+
+    def __init__(self, in_channels=128, out_channels=None, which_bn=None, which_conv=None, upsample_instead=True,
+                 which_unpool=None, wide=False, with_non_local=False):
+        super().__init__()
+        which_bn = which_bn or BatchNorm2d
+        which_conv = which_conv or Conv2d
+        self.in_channels = in_channels
+        self.out_channels = out_channels = in_channels if out_channels is None else out_channels
+        mid = in_channels if wide else out_channels
+        assert upsample_instead
+        main = nn.Sequential(which_bn(in_channels), ReLU(), Upsample(2), which_conv(in_channels, mid, 3, 1, padding=1),
+                             which_bn(mid), ReLU(), which_conv(mid, out_channels, 3, 1, padding=1))
+        ident = Upsample(2)
+        if in_channels != out_channels:
+            ident = nn.Sequential(ident, which_conv(in_channels, out_channels, 1))
+        self.main = ResidualBlock(inner_module=main, identity_map=ident)
+        self.with_non_local = with_non_local
+        if with_non_local:
+            self.attn = Attention(out_channels)
+
+    def forward(self, x):
+        m = self.main.inner_module
+        h = m[0](x, relu=True) if isinstance(m[0], BatchNorm2d) else m[1](m[0](x))     # BN+ReLU fused
+        h = m[3](m[2](h))
+        h = m[4](h, relu=True) if isinstance(m[4], BatchNorm2d) else m[5](m[4](h))
+        h = m[6](h)
+        x = TF.add(self.main.identity_map(x), h)
+        if self.with_non_local:
+            x = self.attn(x)
+        return x
+
+
+class DownSample(nn.Module):
+    """Average-pool by 2 every spatial/temporal dim of extent > 1 (pad 1 if odd) — layers.py:197-217."""
+
+    def forward(self, x):
+        k, s, p = [1, 1, 1], [1, 1, 1], [0, 0, 0]
+        for i in range(3):
+            n = x.size(i + 2)
+            if n == 1:
+                continue
+            k[i] = s[i] = 2
+            if n % 2:
+                p[i] = 1
+        if k == [1, 1, 1]:
+            return x
+        return TF.avg_pool3d(x, k, s, p)
+
+
+class DownBlock(nn.Module):
+    """ReLU-conv-ReLU-conv-DownSample (+) conv1-DownSample — layers.py:219-243."""
+
+    def __init__(self, in_channels=3, out_channels=None, which_conv=None, wide=True):
+        super().__init__()
+        which_conv = which_conv or Conv3d
+        out_channels = in_channels if out_channels is None else out_channels
+        mid = out_channels if wide else in_channels
+        main = nn.Sequential(ReLU(), which_conv(in_channels, mid, kernel_size=3, padding=1), ReLU(),
+                             which_conv(mid, out_channels, kernel_size=3, padding=1), DownSample())
+        ident = nn.Sequential(which_conv(in_channels, out_channels, 1), DownSample())
+        self.main = ResidualBlock(inner_module=main, identity_map=ident)
+
+    def forward(self, x):
+        return self.main(x)
+
+
+class RenderBlock(nn.Module):
+    """BN-ReLU-conv3x3-tanh — layers.py:245-259."""
+
+    def __init__(self, in_channels=128, out_channels=3, which_bn=None, which_conv=None):
+        super().__init__()
+        which_bn = which_bn or BatchNorm2d
+        which_conv = which_conv or Conv2d
+        self.bn = which_bn(in_channels)
+        self.activation = ReLU()
+        self.conv = which_conv(in_channels, out_channels, kernel_size=3, padding=1)
+        self.final = Tanh()
+
+    def forward(self, x):
+        h = self.bn(x, relu=True) if isinstance(self.bn, BatchNorm2d) else self.activation(self.bn(x))
+        return self.final(self.conv(h))

@@ -1,0 +1,47 @@
+"""3-D ResNet discriminator trunk with a non-local block and un/conditional heads — same surface and
+state_dict as txt2vid/models/resnet3d.py:6-57, every op a gfx950 kernel."""
+import torch
+import torch.nn as nn
+
+from .. import functional as TF
+from .layers import ResidualBlock, DownBlock, Attention3d, Conv3d, AvgPool3d, ReLU, Linear
+
+
+class Resnet3D(nn.Module):
+
+    def __init__(self, num_channels=1, mid_ch=64, which_conv=None, which_pool=None, cond_dim=0, num_down_blocks=4,
+                 wide=False, with_attn=True):
+        super().__init__()
+        which_conv = which_conv or Conv3d
+        which_pool = which_pool or AvgPool3d
+        self.activation = ReLU()
+        res_path = nn.Sequential(which_conv(num_channels, mid_ch, 3, 1, padding=1), self.activation,
+                                 which_conv(mid_ch, mid_ch, 3, 1, padding=1), which_pool((1, 2, 2), 2))
+        skip = nn.Sequential(which_pool((1, 2, 2), 2), which_conv(num_channels, mid_ch, 1))
+        self.res_block = ResidualBlock(inner_module=res_path, identity_map=skip)
+        down, in_ch, out_ch = [], mid_ch, 128
+        for i in range(num_down_blocks):
+            down.append(DownBlock(in_channels=in_ch, out_channels=out_ch, which_conv=which_conv, wide=wide))
+            if i == 0 and with_attn:
+                down.append(Attention3d(out_ch, which_conv=which_conv))
+            in_ch, out_ch = out_ch, out_ch * 2
+        self.down = nn.ModuleList(down)
+        self.fc_uncond = Linear(in_ch, 1)
+        if cond_dim > 0:
+            self.fc = Linear(in_ch + cond_dim, 1)
+
+    def forward(self, x=None, cond=None, xbar=None, computed_features=None):
+        uncond = None
+        if computed_features is not None:
+            x = computed_features
+        else:
+            x = self.res_block(x)
+            for d in self.down:
+                x = d(x)
+            x = TF.sum_spatial(x)                           # torch.sum(x, [2,3,4])  (resnet3d.py:48)
+            computed_features = x
+            uncond = self.fc_uncond(x)
+        if cond is not None:
+            c = self.fc(TF.cat_features(x, cond))
+            return uncond, c, computed_features
+        return uncond, None, computed_features
