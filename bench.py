@@ -1,0 +1,203 @@
+"""bench.py — TGANv2 training throughput on MI355X (see the driver contract in DESIGN.md §Measurement).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): unconditional TGANv2, 16x64x64x1 clips, per-GPU batch 32, fp32,
+RSGAN + zero-centred GP (lambda 0.5), Adam(2e-4, (0.5, 0.999)), 1 D step + 1 G step per iteration,
+--subsample_input pyramid 8/16/32/64; synthetic Moving-MNIST-shaped batches resident in HBM.
+One "step" = one full iteration of txt2vid_amd.gan.trainer.train_iteration (G fwd, D loss + GP double
+backward, Adam, real_pred, G loss backward through D, Adam). Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_SAMPLE_AS_WRITTEN = 49.27      # reference-executed FLOPs per base sample, uncond, GP on
+
+
+class Params(object):
+    frame_sizes = [8, 16, 32, 64]
+    subsample_input = True
+    discrim_steps = gen_steps = 1
+    gp_lambda = 0.5
+    no_mean_discrim_loss = no_mean_gen_loss = True
+
+
+def build_models(dev, seed=100):
+    from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+    from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+    from txt2vid_amd.gan.cond_gan import CondGan
+    from txt2vid_amd.gan.losses import MixedGanLoss, RSGANLoss
+    from txt2vid_amd.optim import Adam
+    from txt2vid_amd.util.torch.init import init
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    gen = MultiScaleGen(width=64, height=64, num_channels=1)
+    dis = MultiScaleDiscrim(num_channels=1)
+    init(gen, 'xavier')
+    init(dis, 'xavier')
+    gen.to(dev).train()
+    dis.to(dev).train()
+    optD = Adam([{'params': dis.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = Adam([{'params': gen.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    return gen, dis, optD, optG, MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss()), CondGan
+
+
+def synthetic_batches(batch, n, seed, dev):
+    from txt2vid_amd.data import SyntheticMovingDigits
+    ds = SyntheticMovingDigits(length=batch * n, seed=seed)
+    out = []
+    for i in range(n):
+        vids = torch.stack([ds[i * batch + j][0] for j in range(batch)], 0)          # [B,T,C,H,W]
+        out.append(vids.permute(0, 2, 1, 3, 4).contiguous().to(dev))                # [B,C,T,H,W] in HBM
+    return out
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (== reference semantics, pinned by tests/test_oracle_golden.py) on the host cores:
+    BASELINE config-1 shape (uncond, B=4, GP on), 1 warm-up + 2 timed iterations."""
+    from oracle import tganv2_oracle as O
+    torch.set_num_threads(threads)
+    PG = O.recipe_state(O.gen_shapes(num_channels=1), attn_gamma=0.0)
+    PD = O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0), attn_gamma=0.0)
+    tr = O.OracleTrainer(PG, PD)
+    B = 4
+    xs = [(torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4) for _ in range(3)]
+    tr.step(xs[0])
+    t0 = time.time()
+    for x in xs[1:]:
+        tr.step(x)
+    dt = (time.time() - t0) / 2
+    return {'value': B / dt, 'unit': 'videos/s', 'cores': threads, 'kind': 'port',
+            'sample': 'CPU oracle (plain fp32 PyTorch restatement), uncond TGANv2 16x64x64x1, B=4, RSGAN+GP, '
+                      '2 timed iterations after 1 warm-up, %.2f s/iter' % dt,
+            'steps_per_sec': 1.0 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_roofline', action='store_true')
+    args = ap.parse_args()
+
+    from txt2vid_amd import dist as tdist
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd._lib import lib
+    import torch.distributed as dist
+
+    rank, world = tdist.init_from_env('nccl')
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    T0 = time.perf_counter()
+    gen, dis, optD, optG, losses, CondGan = build_models(dev)
+    gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'], gp_scale=float(world))
+    grad_sync = None
+    if world > 1:
+        arenas = {'D': tdist.GradArena(dis.parameters(), TF.copy_into), 'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
+        grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
+    prm = Params()
+    pool = synthetic_batches(args.batch, 4, 100 + rank, dev)
+    random.seed(100 + rank)
+    np.random.seed(100 + rank)
+    torch.manual_seed(100 + rank)
+
+    from txt2vid_amd.gan.trainer import train_iteration
+
+    def step(i):
+        return train_iteration(gan, pool[i % len(pool)], None, optD, optG, losses, prm, dev, grad_sync=grad_sync)
+
+    def log(msg):
+        if rank == 0:
+            sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - T0, msg))
+            sys.stderr.flush()
+
+    log('models + data ready; warm-up')
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        log('warm-up step %d done' % i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = not args.no_roofline
+    barrier()
+    if prof:
+        lib().t2v_prof_begin(min(1 << 16, 4096 * args.steps))
+        log('instrumentation ready')
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lD, lG, _, _ = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
+    roof = None
+    if prof:
+        out = (C.c_double * 9)()
+        over = lib().t2v_prof_end(out, 3)
+        ms, fl, cnt = out[0], out[1], out[2]
+        if cnt > 0 and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                    'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2)',
+                    'launches_per_step': cnt / args.steps, 'avg_launch_us': ms * 1e3 / cnt,
+                    'flops_counted': 'executed MACs x2 (padding-only taps excluded), summed over all launches',
+                    'share_of_step_time': ms * 1e-3 / dt, 'pool_overflow': bool(over),
+                    'wgrad': {'achieved': (out[4] / (out[3] * 1e-3) / 1e12) if out[3] > 0 else None,
+                              'launches_per_step': out[5] / args.steps, 'share_of_step_time': out[3] * 1e-3 / dt,
+                              'reduce_share_of_step_time': out[6] * 1e-3 / dt}}
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    gb = args.batch * world
+    res = {
+        'metric': 'TGANv2 GAN train throughput (G+D steps x global batch), 16x64x64 videos/sec',
+        'value': gb * args.steps / dt, 'unit': 'videos/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'steps_per_sec': args.steps / dt, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: unconditional TGANv2 16x64x64x1, per-GPU batch %d, fp32, RSGAN + GP 0.5, '
+                               'Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid 8/16/32/64' % args.batch,
+                   'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
+                   'as_written_tflop_per_step': GFLOP_PER_SAMPLE_AS_WRITTEN * gb / 1e3},
+        'final_losses': {'lossD': float(lD), 'lossG': float(lG)},
+        'as_written_tflops': GFLOP_PER_SAMPLE_AS_WRITTEN * gb * args.steps / dt / 1e3,
+    }
+    if roof is not None:
+        res['roofline'] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

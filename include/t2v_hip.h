@@ -171,6 +171,15 @@ int t2v_scalar_combine(const void* const* ptrs, const float* weights, int n, flo
 /* out[r,:] = x[perm[r],:] (inverse=1: out[perm[r],:] = x[r,:]) — cond[gen_perm(B)] of cond_gan.py:133 */
 int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* stream);
 
+
+/* ---- optional launch instrumentation for bench.py's roofline line -----------------------------------
+ * Between begin and end every conv-GEMM launch is bracketed by a hipEvent pair recorded on the launch
+ * stream. end() synchronises and fills out[kind*3+{0,1,2}] = {total ms, executed flops, launches};
+ * kind 0 = forward/data-gradient implicit GEMM, 1 = weight-gradient GEMM, 2 = its split-K reduce.
+ * Returns 1 if the record pool overflowed (totals then cover the recorded launches only). */
+int t2v_prof_begin(int max_records);
+int t2v_prof_end(double* out, int nkinds);
+
 const char* t2v_version(void);
 
 #ifdef __cplusplus

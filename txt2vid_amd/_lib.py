@@ -77,6 +77,8 @@ SIGNATURES = {
     't2v_pyramid_scatter': [_P, _P, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P],
     't2v_scalar_combine': [_P, C.POINTER(C.c_float), _I, _P, _P],
     't2v_gather_rows': [_P, _P, _P, _L, _L, _I, _P],
+    't2v_prof_begin': [_I],
+    't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
 _RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_version': C.c_char_p}
@@ -95,6 +97,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise T2VError('libt2v_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
                            'or `make -C txt2vid_amd/csrc`. There is no CPU/PyTorch fallback.' % LIB_PATH)
+        # torch first: it bundles its own libamdhip64.so.7 / libhsa-runtime64 (same SONAMEs as /opt/rocm).
+        # Whichever is mapped first serves the whole process, and our kernels must launch on the SAME
+        # HIP runtime that owns torch's device memory and streams.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if a declared symbol is not exported

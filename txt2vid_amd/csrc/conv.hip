@@ -17,9 +17,70 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
 
+// hipGetLastError() is sticky per thread and also reports errors of calls the HOST framework made and
+// handled earlier; clear it before every launch so that launch_status() reflects this launch only.
+#define T2V_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? T2V_OK : -(int)e - 1000;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// optional launch instrumentation (bench.py roofline): hipEvent pairs recorded ON THE LAUNCH STREAM
+// around every conv-GEMM launch while enabled. Off by default; the product path never enables it.
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+struct ProfRec { hipEvent_t e0, e1; double flops; int kind; };
+static struct {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    size_t used = 0;
+} g_prof;
+
+struct ProfScope {
+    ProfRec* r = nullptr;
+    hipStream_t s;
+    ProfScope(int kind, double flops, hipStream_t stream) : s(stream) {
+        if (g_prof.on && g_prof.used < g_prof.recs.size()) {
+            r = &g_prof.recs[g_prof.used++];
+            r->kind = kind;
+            r->flops = flops;
+            (void)hipEventRecord(r->e0, s);
+        }
+    }
+    ~ProfScope() { if (r) (void)hipEventRecord(r->e1, s); }
+};
+
+extern "C" int t2v_prof_begin(int max_records) {
+    if (max_records < 1 || max_records > (1 << 20)) return T2V_EINVAL;
+    if ((int)g_prof.recs.size() < max_records) {
+        size_t old = g_prof.recs.size();
+        g_prof.recs.resize(max_records);
+        for (size_t i = old; i < g_prof.recs.size(); ++i) {
+            if (hipEventCreate(&g_prof.recs[i].e0) != hipSuccess || hipEventCreate(&g_prof.recs[i].e1) != hipSuccess) return T2V_ELAUNCH;
+        }
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return T2V_OK;
+}
+// out[kind*3 + {0,1,2}] = {total ms, total flops, launches} for kind in 0..nkinds-1. Synchronises.
+extern "C" int t2v_prof_end(double* out, int nkinds) {
+    g_prof.on = false;
+    if (!out || nkinds < 1) return T2V_EINVAL;
+    for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        ProfRec& r = g_prof.recs[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) return T2V_ELAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return T2V_ELAUNCH;
+        if (r.kind >= 0 && r.kind < nkinds) { out[r.kind * 3] += ms; out[r.kind * 3 + 1] += r.flops; out[r.kind * 3 + 2] += 1.0; }
+    }
+    int dropped = (g_prof.used >= g_prof.recs.size()) ? 1 : 0;
+    g_prof.used = 0;
+    return dropped;    // 1: the record pool filled up (totals cover the recorded launches only)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -65,7 +126,7 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
         tl.t[i] = taps[i];
     }
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, ntaps);
-    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, T, tl, mode);
+    T2V_LAUNCH(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, T, tl, mode);
     return launch_status();
 }
 
@@ -226,10 +287,11 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
                        hipStream_t s) {
     const long M = (long)g.N * g.D * g.H * g.W;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((g.Cout + BN - 1) / BN));
+    ProfScope prof(0, 2.0 * (double)M * g.Cout * g.Cin * g.ntaps, s);      // executed (non-padding-tap) MACs x 2
     if (g.Cin % BK == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_CO, true>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
+        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, true>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_CO, false>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
+        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, false>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
     return launch_status();
 }
 
@@ -396,11 +458,15 @@ extern "C" int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float*
     const long nchunks = (M + WG_BK - 1) / WG_BK;
     const int cps = (int)((nchunks + S - 1) / S);
     dim3 grid((unsigned)(((g->Cout + 63) / 64) * ((g->Cin + 63) / 64)), (unsigned)g->ntaps, (unsigned)S);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, s, x, gy, slab, *g, flags, cps);
+    {
+        ProfScope prof(1, 2.0 * (double)M * g->Cout * g->Cin * g->ntaps, s);
+        T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, x, gy, slab, *g, flags, cps);
+    }
     int st = launch_status();
     if (st) return st;
     const long CoCi = (long)g->Cout * g->Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 255) / 256)), dim3(256), 0, s, slab, dw, CoCi, T,
+    ProfScope prof2(2, 0.0, s);
+    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 255) / 256)), dim3(256), 0, s, slab, dw, CoCi, T,
                        g->ntaps, S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
     return launch_status();
 }
@@ -428,6 +494,6 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 
 extern "C" int t2v_channel_sum(const float* x, float* out, int N, int C, int64_t S, int accum, void* stream) {
     if (!x || !out || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, (long)S, accum);
+    T2V_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, (long)S, accum);
     return launch_status();
 }

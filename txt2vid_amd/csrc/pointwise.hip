@@ -5,6 +5,10 @@
 #include <stdint.h>
 #include "../../include/t2v_hip.h"
 
+// hipGetLastError() is sticky per thread and also reports errors of calls the HOST framework made and
+// handled earlier; clear it before every launch so that launch_status() reflects this launch only.
+#define T2V_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? T2V_OK : -(int)e - 1000;
@@ -54,42 +58,42 @@ __global__ void tanh_bwd_k(const float* g, const float* y, float* gx, long n) { 
 
 extern "C" int t2v_relu(const float* x, float* y, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(relu_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
+    T2V_LAUNCH(relu_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
     return launch_status();
 }
 extern "C" int t2v_relu_mask(const float* g, const float* x, float* gx, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(relu_mask_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, x, gx, (long)n);
+    T2V_LAUNCH(relu_mask_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, x, gx, (long)n);
     return launch_status();
 }
 extern "C" int t2v_add(const float* a, const float* b, float* y, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(add_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, y, (long)n);
+    T2V_LAUNCH(add_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, y, (long)n);
     return launch_status();
 }
 extern "C" int t2v_axpby(float al, const float* a, float be, const float* b, float* y, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(axpby_k, dim3(nblocks(n)), dim3(256), 0, S_(st), al, a, be, b, y, (long)n);
+    T2V_LAUNCH(axpby_k, dim3(nblocks(n)), dim3(256), 0, S_(st), al, a, be, b, y, (long)n);
     return launch_status();
 }
 extern "C" int t2v_scale_dev(const float* s, float mul, const float* a, float* y, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(scale_dev_k, dim3(nblocks(n)), dim3(256), 0, S_(st), s, mul, a, y, (long)n);
+    T2V_LAUNCH(scale_dev_k, dim3(nblocks(n)), dim3(256), 0, S_(st), s, mul, a, y, (long)n);
     return launch_status();
 }
 extern "C" int t2v_fill(float* y, float v, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(fill_k, dim3(nblocks(n)), dim3(256), 0, S_(st), y, v, (long)n);
+    T2V_LAUNCH(fill_k, dim3(nblocks(n)), dim3(256), 0, S_(st), y, v, (long)n);
     return launch_status();
 }
 extern "C" int t2v_tanh(const float* x, float* y, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(tanh_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
+    T2V_LAUNCH(tanh_k, dim3(nblocks(n)), dim3(256), 0, S_(st), x, y, (long)n);
     return launch_status();
 }
 extern "C" int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n, void* st) {
     if (n <= 0) return n == 0 ? T2V_OK : T2V_EINVAL;
-    hipLaunchKernelGGL(tanh_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, y, gx, (long)n);
+    T2V_LAUNCH(tanh_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), g, y, gx, (long)n);
     return launch_status();
 }
 
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void dot_k(const float* a, const float* b, flo
 }
 extern "C" int t2v_dot(const float* a, const float* b, float* out, int64_t n, int accum, void* st) {
     if (n <= 0) return T2V_EINVAL;
-    hipLaunchKernelGGL(dot_k, dim3(1), dim3(256), 0, S_(st), a, b, out, (long)n, accum);
+    T2V_LAUNCH(dot_k, dim3(1), dim3(256), 0, S_(st), a, b, out, (long)n, accum);
     return launch_status();
 }
 
@@ -178,7 +182,7 @@ extern "C" int t2v_avgpool3d(const float* x, float* y, int NC, int D, int H, int
     if (!x || !y || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
     Pool3 q;
     for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
-    hipLaunchKernelGGL(avgpool3d_k, dim3(nblocks((long)NC * Do * Ho * Wo)), dim3(256), 0, S_(st), x, y, NC, D, H, W, Do, Ho, Wo, q);
+    T2V_LAUNCH(avgpool3d_k, dim3(nblocks((long)NC * Do * Ho * Wo)), dim3(256), 0, S_(st), x, y, NC, D, H, W, Do, Ho, Wo, q);
     return launch_status();
 }
 extern "C" int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
@@ -186,7 +190,7 @@ extern "C" int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int 
     if (!gy || !gx || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
     Pool3 q;
     for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
-    hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
+    T2V_LAUNCH(avgpool3d_bwd_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
     return launch_status();
 }
 
@@ -238,17 +242,17 @@ __global__ void maxpool2x2_gather_k(const float* x, const int32_t* idx, float* y
 }
 extern "C" int t2v_maxpool2x2(const float* x, float* y, int32_t* idx, int64_t planes, int H, int W, void* st) {
     if (!x || !y || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
-    hipLaunchKernelGGL(maxpool2x2_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, y, idx, (long)planes, H, W);
+    T2V_LAUNCH(maxpool2x2_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, y, idx, (long)planes, H, W);
     return launch_status();
 }
 extern "C" int t2v_maxpool2x2_scatter(const float* g, const int32_t* idx, float* gx, int64_t planes, int H, int W, void* st) {
     if (!g || !gx || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
-    hipLaunchKernelGGL(maxpool2x2_scatter_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), g, idx, gx, (long)planes, H, W);
+    T2V_LAUNCH(maxpool2x2_scatter_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), g, idx, gx, (long)planes, H, W);
     return launch_status();
 }
 extern "C" int t2v_maxpool2x2_gather(const float* x, const int32_t* idx, float* y, int64_t planes, int H, int W, void* st) {
     if (!x || !y || !idx || planes < 1 || H < 2 || W < 2) return T2V_EINVAL;
-    hipLaunchKernelGGL(maxpool2x2_gather_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, idx, y, (long)planes, H, W);
+    T2V_LAUNCH(maxpool2x2_gather_k, dim3(nblocks(planes * (H / 2) * (W / 2))), dim3(256), 0, S_(st), x, idx, y, (long)planes, H, W);
     return launch_status();
 }
 
@@ -268,12 +272,12 @@ __global__ void rowbcast_k(const float* g, float* gx, long rows, long S) {
 }
 extern "C" int t2v_rowsum(const float* x, float* y, int64_t rows, int64_t S, void* st) {
     if (!x || !y || rows < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(rowsum_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, (long)S);
+    T2V_LAUNCH(rowsum_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, (long)S);
     return launch_status();
 }
 extern "C" int t2v_rowbcast(const float* g, float* gx, int64_t rows, int64_t S, void* st) {
     if (!g || !gx || rows < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(rowbcast_k, dim3(nblocks(rows * S)), dim3(256), 0, S_(st), g, gx, (long)rows, (long)S);
+    T2V_LAUNCH(rowbcast_k, dim3(nblocks(rows * S)), dim3(256), 0, S_(st), g, gx, (long)rows, (long)S);
     return launch_status();
 }
 
@@ -299,12 +303,12 @@ __global__ void upsample2x_bwd_k(const float* gy, float* gx, long planes, int H,
 }
 extern "C" int t2v_upsample2x(const float* x, float* y, int64_t planes, int H, int W, void* st) {
     if (!x || !y || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, y, (long)planes, H, W);
+    T2V_LAUNCH(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, y, (long)planes, H, W);
     return launch_status();
 }
 extern "C" int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* st) {
     if (!gy || !gx || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(upsample2x_bwd_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), gy, gx, (long)planes, H, W);
+    T2V_LAUNCH(upsample2x_bwd_k, dim3(nblocks(planes * H * W)), dim3(256), 0, S_(st), gy, gx, (long)planes, H, W);
     return launch_status();
 }
 
@@ -395,27 +399,27 @@ __global__ void bn_eval_k(const float* x, const float* rm, const float* rv, cons
 extern "C" int t2v_bn_stats(const float* x, float* stats, float* rm, float* rv, int N, int C, int64_t S, float momentum,
                             float eps, void* st) {
     if (!x || !stats || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(bn_stats_k, dim3(C), dim3(256), 0, S_(st), x, stats, rm, rv, N, C, (long)S, momentum, eps);
+    T2V_LAUNCH(bn_stats_k, dim3(C), dim3(256), 0, S_(st), x, stats, rm, rv, N, C, (long)S, momentum, eps);
     return launch_status();
 }
 extern "C" int t2v_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int N, int C,
                             int64_t S, int relu, void* st) {
     if (!x || !stats || !gamma || !beta || !y || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(bn_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, stats, gamma, beta, y, N, C, (long)S, relu);
+    T2V_LAUNCH(bn_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, stats, gamma, beta, y, N, C, (long)S, relu);
     return launch_status();
 }
 extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
                           float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* st) {
     if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
     if (relu && !y) return T2V_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3(C), dim3(256), 0, S_(st), gy, x, y, stats, ws, ggamma, gbeta, N, C, (long)S, relu);
-    hipLaunchKernelGGL(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
+    T2V_LAUNCH(bn_bwd_reduce_k, dim3(C), dim3(256), 0, S_(st), gy, x, y, stats, ws, ggamma, gbeta, N, C, (long)S, relu);
+    T2V_LAUNCH(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
     return launch_status();
 }
 extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,
                            int N, int C, int64_t S, float eps, int relu, void* st) {
     if (!x || !rm || !rv || !gamma || !beta || !y || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(bn_eval_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, rm, rv, gamma, beta, y, N, C, (long)S, eps, relu);
+    T2V_LAUNCH(bn_eval_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), x, rm, rv, gamma, beta, y, N, C, (long)S, eps, relu);
     return launch_status();
 }
 
@@ -451,13 +455,13 @@ __global__ void lstm_gates_bwd_k(const float* gh, const float* gc_in, const floa
 }
 extern "C" int t2v_lstm_gates(const float* pre, const float* c_prev, float* h, float* c_new, float* act, int B, int64_t CS, void* st) {
     if (!pre || !c_prev || !h || !c_new || !act || B < 1 || CS < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(lstm_gates_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), pre, c_prev, h, c_new, act, B, (long)CS);
+    T2V_LAUNCH(lstm_gates_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), pre, c_prev, h, c_new, act, B, (long)CS);
     return launch_status();
 }
 extern "C" int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const float* act, const float* c_prev, const float* c_new,
                                   float* gpre, float* gc_prev, int B, int64_t CS, void* st) {
     if (!gh || !act || !c_prev || !c_new || !gpre || !gc_prev || B < 1 || CS < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(lstm_gates_bwd_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), gh, gc_in, act, c_prev, c_new, gpre, gc_prev, B, (long)CS);
+    T2V_LAUNCH(lstm_gates_bwd_k, dim3(nblocks((long)B * CS)), dim3(256), 0, S_(st), gh, gc_in, act, c_prev, c_new, gpre, gc_prev, B, (long)CS);
     return launch_status();
 }
 
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void bmm_k(const float* A, const float* B, flo
 extern "C" int t2v_bmm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int ta, int tb, int accum, void* st) {
     if (!A || !B || !C || batch < 1 || M < 1 || N < 1 || K < 1 || batch > 65535) return T2V_EINVAL;
     dim3 grid((N + 15) / 16, (M + 15) / 16, batch);
-    hipLaunchKernelGGL(bmm_k, grid, dim3(256), 0, S_(st), A, B, C, M, N, K, ta, tb, accum);
+    T2V_LAUNCH(bmm_k, grid, dim3(256), 0, S_(st), A, B, C, M, N, K, ta, tb, accum);
     return launch_status();
 }
 
@@ -535,17 +539,17 @@ __global__ __launch_bounds__(256) void softmax_bwd_bwd_y_k(const float* y, const
 }
 extern "C" int t2v_softmax(const float* x, float* y, int64_t rows, int n, void* st) {
     if (!x || !y || rows < 1 || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(softmax_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, n);
+    T2V_LAUNCH(softmax_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), x, y, (long)rows, n);
     return launch_status();
 }
 extern "C" int t2v_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, int n, void* st) {
     if (!y || !gy || !gx || rows < 1 || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(softmax_bwd_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gx, (long)rows, n);
+    T2V_LAUNCH(softmax_bwd_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gx, (long)rows, n);
     return launch_status();
 }
 extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, float* out, int64_t rows, int n, void* st) {
     if (!y || !gy || !gg || !out || rows < 1 || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(softmax_bwd_bwd_y_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gg, out, (long)rows, n);
+    T2V_LAUNCH(softmax_bwd_bwd_y_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(st), y, gy, gg, out, (long)rows, n);
     return launch_status();
 }
 
@@ -570,12 +574,12 @@ __global__ void rsgan_bwd_k(const float* a, const float* b, const float* gl, flo
 }
 extern "C" int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* st) {
     if (!a || !b || !loss || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(rsgan_k, dim3(1), dim3(256), 0, S_(st), a, b, loss, n);
+    T2V_LAUNCH(rsgan_k, dim3(1), dim3(256), 0, S_(st), a, b, loss, n);
     return launch_status();
 }
 extern "C" int t2v_rsgan_bwd(const float* a, const float* b, const float* gl, float* ga, float* gb, int n, void* st) {
     if (!a || !b || !gl || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(rsgan_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, gl, ga, gb, n);
+    T2V_LAUNCH(rsgan_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, gl, ga, gb, n);
     return launch_status();
 }
 
@@ -600,17 +604,17 @@ __global__ void row_scale_k(const float* s, float mul, const float* g, float* y,
 }
 extern "C" int t2v_lerp_rows(const float* alpha, const float* xr, const float* xf, float* y, int rows, int64_t S, void* st) {
     if (!alpha || !xr || !xf || !y || rows < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(lerp_rows_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), alpha, xr, xf, y, rows, (long)S);
+    T2V_LAUNCH(lerp_rows_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), alpha, xr, xf, y, rows, (long)S);
     return launch_status();
 }
 extern "C" int t2v_row_sqnorm(const float* g, float* out, int rows, int64_t S, void* st) {
     if (!g || !out || rows < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(row_sqnorm_k, dim3(rows), dim3(256), 0, S_(st), g, out, rows, (long)S);
+    T2V_LAUNCH(row_sqnorm_k, dim3(rows), dim3(256), 0, S_(st), g, out, rows, (long)S);
     return launch_status();
 }
 extern "C" int t2v_row_scale(const float* s, float mul, const float* g, float* y, int rows, int64_t S, void* st) {
     if (!s || !g || !y || rows < 1 || S < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(row_scale_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), s, mul, g, y, rows, (long)S);
+    T2V_LAUNCH(row_scale_k, dim3(nblocks((long)rows * S)), dim3(256), 0, S_(st), s, mul, g, y, rows, (long)S);
     return launch_status();
 }
 
@@ -632,7 +636,7 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, long n, flo
 extern "C" int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                         float bc1, float bc2, float gscale, void* st) {
     if (!p || !g || !m || !v || n < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
+    T2V_LAUNCH(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
     return launch_status();
 }
 
@@ -654,7 +658,7 @@ extern "C" int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T,
                                   int sb, int stt, int bt, void* st) {
     if (!x || !y || B < 1 || C < 1 || T < 1 || Bo < 1 || To < 1 || Ho < 1 || Wo < 1) return T2V_EINVAL;
     if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + bt >= T) return T2V_EINVAL;
-    hipLaunchKernelGGL(pyramid_gather_k, dim3(nblocks((long)Bo * C * To * Ho * Wo)), dim3(256), 0, S_(st), x, y, B, C, T, H, W, Bo, To, Ho, Wo, sb, stt, bt);
+    T2V_LAUNCH(pyramid_gather_k, dim3(nblocks((long)Bo * C * To * Ho * Wo)), dim3(256), 0, S_(st), x, y, B, C, T, H, W, Bo, To, Ho, Wo, sb, stt, bt);
     return launch_status();
 }
 
@@ -669,7 +673,7 @@ __global__ void copy2d_k(const float* src, long src_ld, float* dst, long dst_ld,
 }
 extern "C" int t2v_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int64_t cols, void* st) {
     if (!src || !dst || rows < 1 || cols < 1 || src_ld < cols || dst_ld < cols) return T2V_EINVAL;
-    hipLaunchKernelGGL(copy2d_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), src, (long)src_ld, dst, (long)dst_ld, (long)rows, (long)cols);
+    T2V_LAUNCH(copy2d_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), src, (long)src_ld, dst, (long)dst_ld, (long)rows, (long)cols);
     return launch_status();
 }
 // x[A][B][inner] -> y[B][A][inner]
@@ -683,7 +687,7 @@ __global__ void permute01_k(const float* x, float* y, long A, long B, long inner
 }
 extern "C" int t2v_permute01(const float* x, float* y, int64_t A, int64_t B, int64_t inner, void* st) {
     if (!x || !y || A < 1 || B < 1 || inner < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(permute01_k, dim3(nblocks(A * B * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)inner);
+    T2V_LAUNCH(permute01_k, dim3(nblocks(A * B * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)inner);
     return launch_status();
 }
 // x[A][B][C][inner] -> y[A][C][B][inner]
@@ -698,7 +702,7 @@ __global__ void permute12_k(const float* x, float* y, long A, long B, long Cc, l
 }
 extern "C" int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int64_t Cc, int64_t inner, void* st) {
     if (!x || !y || A < 1 || B < 1 || Cc < 1 || inner < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(permute12_k, dim3(nblocks(A * B * Cc * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)Cc, (long)inner);
+    T2V_LAUNCH(permute12_k, dim3(nblocks(A * B * Cc * inner)), dim3(256), 0, S_(st), x, y, (long)A, (long)B, (long)Cc, (long)inner);
     return launch_status();
 }
 // merged-frames layout [b*T][inner]: keep samples ::2, frames bt::2. adjoint=1 writes y back into x.
@@ -715,7 +719,7 @@ extern "C" int t2v_subsample_frames(float* x, float* y, int64_t b, int64_t T, in
                                     int adjoint, void* st) {
     if (!x || !y || b < 1 || T < 1 || inner < 1 || bo < 1 || To < 1 || bt < 0 || bt > 1) return T2V_EINVAL;
     if (2 * (bo - 1) >= b || 2 * (To - 1) + bt >= T) return T2V_EINVAL;
-    hipLaunchKernelGGL(subsample_frames_k, dim3(nblocks(bo * To * inner)), dim3(256), 0, S_(st), x, y, (long)T, (long)inner, (long)bo, (long)To, bt, adjoint);
+    T2V_LAUNCH(subsample_frames_k, dim3(nblocks(bo * To * inner)), dim3(256), 0, S_(st), x, y, (long)T, (long)inner, (long)bo, (long)To, bt, adjoint);
     return launch_status();
 }
 // adjoint of pyramid_gather without spatial resampling: gx[b*sb, c, t*st+bt, :] = g[b, c, t, :]
@@ -732,7 +736,7 @@ extern "C" int t2v_pyramid_scatter(const float* g, float* gx, int B, int Cc, int
                                    int bt, void* st) {
     if (!g || !gx || B < 1 || Cc < 1 || T < 1 || HW < 1 || Bo < 1 || To < 1) return T2V_EINVAL;
     if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + bt >= T) return T2V_EINVAL;
-    hipLaunchKernelGGL(pyramid_scatter_k, dim3(nblocks((long)Bo * Cc * To * HW)), dim3(256), 0, S_(st), g, gx, (long)Cc, (long)T, (long)HW, (long)Bo, (long)To, sb, stt, bt);
+    T2V_LAUNCH(pyramid_scatter_k, dim3(nblocks((long)Bo * Cc * To * HW)), dim3(256), 0, S_(st), g, gx, (long)Cc, (long)T, (long)HW, (long)Bo, (long)To, sb, stt, bt);
     return launch_status();
 }
 
@@ -751,7 +755,7 @@ extern "C" int t2v_scalar_combine(const void* const* ptrs, const float* weights,
     ScalarList l;
     l.n = n;
     for (int i = 0; i < n; ++i) { l.p[i] = (const float*)ptrs[i]; l.w[i] = weights[i]; if (!l.p[i]) return T2V_EINVAL; }
-    hipLaunchKernelGGL(scalar_combine_k, dim3(1), dim3(64), 0, S_(st), l, out);
+    T2V_LAUNCH(scalar_combine_k, dim3(1), dim3(64), 0, S_(st), l, out);
     return launch_status();
 }
 // out[r] = x[perm[r]]  (inverse: out[perm[r]] = x[r])
@@ -764,7 +768,7 @@ __global__ void gather_rows_k(const float* x, const int32_t* perm, float* out, l
 }
 extern "C" int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* st) {
     if (!x || !perm || !out || rows < 1 || cols < 1) return T2V_EINVAL;
-    hipLaunchKernelGGL(gather_rows_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), x, perm, out, (long)rows, (long)cols, inverse);
+    T2V_LAUNCH(gather_rows_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), x, perm, out, (long)rows, (long)cols, inverse);
     return launch_status();
 }
 

@@ -1206,3 +1206,10 @@ def video_to_channel_first(x):
     out = torch.empty((B, Cc, T, H, W), device=x.device, dtype=torch.float32)
     check(lib().t2v_permute12(_p(x), _p(out), B, T, Cc, H * W, _stream()), 't2v_permute12')
     return out
+
+
+def copy_into(src, dst):
+    """dst <- src (dense, same numel) on the copy kernel (gradient arena gather, txt2vid_amd.dist)."""
+    src = _c(src)
+    n = src.numel()
+    _copy2d(src, 0, n, dst, 0, n, 1, n)
