@@ -55,8 +55,11 @@ int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const i
  * when given the mode-1 packed weight (x := dL/dy, Cin := Cout_fwd, Cout := Cin_fwd).
  * Replaces F.conv3d / F.conv2d / F.linear forward and their input-gradient
  * (autograd of the call sites above; double backward for losses.py:178). */
-int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const t2v_conv_geom* g,
+int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, float* ws, const t2v_conv_geom* g,
                  int flags, void* stream);
+/* floats of workspace `ws` the call above needs for this geometry (0: none). Layers with few output
+ * voxels and a long reduction are run split-K: partial tiles go to ws and are summed in a fixed order. */
+int64_t t2v_conv_fwd_ws_floats(const t2v_conv_geom* g);
 
 /* dw[Cout][Cin][T] = sum_m gy[m][co] * x[m + off(tap)][ci]   (weight gradient; PyTorch layout out).
  * `slab` is a workspace of t2v_conv_wgrad_slab_floats(g, T) floats (split-K partial sums, reduced
@@ -67,7 +70,8 @@ int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float* slab, cons
                    const int32_t* taps, int T, int flags, void* stream);
 
 /* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
-int t2v_channel_sum(const float* x, float* out, int N, int C, int64_t S, int accum, void* stream);
+int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S);   /* floats of `ws` needed (0: none) */
+int t2v_channel_sum(const float* x, float* out, float* ws, int N, int C, int64_t S, int accum, void* stream);
 
 /* ---- pointwise / pooling (txt2vid/models/layers.py, resnet3d.py) ------------------------------ */
 int t2v_relu(const float* x, float* y, int64_t n, void* stream);                 /* layers.py:172,230 */
@@ -75,7 +79,7 @@ int t2v_relu_mask(const float* g, const float* x, float* gx, int64_t n, void* st
 int t2v_add(const float* a, const float* b, float* y, int64_t n, void* stream);  /* layers.py:96     */
 int t2v_axpby(float alpha, const float* a, float beta, const float* b, float* y, int64_t n, void* stream);
 int t2v_scale_dev(const float* s, float mul, const float* a, float* y, int64_t n, void* stream); /* y = (*s*mul)*a */
-int t2v_dot(const float* a, const float* b, float* out, int64_t n, int accum, void* stream);
+int t2v_dot(const float* a, const float* b, float* out, float* ws /*256 floats*/, int64_t n, int accum, void* stream);
 int t2v_fill(float* y, float v, int64_t n, void* stream);
 int t2v_tanh(const float* x, float* y, int64_t n, void* stream);                 /* layers.py:258    */
 int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n, void* stream);
@@ -104,13 +108,14 @@ int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W,
 /* BatchNorm2d, training mode (layers.py:171,175,249): per-channel batch statistics over (N,H,W),
  * running stats updated with `momentum` (unbiased variance), y = relu?((x-mean)*invstd*gamma+beta).
  * stats[0:C] = mean, stats[C:2C] = invstd (saved for backward). */
-int t2v_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, int N, int C,
+int64_t t2v_bn_ws_floats(int N, int C, int64_t S);   /* floats of `ws` for bn_stats / bn_bwd */
+int t2v_bn_stats(const float* x, float* stats, float* running_mean, float* running_var, float* ws, int N, int C,
                  int64_t S, float momentum, float eps, void* stream);
 int t2v_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
                  int N, int C, int64_t S, int relu, void* stream);
 /* backward of bn_apply(+relu): needs y (for the relu mask) ; writes gx, ggamma[C], gbeta[C] */
 int t2v_bn_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma,
-               float* gx, float* ggamma, float* gbeta, float* ws /*2C floats*/, int N, int C, int64_t S,
+               float* gx, float* ggamma, float* gbeta, float* ws /*t2v_bn_ws_floats*/, int N, int C, int64_t S,
                int relu, void* stream);
 /* eval-mode affine: y = relu?((x-rm)*rsqrt(rv+eps)*gamma+beta) */
 int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta,

@@ -31,16 +31,18 @@ _G = C.POINTER(ConvGeom)
 # name -> argtypes (restype is int unless stated); must list EVERY symbol of include/t2v_hip.h
 SIGNATURES = {
     't2v_pack_weight': [_P, _P, _I, _I, _I, _I3, _I, _I, _P],
-    't2v_conv_fwd': [_P, _P, _P, _P, _G, _I, _P],
+    't2v_conv_fwd': [_P, _P, _P, _P, _P, _G, _I, _P],
+    't2v_conv_fwd_ws_floats': [_G],
     't2v_conv_wgrad_slab_floats': [_G],
     't2v_conv_wgrad': [_P, _P, _P, _P, _G, _I3, _I, _I, _P],
-    't2v_channel_sum': [_P, _P, _I, _I, _L, _I, _P],
+    't2v_channel_sum_ws_floats': [_I, _I, _L],
+    't2v_channel_sum': [_P, _P, _P, _I, _I, _L, _I, _P],
     't2v_relu': [_P, _P, _L, _P],
     't2v_relu_mask': [_P, _P, _P, _L, _P],
     't2v_add': [_P, _P, _P, _L, _P],
     't2v_axpby': [_F, _P, _F, _P, _P, _L, _P],
     't2v_scale_dev': [_P, _F, _P, _P, _L, _P],
-    't2v_dot': [_P, _P, _P, _L, _I, _P],
+    't2v_dot': [_P, _P, _P, _P, _L, _I, _P],
     't2v_fill': [_P, _F, _L, _P],
     't2v_tanh': [_P, _P, _L, _P],
     't2v_tanh_bwd': [_P, _P, _P, _L, _P],
@@ -53,7 +55,8 @@ SIGNATURES = {
     't2v_rowbcast': [_P, _P, _L, _L, _P],
     't2v_upsample2x': [_P, _P, _L, _I, _I, _P],
     't2v_upsample2x_bwd': [_P, _P, _L, _I, _I, _P],
-    't2v_bn_stats': [_P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
+    't2v_bn_ws_floats': [_I, _I, _L],
+    't2v_bn_stats': [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
     't2v_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
@@ -81,7 +84,7 @@ SIGNATURES = {
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
-_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_version': C.c_char_p}
+_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None
 

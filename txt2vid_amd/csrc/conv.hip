@@ -132,21 +132,34 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad implicit GEMM
+//   tile BM (voxels) x BN (output channels), K consumed in chunks of BKT (one tap x BKT channels on the
+//   FAST path), 4 waves, each owning (BN/WAVES_CO) x (BM/WAVES_M) as 32x32 MFMA tiles.
+//   Global -> registers (issued one chunk ahead, right after the barrier) -> LDS -> MFMA.
+//   Split-K (gridDim.z > 1): every split writes its partial tile into slab[z] and a second kernel sums
+//   the splits in a fixed order (deterministic) and adds the bias: the layers with M of a few dozen
+//   voxels and K of several thousand (the deep discriminator blocks, the ConvLSTM) are otherwise a
+//   handful of workgroups each walking K serially at memory latency.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_CO, bool FAST>
+template <int BM, int BN, int WAVES_CO, int BKT, bool FAST, bool VECB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         const t2v_conv_geom g, const int flags) {
+                                                         float* __restrict__ slab, const t2v_conv_geom g, const int flags,
+                                                         const int chunks_per_split) {
     constexpr int WAVES_M = 4 / WAVES_CO;
     constexpr int WCO = BN / WAVES_CO;      // co extent per wave
     constexpr int WM = BM / WAVES_M;        // m extent per wave
     constexpr int NCO = WCO / 32, NM = WM / 32;
-    constexpr int LA = BK * BM / 256, LB = BK * BN / 256;
-    constexpr int KSA = 256 / BM, KSB = 256 / BN;   // k stride between a thread's successive loads
-    static_assert(NCO >= 1 && NM >= 1, "tile");
+    constexpr int LA = BKT * BM / 256;
+    constexpr int KSA = 256 / BM;           // k stride between a thread's successive A loads
+    constexpr int LB = BKT * BN / 256;      // scalar B loads per thread
+    constexpr int KSB = 256 / BN;
+    constexpr int NV = BKT * BN / 4;        // float4s in the B tile
+    constexpr int LBV = NV >= 256 ? NV / 256 : 1;   // float4 B loads per thread (threads >= NV idle when NV < 256)
+    constexpr int KSBV = 1024 / BN;         // k rows covered by one float4 pass of the workgroup
+    static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LB >= 1, "tile");
 
-    __shared__ float As[BK * BM];
-    __shared__ float Bs[BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[BKT * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
     __shared__ int s_off[T2V_MAX_TAPS];
 
     const int tid = threadIdx.x;
@@ -177,8 +190,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
             if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) tapmask |= 1u << t;
         }
     }
-    const int cob_l = tid % BN, kb_l = tid / BN;
-    const bool co_ok = (co0 + cob_l) < Cout;
+    const int cob_l = tid % BN, kb_l = tid / BN;                 // scalar B mapping
+    const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4); // float4 B mapping
+    const bool vact = (NV >= 256) || (tid < NV);
+    const bool co_ok = VECB ? (vact && (co0 + cv_l) < Cout) : (co0 + cob_l) < Cout;
     const bool relu_in = flags & T2V_CONV_RELU_IN;
 
     f32x16 acc[NCO][NM];
@@ -189,9 +204,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[LA], rb[LB];
+    float ra[LA];
+    float rb[VECB ? 1 : LB];
+    float4 rbv[VECB ? LBV : 1];
     const int Ktot = ntaps * Cin;
-    const int nchunks = (Ktot + BK - 1) / BK;
+    const int nchunks = FAST ? ntaps * (Cin / BKT) : (Ktot + BKT - 1) / BKT;
+    const int q0 = blockIdx.z * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
     __syncthreads();   // s_off visible
 
     auto load_chunk = [&](int q, int t, int c0) {
@@ -203,13 +223,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
                 float val = v ? px[(size_t)j * KSA * DHW] : 0.f;
                 ra[j] = relu_in ? fmaxf(val, 0.f) : val;
             }
-            const float* pw = wp + ((size_t)t * Cin + c0 + kb_l) * Cout + co0 + cob_l;
+            if (VECB) {
+                const float* pw = wp + ((size_t)t * Cin + c0 + kv_l) * Cout + co0 + cv_l;
 #pragma unroll
-            for (int j = 0; j < LB; ++j) rb[j] = co_ok ? pw[(size_t)j * KSB * Cout] : 0.f;
+                for (int j = 0; j < LBV; ++j)
+                    rbv[j] = co_ok ? *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* pw = wp + ((size_t)t * Cin + c0 + kb_l) * Cout + co0 + cob_l;
+#pragma unroll
+                for (int j = 0; j < LB; ++j) rb[j] = co_ok ? pw[(size_t)j * KSB * Cout] : 0.f;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                int kk = q * BK + ka_l + j * KSA;
+                int kk = q * BKT + ka_l + j * KSA;
                 float val = 0.f;
                 if (kk < Ktot) {
                     int tt = kk / Cin, ci = kk - tt * Cin;
@@ -219,29 +246,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
-                int kk = q * BK + kb_l + j * KSB;
+                int kk = q * BKT + kb_l + j * KSB;
                 rb[j] = (co_ok && kk < Ktot) ? wp[(size_t)kk * Cout + co0 + cob_l] : 0.f;
             }
         }
     };
 
     int t_cur = 0, c_cur = 0;
-    load_chunk(0, 0, 0);
-    for (int q = 0; q < nchunks; ++q) {
+    if (FAST) {
+        const int cpt = Cin / BKT;
+        t_cur = q0 / cpt;
+        c_cur = (q0 - t_cur * cpt) * BKT;
+    }
+    if (q0 < q1) load_chunk(q0, t_cur, c_cur);
+    for (int q = q0; q < q1; ++q) {
         // registers -> LDS
 #pragma unroll
         for (int j = 0; j < LA; ++j) As[(ka_l + j * KSA) * BM + ma_l] = ra[j];
+        if (VECB) {
 #pragma unroll
-        for (int j = 0; j < LB; ++j) Bs[(kb_l + j * KSB) * BN + cob_l] = rb[j];
+            for (int j = 0; j < LBV; ++j)
+                if (vact) *reinterpret_cast<float4*>(&Bs[(kv_l + j * KSBV) * BN + cv_l]) = rbv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < LB; ++j) Bs[(kb_l + j * KSB) * BN + cob_l] = rb[j];
+        }
         __syncthreads();
         // issue the next chunk's global loads before the MFMAs (latency hides under compute)
-        if (q + 1 < nchunks) {
-            c_cur += BK;
+        if (q + 1 < q1) {
+            c_cur += BKT;
             if (FAST && c_cur >= Cin) { c_cur = 0; ++t_cur; }
             load_chunk(q + 1, t_cur, c_cur);
         }
-#pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
+#pragma unroll 8
+        for (int k2 = 0; k2 < BKT / 2; ++k2) {
             float a[NCO], b[NM];
             const int krow = k2 * 2 + hi;
 #pragma unroll
@@ -258,14 +296,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     }
 
     // ---- epilogue: rows (registers) = co, columns (lanes) = m
-    const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
-    const bool accum = flags & T2V_CONV_ACCUM;
+    const bool split = gridDim.z > 1;
+    const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const bool accum = !split && (flags & T2V_CONV_ACCUM);
+    float* out = split ? slab + (size_t)blockIdx.z * ((size_t)M * Cout) : y;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
         const int m = m0 + wm * WM + j * 32 + l31;
         if (m >= M) continue;
         const int n = m / DHW, sp = m - n * DHW;
-        float* py = y + (size_t)n * Cout * DHW + sp;
+        float* py = out + (size_t)n * Cout * DHW + sp;
 #pragma unroll
         for (int i = 0; i < NCO; ++i) {
 #pragma unroll
@@ -282,17 +322,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     }
 }
 
-template <int BM, int BN, int WAVES_CO>
-static int launch_conv(const float* x, const float* wp, const float* bias, float* y, const t2v_conv_geom& g, int flags,
-                       hipStream_t s) {
+// y = (accum ? y : 0) + bias[co] + sum_s slab[s]   (fixed summation order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long total, int S, int Cout, int DHW, int flags) {
+    const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const bool accum = flags & T2V_CONV_ACCUM;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + i];
+        if (has_bias) v += bias[(i / DHW) % Cout];
+        y[i] = accum ? y[i] + v : v;
+    }
+}
+
+struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S, cps; long tiles; };
+
+static ConvPlan conv_plan(const t2v_conv_geom& g) {
+    ConvPlan p;
     const long M = (long)g.N * g.D * g.H * g.W;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((g.Cout + BN - 1) / BN));
-    ProfScope prof(0, 2.0 * (double)M * g.Cout * g.Cin * g.ntaps, s);      // executed (non-padding-tap) MACs x 2
-    if (g.Cin % BK == 0)
-        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, true>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
-    else
-        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, false>), grid, dim3(256), 0, s, x, wp, bias, y, g, flags);
-    return launch_status();
+    p.bk = (g.Cin % 64 == 0) ? 64 : (g.Cin % 32 == 0) ? 32 : 16;
+    p.fast = (g.Cin % 16 == 0);
+    p.vecb = (g.Cout % 4 == 0);
+    if (g.Cout <= 32) { p.bm = 128; p.bn = 32; if (p.bk > 32) p.bk = 32; }
+    else {
+        p.bn = 64;
+        const long t128 = ((M + 127) / 128) * ((g.Cout + 63) / 64);
+        p.bm = (t128 >= 768) ? 128 : 64;
+        if (p.bm == 128 && p.bk > 32) p.bk = 32;
+    }
+    p.tiles = ((M + p.bm - 1) / p.bm) * ((g.Cout + p.bn - 1) / p.bn);
+    const long K = (long)g.ntaps * g.Cin;
+    const long nchunks = p.fast ? (long)g.ntaps * (g.Cin / p.bk) : (K + p.bk - 1) / p.bk;
+    long S = 1;
+    if (p.tiles < 384) {
+        S = (768 + p.tiles - 1) / p.tiles;
+        long maxS = nchunks / 2;                       // >= 2 chunks per split
+        if (S > maxS) S = maxS;
+        if (S > 64) S = 64;
+        while (S > 1 && (double)S * M * g.Cout * 4.0 > 256e6) --S;   // keep the slab small (L2/MALL resident)
+        if (S < 1) S = 1;
+    }
+    p.cps = (int)((nchunks + S - 1) / S);
+    p.S = (int)((nchunks + p.cps - 1) / p.cps);
+    return p;
+}
+
+template <int BM, int BN, int WAVES_CO, int BKT>
+static void launch_conv_t(const float* x, const float* wp, const float* bias, float* y, float* slab, const t2v_conv_geom& g,
+                          int flags, const ConvPlan& p, hipStream_t s) {
+    const long M = (long)g.N * g.D * g.H * g.W;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((g.Cout + BN - 1) / BN), (unsigned)p.S);
+    if (p.fast) {
+        if (p.vecb) T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
+        else T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
+    } else {
+        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
+    }
 }
 
 static bool geom_ok(const t2v_conv_geom* g) {
@@ -307,19 +392,45 @@ static bool geom_ok(const t2v_conv_geom* g) {
     return true;
 }
 
-extern "C" int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, const t2v_conv_geom* g,
+extern "C" int64_t t2v_conv_fwd_ws_floats(const t2v_conv_geom* g) {
+    if (!geom_ok(g)) return T2V_EINVAL;
+    ConvPlan p = conv_plan(*g);
+    if (p.S <= 1) return 0;
+    return (int64_t)p.S * g->N * g->D * g->H * g->W * g->Cout;
+}
+
+extern "C" int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, float* ws, const t2v_conv_geom* g,
                             int flags, void* stream) {
     if (!x || !wp || !y || !geom_ok(g)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const ConvPlan p = conv_plan(*g);
+    if (p.S > 1 && !ws) return T2V_EINVAL;
     const long M = (long)g->N * g->D * g->H * g->W;
-    const int Cout = g->Cout;
-    // tile choice: fill >= ~2 workgroups per CU where the problem allows it
-    if (Cout <= 32) return launch_conv<128, 32, 1>(x, wp, bias, y, *g, flags, s);
-    const long t128 = ((M + 127) / 128) * ((Cout + 127) / 128);
-    const long t12864 = ((M + 127) / 128) * ((Cout + 63) / 64);
-    if (Cout >= 128 && t128 >= 1024) return launch_conv<128, 128, 2>(x, wp, bias, y, *g, flags, s);
-    if (t12864 >= 1024) return launch_conv<128, 64, 2>(x, wp, bias, y, *g, flags, s);
-    return launch_conv<64, 64, 2>(x, wp, bias, y, *g, flags, s);
+    {
+        ProfScope prof(0, 2.0 * (double)M * g->Cout * g->Cin * g->ntaps, s);      // executed (non-padding-tap) MACs x 2
+        const int bk = p.fast ? p.bk : 16;
+        if (p.bn == 32) {
+            if (bk == 32) launch_conv_t<128, 32, 1, 32>(x, wp, bias, y, ws, *g, flags, p, s);
+            else launch_conv_t<128, 32, 1, 16>(x, wp, bias, y, ws, *g, flags, p, s);
+        } else if (p.bm == 128) {
+            if (bk == 32) launch_conv_t<128, 64, 2, 32>(x, wp, bias, y, ws, *g, flags, p, s);
+            else launch_conv_t<128, 64, 2, 16>(x, wp, bias, y, ws, *g, flags, p, s);
+        } else {
+            if (bk == 64) launch_conv_t<64, 64, 2, 64>(x, wp, bias, y, ws, *g, flags, p, s);
+            else if (bk == 32) launch_conv_t<64, 64, 2, 32>(x, wp, bias, y, ws, *g, flags, p, s);
+            else launch_conv_t<64, 64, 2, 16>(x, wp, bias, y, ws, *g, flags, p, s);
+        }
+        int st = launch_status();
+        if (st) return st;
+        if (p.S > 1) {
+            const long total = M * g->Cout;
+            long blocks = (total + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            T2V_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, bias, y, total, p.S, g->Cout,
+                       g->D * g->H * g->W, flags);
+        }
+    }
+    return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,18 +523,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> geometry tap j or -1
 
+// dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
+// lane-contiguous along (co,ci); the [i][t] transposition goes through LDS so that the PyTorch-layout
+// gradient is written as one contiguous run per workgroup.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                            long CoCi, int T, int ntaps, int S, TapMap map, int accum) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= CoCi) return;
-    for (int t = 0; t < T; ++t) {
+    // workgroup = 64 (co,ci) pairs x T taps; the 4 waves take taps t = wave, wave+4, ...
+    __shared__ float tile[64 * T2V_MAX_TAPS];
+    const long i0 = (long)blockIdx.x * 64;
+    const int il = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const long i = i0 + il;
+    for (int t = tg; t < T; t += 4) {
         const int j = map.j[t];
-        float v = 0.f;
-        if (j >= 0)
-            for (int s = 0; s < S; ++s) v += slab[((size_t)s * ntaps + j) * CoCi + i];
-        float* p = dw + (size_t)i * T + t;
-        *p = accum ? (*p + v) : v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (j >= 0 && i < CoCi) {
+            const float* p = slab + (size_t)j * CoCi + i;
+            const size_t st = (size_t)ntaps * CoCi;
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {
+                v0 += p[(size_t)s * st]; v1 += p[(size_t)(s + 1) * st]; v2 += p[(size_t)(s + 2) * st]; v3 += p[(size_t)(s + 3) * st];
+            }
+            for (; s < S; ++s) v0 += p[(size_t)s * st];
+        }
+        tile[il * T + t] = (v0 + v1) + (v2 + v3);
     }
+    __syncthreads();
+    long cnt = CoCi - i0;
+    if (cnt > 64) cnt = 64;
+    const long nval = cnt * T;
+    float* p = dw + (size_t)i0 * T;
+    for (long k = threadIdx.x; k < nval; k += 256) p[k] = accum ? p[k] + tile[k] : tile[k];
 }
 
 static int wgrad_splits(const t2v_conv_geom* g) {
@@ -466,21 +595,27 @@ extern "C" int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float*
     if (st) return st;
     const long CoCi = (long)g->Cout * g->Cin;
     ProfScope prof2(2, 0.0, s);
-    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 255) / 256)), dim3(256), 0, s, slab, dw, CoCi, T,
+    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T,
                        g->ntaps, S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
     return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-channel sum over (N, S): bias gradient / BatchNorm reductions
+// per-channel sum over (N, S): bias gradient. grid (C, SPLIT): each workgroup sums a contiguous range of
+// the N*S elements of its channel; SPLIT > 1 leaves partials in `ws` for the finalize kernel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int N,
-                                                          int C, long S, int accum) {
+                                                          int C, long S, int accum, int split, float* __restrict__ ws) {
     const int c = blockIdx.x;
+    const long total = (long)N * S;
+    const long per = (total + split - 1) / split;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((size_t)n * C + c) * S;
-        for (long i = threadIdx.x; i < S; i += 256) acc += p[i];
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const long n = e / S, sp = e - n * S;
+        acc += x[((size_t)n * C + c) * S + sp];
     }
     __shared__ float red[256];
     red[threadIdx.x] = acc;
@@ -489,11 +624,37 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = accum ? out[c] + red[0] : red[0];
+    if (threadIdx.x == 0) {
+        if (split > 1) ws[(size_t)c * split + blockIdx.y] = red[0];
+        else out[c] = accum ? out[c] + red[0] : red[0];
+    }
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int C, int split, int accum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float v = 0.f;
+    for (int k = 0; k < split; ++k) v += ws[(size_t)c * split + k];
+    out[c] = accum ? out[c] + v : v;
 }
 
-extern "C" int t2v_channel_sum(const float* x, float* out, int N, int C, int64_t S, int accum, void* stream) {
+static int channel_split(int N, int C, int64_t S) {
+    const long total = (long)N * S;
+    long sp = (1024 + C - 1) / C;
+    if (sp > total / 2048) sp = total / 2048;      // >= 2048 elements per workgroup
+    if (sp > 64) sp = 64;
+    if (sp < 1) sp = 1;
+    return (int)sp;
+}
+extern "C" int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S) {
+    if (N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    const int sp = channel_split(N, C, S);
+    return sp > 1 ? (int64_t)C * sp : 0;
+}
+extern "C" int t2v_channel_sum(const float* x, float* out, float* ws, int N, int C, int64_t S, int accum, void* stream) {
     if (!x || !out || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    T2V_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, N, C, (long)S, accum);
+    const int sp = channel_split(N, C, S);
+    if (sp > 1 && !ws) return T2V_EINVAL;
+    T2V_LAUNCH(channel_sum_kernel, dim3(C, sp), dim3(256), 0, (hipStream_t)stream, x, out, N, C, (long)S, accum, sp, ws);
+    if (sp > 1) T2V_LAUNCH(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, out, C, sp, accum);
     return launch_status();
 }

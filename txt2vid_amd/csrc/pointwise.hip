@@ -97,17 +97,26 @@ extern "C" int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n
     return launch_status();
 }
 
-// dot product: single workgroup chain (deterministic). n is small on this path (<= a few M).
-__global__ __launch_bounds__(256) void dot_k(const float* a, const float* b, float* out, long n, int accum) {
+// dot product, two deterministic stages: up to 256 workgroups leave partial sums in ws, one wave-pass sums them.
+__global__ __launch_bounds__(256) void dot_partial_k(const float* a, const float* b, float* ws, long n) {
     __shared__ float red[4];
     float acc = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += a[i] * b[i];
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void dot_final_k(const float* ws, float* out, int nb, int accum) {
+    __shared__ float red[4];
+    float acc = threadIdx.x < nb ? ws[threadIdx.x] : 0.f;
     float s = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = accum ? out[0] + s : s;
 }
-extern "C" int t2v_dot(const float* a, const float* b, float* out, int64_t n, int accum, void* st) {
-    if (n <= 0) return T2V_EINVAL;
-    T2V_LAUNCH(dot_k, dim3(1), dim3(256), 0, S_(st), a, b, out, (long)n, accum);
+extern "C" int t2v_dot(const float* a, const float* b, float* out, float* ws, int64_t n, int accum, void* st) {
+    if (n <= 0 || !a || !b || !out || !ws) return T2V_EINVAL;
+    long nb = (n + 4095) / 4096;
+    if (nb > 256) nb = 256;
+    T2V_LAUNCH(dot_partial_k, dim3((unsigned)nb), dim3(256), 0, S_(st), a, b, ws, (long)n);
+    T2V_LAUNCH(dot_final_k, dim3(1), dim3(256), 0, S_(st), ws, out, (int)nb, accum);
     return launch_status();
 }
 
@@ -313,34 +322,63 @@ extern "C" int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, in
 }
 
 // ---------------------------------------------------------------- BatchNorm2d (training)
-// one workgroup per channel; two-pass (mean, then centred second moment) for accuracy.
-__global__ __launch_bounds__(256) void bn_stats_k(const float* x, float* stats, float* rmean, float* rvar, int N, int C,
-                                                  long S, float momentum, float eps) {
+// Statistics in two deterministic stages: grid (C, SPLIT) workgroups compute (count, mean, M2) of a
+// contiguous slice of their channel (two passes over the slice, which stays in L2), the finalize kernel
+// merges the slices with Chan's parallel-variance formula and updates the running statistics.
+#define BN_MAXSPLIT 64
+__device__ __forceinline__ float bn_elem(const float* x, long e, int C, int c, long S) {
+    const long n = e / S, sp = e - n * S;
+    return x[((size_t)n * C + c) * S + sp];
+}
+__global__ __launch_bounds__(256) void bn_stats_part_k(const float* x, float* part, int N, int C, long S, int split) {
     __shared__ float red[4];
     const int c = blockIdx.x;
-    const long cnt = (long)N * S;
+    const long total = (long)N * S;
+    const long per = (total + split - 1) / split;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    const long cnt = e1 > e0 ? e1 - e0 : 0;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * C + c) * S;
-        for (long i = threadIdx.x; i < S; i += 256) acc += p[i];
-    }
-    const float mean = block_sum(acc, red) / (float)cnt;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) acc += bn_elem(x, e, C, c, S);
+    const float mean = cnt > 0 ? block_sum(acc, red) / (float)cnt : 0.f;
     acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * C + c) * S;
-        for (long i = threadIdx.x; i < S; i += 256) { float d = p[i] - mean; acc += d * d; }
-    }
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) { const float d = bn_elem(x, e, C, c, S) - mean; acc += d * d; }
     const float m2 = block_sum(acc, red);
     if (threadIdx.x == 0) {
-        const float var = m2 / (float)cnt;
-        stats[c] = mean;
-        stats[C + c] = 1.f / sqrtf(var + eps);
-        if (rmean) {
-            const float unb = cnt > 1 ? m2 / (float)(cnt - 1) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
-        }
+        float* p = part + ((size_t)c * split + blockIdx.y) * 3;
+        p[0] = (float)cnt; p[1] = mean; p[2] = m2;
     }
+}
+__global__ void bn_stats_final_k(const float* part, float* stats, float* rmean, float* rvar, int C, int split, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < split; ++k) {
+        const float* p = part + ((size_t)c * split + k) * 3;
+        const float nb = p[0];
+        if (nb <= 0.f) continue;
+        const float delta = p[1] - mean, nt = n + nb;
+        mean += delta * (nb / nt);
+        m2 += p[2] + delta * delta * (n * nb / nt);
+        n = nt;
+    }
+    const float var = m2 / n;
+    stats[c] = mean;
+    stats[C + c] = 1.f / sqrtf(var + eps);
+    if (rmean) {
+        const float unb = n > 1.f ? m2 / (n - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+static int bn_split(int N, int C, long S) {
+    const long total = (long)N * S;
+    long sp = (1024 + C - 1) / C;
+    if (sp > total / 1024) sp = total / 1024;
+    if (sp > BN_MAXSPLIT) sp = BN_MAXSPLIT;
+    if (sp < 1) sp = 1;
+    return (int)sp;
 }
 __global__ void bn_apply_k(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int N, int C,
                            long S, int relu) {
@@ -351,28 +389,40 @@ __global__ void bn_apply_k(const float* x, const float* stats, const float* gamm
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
 }
-// pass 1: per channel sums  ws[c] = sum g', ws[C+c] = sum g' * xhat   (g' = gy masked by relu)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const float* gy, const float* x, const float* y, const float* stats,
-                                                       float* ws, float* ggamma, float* gbeta, int N, int C, long S, int relu) {
+// pass 1: per channel sums  s1 = sum g', s2 = sum g' * xhat   (g' = gy masked by relu); grid (C, SPLIT)
+__global__ __launch_bounds__(256) void bn_bwd_part_k(const float* gy, const float* x, const float* y, const float* stats,
+                                                     float* part, int N, int C, long S, int relu, int split) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     const float mean = stats[c], istd = stats[C + c];
+    const long total = (long)N * S;
+    const long per = (total + split - 1) / split;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
     float s1 = 0.f, s2 = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const long base = ((long)n * C + c) * S;
-        for (long i = threadIdx.x; i < S; i += 256) {
-            float g = gy[base + i];
-            if (relu && !(y[base + i] > 0.f)) g = 0.f;
-            s1 += g;
-            s2 += g * (x[base + i] - mean) * istd;
-        }
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const long n = e / S, sp = e - n * S;
+        const size_t idx = ((size_t)n * C + c) * S + sp;
+        float g = gy[idx];
+        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        s1 += g;
+        s2 += g * (x[idx] - mean) * istd;
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
-        ws[c] = s1; ws[C + c] = s2;
-        gbeta[c] = s1; ggamma[c] = s2;
+        float* p = part + ((size_t)c * split + blockIdx.y) * 2;
+        p[0] = s1; p[1] = s2;
     }
+}
+__global__ void bn_bwd_final_k(const float* part, float* ws, float* ggamma, float* gbeta, int C, int split) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < split; ++k) { s1 += part[((size_t)c * split + k) * 2]; s2 += part[((size_t)c * split + k) * 2 + 1]; }
+    ws[c] = s1; ws[C + c] = s2;
+    gbeta[c] = s1; ggamma[c] = s2;
 }
 __global__ void bn_bwd_apply_k(const float* gy, const float* x, const float* y, const float* stats, const float* gamma,
                                const float* ws, float* gx, int N, int C, long S, int relu) {
@@ -396,10 +446,16 @@ __global__ void bn_eval_k(const float* x, const float* rm, const float* rv, cons
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
 }
-extern "C" int t2v_bn_stats(const float* x, float* stats, float* rm, float* rv, int N, int C, int64_t S, float momentum,
+extern "C" int64_t t2v_bn_ws_floats(int N, int C, int64_t S) {
+    if (N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    return (int64_t)C * bn_split(N, C, (long)S) * 3 + 2 * C;
+}
+extern "C" int t2v_bn_stats(const float* x, float* stats, float* rm, float* rv, float* ws, int N, int C, int64_t S, float momentum,
                             float eps, void* st) {
-    if (!x || !stats || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
-    T2V_LAUNCH(bn_stats_k, dim3(C), dim3(256), 0, S_(st), x, stats, rm, rv, N, C, (long)S, momentum, eps);
+    if (!x || !stats || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    const int sp = bn_split(N, C, (long)S);
+    T2V_LAUNCH(bn_stats_part_k, dim3(C, sp), dim3(256), 0, S_(st), x, ws, N, C, (long)S, sp);
+    T2V_LAUNCH(bn_stats_final_k, dim3((C + 255) / 256), dim3(256), 0, S_(st), ws, stats, rm, rv, C, sp, momentum, eps);
     return launch_status();
 }
 extern "C" int t2v_bn_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int N, int C,
@@ -412,7 +468,10 @@ extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const
                           float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* st) {
     if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
     if (relu && !y) return T2V_EINVAL;
-    T2V_LAUNCH(bn_bwd_reduce_k, dim3(C), dim3(256), 0, S_(st), gy, x, y, stats, ws, ggamma, gbeta, N, C, (long)S, relu);
+    const int sp = bn_split(N, C, (long)S);
+    float* part = ws + 2 * C;
+    T2V_LAUNCH(bn_bwd_part_k, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, part, N, C, (long)S, relu, sp);
+    T2V_LAUNCH(bn_bwd_final_k, dim3((C + 255) / 256), dim3(256), 0, S_(st), part, ws, ggamma, gbeta, C, sp);
     T2V_LAUNCH(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
     return launch_status();
 }

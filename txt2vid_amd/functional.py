@@ -71,7 +71,7 @@ def bump_weight_epoch():
 # ------------------------------------------------------------------------------------------------
 
 class _Geom(object):
-    __slots__ = ('cg', 'taps', 'taps_c', 'T', 'mask', 'kshape')
+    __slots__ = ('cg', 'taps', 'taps_c', 'T', 'mask', 'kshape', 'ws_floats')
 
 
 _geom_cache = {}
@@ -102,6 +102,7 @@ def conv_geom(N, Cin, D, H, W, Cout, kD, kH, kW):
     g.cg, g.taps, g.T, g.kshape = cg, taps, kD * kH * kW, (kD, kH, kW)
     g.taps_c = (C.c_int32 * len(taps))(*taps)
     g.mask = sum(1 << t for t in taps)
+    g.ws_floats = None
     _geom_cache[key] = g
     return g
 
@@ -145,6 +146,17 @@ def _geom_for(x5, w5):
                      w5.shape[2], w5.shape[3], w5.shape[4])
 
 
+def _conv_ws(g, device):
+    """split-K workspace for this geometry (None when the launch plan does not split)."""
+    n = getattr(g, 'ws_floats', None)
+    if n is None:
+        n = int(lib().t2v_conv_fwd_ws_floats(C.byref(g.cg)))
+        if n < 0:
+            raise RuntimeError('bad conv geometry')
+        g.ws_floats = n
+    return torch.empty((n,), device=device, dtype=torch.float32) if n > 0 else None
+
+
 def conv_fwd_raw(x5, w5, bias=None, relu_in=False, out=None, accum=False):
     x5, w5 = _c(x5), _c(w5)
     g = _geom_for(x5, w5)
@@ -152,7 +164,8 @@ def conv_fwd_raw(x5, w5, bias=None, relu_in=False, out=None, accum=False):
     y = out if out is not None else torch.empty((x5.shape[0], w5.shape[0]) + tuple(x5.shape[2:]), device=x5.device,
                                                 dtype=torch.float32)
     flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0)
-    check(lib().t2v_conv_fwd(_p(x5), _p(wp), _p(bias), _p(y), C.byref(g.cg), flags, _stream()), 't2v_conv_fwd')
+    check(lib().t2v_conv_fwd(_p(x5), _p(wp), _p(bias), _p(y), _p(_conv_ws(g, x5.device)), C.byref(g.cg), flags, _stream()),
+          't2v_conv_fwd')
     return y
 
 
@@ -165,8 +178,8 @@ def conv_dgrad_raw(gy5, w5, out=None, accum=False):
     wp = packed_weight(w5, gt, 1)
     gx = out if out is not None else torch.empty((gy5.shape[0], Cin) + tuple(gy5.shape[2:]), device=gy5.device,
                                                  dtype=torch.float32)
-    check(lib().t2v_conv_fwd(_p(gy5), _p(wp), None, _p(gx), C.byref(gt.cg), FLAG_ACCUM if accum else 0, _stream()),
-          't2v_conv_fwd(dgrad)')
+    check(lib().t2v_conv_fwd(_p(gy5), _p(wp), None, _p(gx), _p(_conv_ws(gt, gy5.device)), C.byref(gt.cg),
+                             FLAG_ACCUM if accum else 0, _stream()), 't2v_conv_fwd(dgrad)')
     return gx
 
 
@@ -188,7 +201,9 @@ def channel_sum_raw(t5):
     N, Cc = t5.shape[0], t5.shape[1]
     S = t5.numel() // (N * Cc)
     out = torch.empty((Cc,), device=t5.device, dtype=torch.float32)
-    check(lib().t2v_channel_sum(_p(t5), _p(out), N, Cc, S, 0, _stream()), 't2v_channel_sum')
+    nws = int(lib().t2v_channel_sum_ws_floats(N, Cc, S))
+    ws = torch.empty((nws,), device=t5.device, dtype=torch.float32) if nws > 0 else None
+    check(lib().t2v_channel_sum(_p(t5), _p(out), _p(ws), N, Cc, S, 0, _stream()), 't2v_channel_sum')
     return out
 
 
@@ -254,6 +269,50 @@ class ConvWgrad(Function):
         return d_x, d_gy, None
 
 
+class ReluConv(Function):
+    """y = conv(relu(x), w) + b with the ReLU applied while gathering (no activated copy is written):
+    the `ReLU -> conv` pairs of DownBlock / res_block (layers.py:230-233, resnet3d.py:14-15).
+    Backward: gx = dgrad(gy, w) * [x > 0];  gw = wgrad(relu(x), gy) with the same fused gather."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return conv_fwd_raw(x, w, b, relu_in=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ReluMask.apply(ConvDgrad.apply(gy, w), x)
+        if _param_grads_enabled:
+            if ctx.needs_input_grad[1]:
+                gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = ChannelSum.apply(gy)
+        return gx, gw, gb
+
+
+class ReluConvWgrad(Function):
+    """gw = wgrad(relu(x), gy). Its adjoints: d_x = dgrad(gy, ggw) * [x > 0], d_gy = conv(relu(x), ggw)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, wshape):
+        ctx.save_for_backward(x, gy)
+        return conv_wgrad_raw(x, gy, wshape, relu_in=True)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        d_x = d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_x = ReluMask.apply(ConvDgrad.apply(gy, ggw), x)
+        if ctx.needs_input_grad[1]:
+            d_gy = ReluConv.apply(x, ggw, None)
+        return d_x, d_gy, None
+
+
 class ChannelSum(Function):
     @staticmethod
     def forward(ctx, t):
@@ -283,6 +342,13 @@ def conv(x, w, b=None):
     if dim == 2:
         return y.view(y.size(0), y.size(1))
     return y
+
+
+def relu_conv(x, w, b=None):
+    """conv(relu(x), w) + b with the ReLU fused into the gather."""
+    dim = x.dim()
+    y = ReluConv.apply(_as5(x), _as5(w), b)
+    return y.squeeze(2) if dim == 4 else y
 
 
 def linear(x, w, b=None):
@@ -600,7 +666,8 @@ class Dot(Function):
         a, b = _c(a), _c(b)
         ctx.save_for_backward(a, b)
         out = torch.empty((), device=a.device, dtype=torch.float32)
-        check(lib().t2v_dot(_p(a), _p(b), _p(out), a.numel(), 0, _stream()), 't2v_dot')
+        ws = torch.empty((256,), device=a.device, dtype=torch.float32)
+        check(lib().t2v_dot(_p(a), _p(b), _p(out), _p(ws), a.numel(), 0, _stream()), 't2v_dot')
         return out
 
     @staticmethod
@@ -696,7 +763,9 @@ class BatchNormAct(Function):
         y = torch.empty_like(x)
         if training:
             stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
-            check(lib().t2v_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), N, Cc, S, momentum, eps, _stream()), 't2v_bn_stats')
+            ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
+            check(lib().t2v_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S, momentum, eps, _stream()),
+                  't2v_bn_stats')
             check(lib().t2v_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, Cc, S, int(relu), _stream()), 't2v_bn_apply')
             ctx.save_for_backward(x, y, stats, gamma)
             ctx.relu = relu
@@ -718,7 +787,7 @@ class BatchNormAct(Function):
         gx = torch.empty_like(x)
         gg = torch.empty_like(gamma)
         gb = torch.empty_like(gamma)
-        ws = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
         check(lib().t2v_bn_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
                                int(ctx.relu), _stream()), 't2v_bn_bwd')
         return gx, gg, gb, None, None, None, None, None, None
@@ -1213,3 +1282,30 @@ def copy_into(src, dst):
     src = _c(src)
     n = src.numel()
     _copy2d(src, 0, n, dst, 0, n, 1, n)
+
+
+class CatBatch(Function):
+    """torch.cat((a, b), dim=0) of two dense tensors (two copy launches into one buffer)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        ctx.na = a.shape[0]
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+        na, nb = a.numel(), b.numel()
+        _copy2d(a, 0, na, out, 0, na, 1, na)
+        _copy2d(b, 0, nb, out, na, nb, 1, nb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g[:ctx.na] if ctx.needs_input_grad[0] else None), (g[ctx.na:] if ctx.needs_input_grad[1] else None)
+
+
+def cat_batch(a, b):
+    return CatBatch.apply(a, b)
+
+
+def tail_rows(x, n_skip):
+    """x[n_skip:] — a trailing-rows slice of a contiguous tensor is a view."""
+    return x[n_skip:]

@@ -52,10 +52,17 @@ class CondGan(object):
                 # (lu + (l1 + l2)/2) / 2
                 l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
         else:
-            if real is not None:
-                real_pred = [r[0] for r in discrim(x=real, cond=None, xbar=None)]
-            if fake is not None:
-                fake_pred = [f[0] for f in discrim(x=fake, cond=None, xbar=None)]
+            if real is not None and fake is not None and _can_batch(real, fake):
+                # D has no batch-coupled op (no BatchNorm; the non-local block is per sample), so
+                # D(cat(real, fake)) == cat(D(real), D(fake)): one pass per level instead of two.
+                both = discrim(x=[TF.cat_batch(r, f) for r, f in zip(real, fake)], cond=None, xbar=None)
+                real_pred = [TF.head_rows(o[0], r.size(0)) for o, r in zip(both, real)]
+                fake_pred = [TF.tail_rows(o[0], r.size(0)) for o, r in zip(both, real)]
+            else:
+                if real is not None:
+                    real_pred = [r[0] for r in discrim(x=real, cond=None, xbar=None)]
+                if fake is not None:
+                    fake_pred = [f[0] for f in discrim(x=fake, cond=None, xbar=None)]
             if loss is not None and fake_pred is not None and real_pred is not None:
                 l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(fake_pred, real_pred)])
         if l is not None and gp_lambda > 0:
@@ -147,6 +154,10 @@ class CondGan(object):
         for name, d in zip(self.discrim_names, self.discrims):
             if name in to_load:
                 d.load_state_dict(_match_keys(to_load[name], d.state_dict().keys()))
+
+
+def _can_batch(real, fake):
+    return all(r.is_cuda and r.shape == f.shape for r, f in zip(real, fake))
 
 
 def _match_keys(sd, want):

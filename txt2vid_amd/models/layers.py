@@ -246,6 +246,11 @@ class DownBlock(nn.Module):
         self.main = ResidualBlock(inner_module=main, identity_map=ident)
 
     def forward(self, x):
+        m = self.main.inner_module
+        if isinstance(m[1], Conv3d) and isinstance(m[3], Conv3d):
+            h = TF.relu_conv(x, m[1].weight, m[1].bias)            # ReLU fused into the conv gather
+            h = TF.relu_conv(h, m[3].weight, m[3].bias)
+            return TF.add(self.main.identity_map(x), m[4](h))
         return self.main(x)
 
 

@@ -30,12 +30,21 @@ class Resnet3D(nn.Module):
         if cond_dim > 0:
             self.fc = Linear(in_ch + cond_dim, 1)
 
+    def _stem(self, x):
+        """res_block (resnet3d.py:12-19) with the ReLU fused into the second convolution's gather."""
+        m = self.res_block.inner_module
+        if isinstance(m[0], Conv3d) and isinstance(m[2], Conv3d):
+            h = m[0](x)
+            h = TF.relu_conv(h, m[2].weight, m[2].bias)
+            return TF.add(self.res_block.identity_map(x), m[3](h))
+        return self.res_block(x)
+
     def forward(self, x=None, cond=None, xbar=None, computed_features=None):
         uncond = None
         if computed_features is not None:
             x = computed_features
         else:
-            x = self.res_block(x)
+            x = self._stem(x)
             for d in self.down:
                 x = d(x)
             x = TF.sum_spatial(x)                           # torch.sum(x, [2,3,4])  (resnet3d.py:48)
