@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_roofline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay (eager launches)')
     args = ap.parse_args()
 
     from txt2vid_amd import dist as tdist
@@ -121,9 +122,15 @@ def main():
     np.random.seed(100 + rank)
     torch.manual_seed(100 + rank)
 
-    from txt2vid_amd.gan.trainer import train_iteration
+    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
+
+    graphed = None
+    if not args.eager:
+        graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2)
 
     def step(i):
+        if graphed is not None:
+            return graphed.step(pool[i % len(pool)]) + (None, None)
         return train_iteration(gan, pool[i % len(pool)], None, optD, optG, losses, prm, dev, grad_sync=grad_sync)
 
     def log(msg):
@@ -131,6 +138,8 @@ def main():
             sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - T0, msg))
             sys.stderr.flush()
 
+    if graphed is not None and args.warmup < 3:
+        args.warmup = 3                      # 2 eager iterations + the capture must precede the timed region
     log('models + data ready; warm-up')
     for i in range(args.warmup):
         step(i)
@@ -143,8 +152,9 @@ def main():
         torch.cuda.synchronize()
 
     prof = not args.no_roofline
+    prof_in_region = prof and graphed is None        # eager launches: events bracket them inside the timed region
     barrier()
-    if prof:
+    if prof_in_region:
         lib().t2v_prof_begin(min(1 << 16, 4096 * args.steps))
         log('instrumentation ready')
     t0 = time.perf_counter()
@@ -156,7 +166,21 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
+    lD, lG = float(lD), float(lG)
     roof = None
+    prof_steps, prof_dt = args.steps, dt
+    if prof and not prof_in_region:
+        # A replayed HIP graph re-issues no launch calls, so per-launch hipEvents cannot be recorded inside
+        # it: the same iterations are re-run eagerly right after the timed region with the events on.
+        prof_steps = min(args.steps, 5)
+        torch.cuda.synchronize()
+        lib().t2v_prof_begin(min(1 << 16, 4096 * prof_steps))
+        t1 = time.perf_counter()
+        for i in range(prof_steps):
+            train_iteration(gan, pool[i % len(pool)], None, optD, optG, losses, prm, dev, grad_sync=grad_sync)
+        torch.cuda.synchronize()
+        prof_dt = time.perf_counter() - t1
+        log('instrumented eager pass done: %.1f ms/step' % (prof_dt / prof_steps * 1e3))
     if prof:
         out = (C.c_double * 9)()
         over = lib().t2v_prof_end(out, 3)
@@ -165,13 +189,17 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                    'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2)',
-                    'launches_per_step': cnt / args.steps, 'avg_launch_us': ms * 1e3 / cnt,
+                    'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2; '
+                              'includes its split-K reduce pass)',
+                    'launches_per_step': cnt / prof_steps, 'avg_launch_us': ms * 1e3 / cnt,
                     'flops_counted': 'executed MACs x2 (padding-only taps excluded), summed over all launches',
-                    'share_of_step_time': ms * 1e-3 / dt, 'pool_overflow': bool(over),
+                    'measured_over': ('the timed region (eager launches)' if prof_in_region else
+                                      '%d eager iterations right after the timed region (graph replay has no launch calls to '
+                                      'bracket)' % prof_steps),
+                    'gpu_ms_per_step': ms / prof_steps, 'pool_overflow': bool(over),
                     'wgrad': {'achieved': (out[4] / (out[3] * 1e-3) / 1e12) if out[3] > 0 else None,
-                              'launches_per_step': out[5] / args.steps, 'share_of_step_time': out[3] * 1e-3 / dt,
-                              'reduce_share_of_step_time': out[6] * 1e-3 / dt}}
+                              'launches_per_step': out[5] / prof_steps, 'gpu_ms_per_step': out[3] / prof_steps,
+                              'reduce_gpu_ms_per_step': out[6] / prof_steps}}
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -186,7 +214,7 @@ def main():
                                'Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid 8/16/32/64' % args.batch,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
                    'as_written_tflop_per_step': GFLOP_PER_SAMPLE_AS_WRITTEN * gb / 1e3},
-        'final_losses': {'lossD': float(lD), 'lossG': float(lG)},
+        'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (3 graphs/step)',
         'as_written_tflops': GFLOP_PER_SAMPLE_AS_WRITTEN * gb * args.steps / dt / 1e3,
     }
     if roof is not None:

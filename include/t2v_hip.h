@@ -149,12 +149,15 @@ int t2v_row_scale(const float* s, float mul, const float* g, float* y, int rows,
 
 /* ---- optimiser (torch.optim.Adam call site txt2vid/train/gan.py:93-94) ------------------------- */
 int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-             float eps, float bc1, float bc2, float gscale, void* stream);
+             float eps, float bc1, float bc2, float gscale, const float* step_dev, void* stream);
+/* step_dev != NULL: a device-resident {step, 1-b1^step, 1-b2^step} triple supplies the bias corrections
+ * (HIP-graph replay cannot bake a host-side step number); t2v_adam_tick advances it by one step. */
+int t2v_adam_tick(float* state, float b1, float b2, void* stream);
 
 /* ---- pyramid (trainer.py:131-165, layers.py:106-111) ------------------------------------------- */
 /* y[b,c,t,h,w] = x[b*sb, c, t*st+bt, (h*H)/Ho, (w*W)/Wo]  — Subsample + nearest F.interpolate. */
 int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
-                       int sb, int st, int bt, void* stream);
+                       int sb, int st, int bt, const int32_t* bt_dev /* NULL or device-resident phase */, void* stream);
 
 
 /* ---- layout glue: the permutes / slices between the reference's tensor layouts --------------------
@@ -164,7 +167,7 @@ int t2v_permute01(const float* x, float* y, int64_t A, int64_t B, int64_t inner,
 int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int64_t C, int64_t inner, void* stream); /* [A,B,C,i]->[A,C,B,i] */
 /* merged-frames [b*T, inner]: keep samples ::2 and frames bt::2 (gen.py:98-109); adjoint=1 scatters y into x */
 int t2v_subsample_frames(float* x, float* y, int64_t b, int64_t T, int64_t inner, int64_t bo, int64_t To, int bt,
-                         int adjoint, void* stream);
+                         int adjoint, const int32_t* bt_dev /* NULL or device-resident phase */, void* stream);
 /* adjoint of t2v_pyramid_gather for Ho=H, Wo=W: gx[b*sb, c, t*st+bt, :] = g[b, c, t, :] (gx pre-zeroed) */
 int t2v_pyramid_scatter(const float* g, float* gx, int B, int C, int T, int64_t HW, int Bo, int To, int sb, int st,
                         int bt, void* stream);

@@ -342,3 +342,44 @@ def test_first_step_grad_norms_vs_reference_golden(golden):
     lG = gan.gen_step(fake=fake, real_pred=real_pred, cond=None, loss=losses.gen_loss)
     lG.backward()
     norms_close(gan.gen, g, 'it0_G_gn', rtol=3e-3)
+
+
+def test_graph_replay_matches_eager():
+    """HIP-graph replay (3 graphs per iteration, device-resident random draws and Adam step counter) must
+    reproduce the eager iteration: same seeds -> same losses on every step, captured or replayed."""
+    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
+
+    def batches():
+        g = torch.Generator()
+        g.manual_seed(11)
+        return [(torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(6)]
+
+    def seed():
+        random.seed(5)
+        np.random.seed(5)
+        torch.manual_seed(5)
+    # Burn-in: the first backward in a process runs with the autograd worker thread's node numbering at
+    # zero, which orders the (independent) per-level gradient accumulations differently from every later
+    # run: ~1e-7 relative differences in the summed weight gradients, amplified by the GAN dynamics.
+    gan, optD, optG, losses, prm = _make_uncond()
+    train_iteration(gan, batches()[0], None, optD, optG, losses, prm, DEV)
+    gan, optD, optG, losses, prm = _make_uncond()
+    seed()
+    eager = []
+    for x in batches():
+        lD, lG, _, _ = train_iteration(gan, x, None, optD, optG, losses, prm, DEV)
+        eager.append((float(lD), float(lG)))
+    gan, optD, optG, losses, prm = _make_uncond()
+    seed()
+    gs = GraphedTrainStep(gan, optD, optG, losses, prm, DEV, (4, 1, 16, 64, 64), warmup=2)
+    for i, x in enumerate(batches()):
+        lD, lG = gs.step(x)
+        got = (float(lD), float(lG))
+        print('step %d (%s): %s vs eager %s' % (i, 'replay' if i >= 2 else 'eager', got, eager[i]))
+        # eager iterations must agree bit for bit; from the capture on, the order in which autograd
+        # accumulates the per-level contributions into the shared D weights is the one frozen at capture
+        # time (a different but equally valid fp32 summation order): ~1e-7 relative in the gradients,
+        # amplified by the dynamics to ~1e-5 in the next loss.
+        tol = 1e-7 if i < 2 else 2e-4
+        assert abs(got[0] - eager[i][0]) < tol and abs(got[1] - eager[i][1]) < tol, (i, got, eager[i])
+    assert gs.graphs is not None

@@ -71,12 +71,13 @@ SIGNATURES = {
     't2v_lerp_rows': [_P, _P, _P, _P, _I, _L, _P],
     't2v_row_sqnorm': [_P, _P, _I, _L, _P],
     't2v_row_scale': [_P, _F, _P, _P, _I, _L, _P],
-    't2v_adam': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P],
-    't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    't2v_adam': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P],
+    't2v_adam_tick': [_P, _F, _F, _P],
+    't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     't2v_copy2d': [_P, _L, _P, _L, _L, _L, _P],
     't2v_permute01': [_P, _P, _L, _L, _L, _P],
     't2v_permute12': [_P, _P, _L, _L, _L, _L, _P],
-    't2v_subsample_frames': [_P, _P, _L, _L, _L, _L, _L, _I, _I, _P],
+    't2v_subsample_frames': [_P, _P, _L, _L, _L, _L, _L, _I, _I, _P, _P],
     't2v_pyramid_scatter': [_P, _P, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P],
     't2v_scalar_combine': [_P, C.POINTER(C.c_float), _I, _P, _P],
     't2v_gather_rows': [_P, _P, _P, _L, _L, _I, _P],

@@ -679,7 +679,11 @@ extern "C" int t2v_row_scale(const float* s, float mul, const float* g, float* y
 
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics)
 __global__ void adam_k(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                       float bc1, float bc2, float gscale) {
+                       float bc1, float bc2, float gscale, const float* step_dev) {
+    if (step_dev) {                      // device-resident step state (HIP-graph replay): {step, bc1, bc2}
+        bc1 = step_dev[1];
+        bc2 = step_dev[2];
+    }
     const float step = lr / bc1;
     const float isq = 1.f / sqrtf(bc2);
     GRID_STRIDE(i, n) {
@@ -693,15 +697,31 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, long n, flo
     }
 }
 extern "C" int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                        float bc1, float bc2, float gscale, void* st) {
+                        float bc1, float bc2, float gscale, const float* step_dev, void* st) {
     if (!p || !g || !m || !v || n < 1) return T2V_EINVAL;
-    T2V_LAUNCH(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale);
+    T2V_LAUNCH(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, step_dev);
+    return launch_status();
+}
+// step state {step, bc1, bc2}: step += 1 and the bias corrections 1 - beta^step, evaluated in double and
+// rounded to float exactly like the host path does (python float -> c_float).
+__global__ void adam_tick_k(float* state, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float t = state[0] + 1.f;
+        state[0] = t;
+        state[1] = (float)(1.0 - pow((double)b1, (double)t));
+        state[2] = (float)(1.0 - pow((double)b2, (double)t));
+    }
+}
+extern "C" int t2v_adam_tick(float* state, float b1, float b2, void* st) {
+    if (!state) return T2V_EINVAL;
+    T2V_LAUNCH(adam_tick_k, dim3(1), dim3(64), 0, S_(st), state, b1, b2);
     return launch_status();
 }
 
 // ---------------------------------------------------------------- pyramid gather
 __global__ void pyramid_gather_k(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
-                                 int sb, int stt, int bt) {
+                                 int sb, int stt, int bt, const int32_t* bt_dev) {
+    if (bt_dev) bt = bt_dev[0];
     const long n = (long)Bo * C * To * Ho * Wo;
     GRID_STRIDE(i, n) {
         int wo = i % Wo; long r = i / Wo;
@@ -714,10 +734,12 @@ __global__ void pyramid_gather_k(const float* x, float* y, int B, int C, int T, 
     }
 }
 extern "C" int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int W, int Bo, int To, int Ho, int Wo,
-                                  int sb, int stt, int bt, void* st) {
+                                  int sb, int stt, int bt, const int32_t* bt_dev, void* st) {
     if (!x || !y || B < 1 || C < 1 || T < 1 || Bo < 1 || To < 1 || Ho < 1 || Wo < 1) return T2V_EINVAL;
-    if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + bt >= T) return T2V_EINVAL;
-    T2V_LAUNCH(pyramid_gather_k, dim3(nblocks((long)Bo * C * To * Ho * Wo)), dim3(256), 0, S_(st), x, y, B, C, T, H, W, Bo, To, Ho, Wo, sb, stt, bt);
+    // with a device-resident phase the caller guarantees 0 <= *bt_dev < stt and (To-1)*stt + stt-1 < T
+    const int btmax = bt_dev ? stt - 1 : bt;
+    if ((long)(Bo - 1) * sb >= B || (long)(To - 1) * stt + btmax >= T) return T2V_EINVAL;
+    T2V_LAUNCH(pyramid_gather_k, dim3(nblocks((long)Bo * C * To * Ho * Wo)), dim3(256), 0, S_(st), x, y, B, C, T, H, W, Bo, To, Ho, Wo, sb, stt, bt, bt_dev);
     return launch_status();
 }
 
@@ -765,7 +787,9 @@ extern "C" int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int
     return launch_status();
 }
 // merged-frames layout [b*T][inner]: keep samples ::2, frames bt::2. adjoint=1 writes y back into x.
-__global__ void subsample_frames_k(float* x, float* y, long T, long inner, long bo, long To, int bt, int adjoint) {
+__global__ void subsample_frames_k(float* x, float* y, long T, long inner, long bo, long To, int bt, int adjoint,
+                                   const int32_t* bt_dev) {
+    if (bt_dev) bt = bt_dev[0];
     const long n = bo * To * inner;
     GRID_STRIDE(i, n) {
         const long in = i % inner; long r = i / inner;
@@ -775,10 +799,11 @@ __global__ void subsample_frames_k(float* x, float* y, long T, long inner, long 
     }
 }
 extern "C" int t2v_subsample_frames(float* x, float* y, int64_t b, int64_t T, int64_t inner, int64_t bo, int64_t To, int bt,
-                                    int adjoint, void* st) {
+                                    int adjoint, const int32_t* bt_dev, void* st) {
     if (!x || !y || b < 1 || T < 1 || inner < 1 || bo < 1 || To < 1 || bt < 0 || bt > 1) return T2V_EINVAL;
-    if (2 * (bo - 1) >= b || 2 * (To - 1) + bt >= T) return T2V_EINVAL;
-    T2V_LAUNCH(subsample_frames_k, dim3(nblocks(bo * To * inner)), dim3(256), 0, S_(st), x, y, (long)T, (long)inner, (long)bo, (long)To, bt, adjoint);
+    const int btmax = bt_dev ? 1 : bt;
+    if (2 * (bo - 1) >= b || 2 * (To - 1) + btmax >= T) return T2V_EINVAL;
+    T2V_LAUNCH(subsample_frames_k, dim3(nblocks(bo * To * inner)), dim3(256), 0, S_(st), x, y, (long)T, (long)inner, (long)bo, (long)To, bt, adjoint, bt_dev);
     return launch_status();
 }
 // adjoint of pyramid_gather without spatial resampling: gx[b*sb, c, t*st+bt, :] = g[b, c, t, :]

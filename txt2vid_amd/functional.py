@@ -107,27 +107,54 @@ def conv_geom(N, Cin, D, H, W, Cout, kD, kH, kW):
     return g
 
 
-_pack_cache = {}
+_pack_cache = {}      # id(base parameter) -> {(shape5, tap mask, mode): [weakref, tag, buffer, geom]}
 
 
 def packed_weight(w5, geom, mode):
-    """wp[ntaps][Cin][Cout] (mode 0) / wp[ntaps][Cout][Cin] mirrored (mode 1), cached per
-    (parameter, tap set, mode) until the weight changes."""
+    """wp[ntaps][Cin][Cout] (mode 0) / wp[ntaps][Cout][Cin] mirrored (mode 1). For parameters the packed
+    buffer is PERSISTENT (one per (parameter, tap set, mode)) and is refreshed in place — lazily here when
+    the parameter changed, eagerly by `repack_params` right after an optimiser step — so that a captured
+    HIP graph always reads the same addresses."""
     Cout, Cin = w5.shape[0], w5.shape[1]
     base = w5._base if w5._base is not None else w5          # 2-D convs / Linear arrive as 5-D views
     cacheable = isinstance(base, torch.nn.Parameter)
-    key = (id(base), tuple(w5.shape), geom.mask, mode)
+    if not cacheable:
+        wp = torch.empty((len(geom.taps), Cin * Cout), device=w5.device, dtype=torch.float32)
+        check(lib().t2v_pack_weight(_p(w5), _p(wp), Cout, Cin, geom.T, geom.taps_c, len(geom.taps), mode, _stream()),
+              't2v_pack_weight')
+        return wp
+    key = (tuple(w5.shape), geom.mask, mode)
     tag = (base._version, WEIGHT_EPOCH, w5.data_ptr())
-    if cacheable:
-        hit = _pack_cache.get(key)
-        if hit is not None and hit[0]() is base and hit[1] == tag:
-            return hit[2]
+    ent = _pack_cache.setdefault(id(base), {})
+    hit = ent.get(key)
+    if hit is not None and hit[0]() is base:
+        if hit[1] != tag:
+            check(lib().t2v_pack_weight(_p(w5), _p(hit[2]), Cout, Cin, geom.T, geom.taps_c, len(geom.taps), mode, _stream()),
+                  't2v_pack_weight')
+            hit[1] = tag
+        return hit[2]
     wp = torch.empty((len(geom.taps), Cin * Cout), device=w5.device, dtype=torch.float32)
     check(lib().t2v_pack_weight(_p(w5), _p(wp), Cout, Cin, geom.T, geom.taps_c, len(geom.taps), mode, _stream()),
           't2v_pack_weight')
-    if cacheable:
-        _pack_cache[key] = (weakref.ref(base), tag, wp)
+    ent[key] = [weakref.ref(base), tag, wp, geom]
     return wp
+
+
+def repack_params(params):
+    """Refresh every packed variant of these parameters in place (called by the optimiser after its
+    in-place update, inside the captured graph when graphs are in use)."""
+    for p in params:
+        ent = _pack_cache.get(id(p))
+        if not ent:
+            continue
+        for key, hit in ent.items():
+            if hit[0]() is not p:
+                continue
+            shape5, _, mode = key
+            geom = hit[3]
+            check(lib().t2v_pack_weight(_p(p), _p(hit[2]), shape5[0], shape5[1], geom.T, geom.taps_c, len(geom.taps), mode,
+                                        _stream()), 't2v_pack_weight')
+            hit[1] = (p._version, WEIGHT_EPOCH, p.data_ptr())
 
 
 def _as5(t):
@@ -952,12 +979,14 @@ def row_sqnorm(g):
     return RowSqNorm.apply(g)
 
 
-def pyramid_gather(x, Bo, To, Ho, Wo, sb, st, bt):
-    """y[b,c,t,h,w] = x[b*sb, c, t*st+bt, nearest(h), nearest(w)] — Subsample + F.interpolate(nearest)."""
+def pyramid_gather(x, Bo, To, Ho, Wo, sb, st, bt, bt_dev=None):
+    """y[b,c,t,h,w] = x[b*sb, c, t*st+bt, nearest(h), nearest(w)] — Subsample + F.interpolate(nearest).
+    bt_dev: optional int32 device tensor holding the phase (graph replay)."""
     x = _c(x)
     B, Cc, T, H, W = x.shape
     y = torch.empty((Bo, Cc, To, Ho, Wo), device=x.device, dtype=torch.float32)
-    check(lib().t2v_pyramid_gather(_p(x), _p(y), B, Cc, T, H, W, Bo, To, Ho, Wo, sb, st, bt, _stream()), 't2v_pyramid_gather')
+    check(lib().t2v_pyramid_gather(_p(x), _p(y), B, Cc, T, H, W, Bo, To, Ho, Wo, sb, st, bt, _p(bt_dev), _stream()),
+          't2v_pyramid_gather')
     return y
 
 
@@ -983,10 +1012,11 @@ class PyramidGather(Function):
         return gx, None
 
 
-def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0, step_dev=None):
     bc1 = 1.0 - b1 ** step
     bc2 = 1.0 - b2 ** step
-    check(lib().t2v_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, bc1, bc2, gscale, _stream()), 't2v_adam')
+    check(lib().t2v_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, bc1, bc2, gscale, _p(step_dev), _stream()),
+          't2v_adam')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1117,14 +1147,18 @@ class _SubsampleFrames(Function):
     """[b*T,C,h,w] -> keep samples ::2 and frames bt::2 -> [ceil(b/2)*(T/2),C,h,w] (gen.py:98-109)."""
 
     @staticmethod
-    def forward(ctx, x, T, bt):
+    def forward(ctx, x, T, bt, bt_dev):
         x = _c(x)
         bT, Cc, H, W = x.shape
         b = bT // T
+        if bt_dev is not None and T % 2:
+            raise ValueError('a device-resident phase needs an even frame count (the output shape must not depend on it)')
         bo, To = (b + 1) // 2, (T - bt + 1) // 2
         ctx.cfg = (tuple(x.shape), b, T, bt, bo, To)
+        ctx.bt_dev = bt_dev
         out = torch.empty((bo * To, Cc, H, W), device=x.device, dtype=torch.float32)
-        check(lib().t2v_subsample_frames(_p(x), _p(out), b, T, Cc * H * W, bo, To, bt, 0, _stream()), 't2v_subsample_frames')
+        check(lib().t2v_subsample_frames(_p(x), _p(out), b, T, Cc * H * W, bo, To, bt, 0, _p(bt_dev), _stream()),
+              't2v_subsample_frames')
         return out
 
     @staticmethod
@@ -1134,13 +1168,13 @@ class _SubsampleFrames(Function):
         g = _c(g)
         gx = torch.empty(shp, device=g.device, dtype=torch.float32)
         check(lib().t2v_fill(_p(gx), 0.0, gx.numel(), _stream()), 't2v_fill')
-        check(lib().t2v_subsample_frames(_p(gx), _p(g), b, T, shp[1] * shp[2] * shp[3], bo, To, bt, 1, _stream()),
+        check(lib().t2v_subsample_frames(_p(gx), _p(g), b, T, shp[1] * shp[2] * shp[3], bo, To, bt, 1, _p(ctx.bt_dev), _stream()),
               't2v_subsample_frames(adjoint)')
-        return gx, None, None
+        return gx, None, None, None
 
 
-def subsample_frames(x, T, bt):
-    return _SubsampleFrames.apply(x, T, bt)
+def subsample_frames(x, T, bt, bt_dev=None):
+    return _SubsampleFrames.apply(x, T, bt, bt_dev)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1309,3 +1343,96 @@ def cat_batch(a, b):
 def tail_rows(x, n_skip):
     """x[n_skip:] — a trailing-rows slice of a contiguous tensor is a view."""
     return x[n_skip:]
+
+
+# ------------------------------------------------------------------------------------------------
+# random draws of one training iteration (SURVEY §7 "RNG parity"): always made on the HOST generators in
+# the reference's order. `HostDraws` hands them out as they are made (eager mode); `StaticDraws` makes
+# all of an iteration's draws up front and keeps them in fixed device buffers, so that a captured HIP
+# graph reads this iteration's phases / z / alphas from the same addresses on every replay.
+# ------------------------------------------------------------------------------------------------
+
+class HostDraws(object):
+    def multiscale_t0(self, n):
+        """n Subsample draws of trainer.multiscale_data; returns per level (t0 host int, None)."""
+        out, t0, st = [], 0, 1
+        for _ in range(n):
+            out.append((t0, None))
+            bt = int(torch.randint(2, (1,)))
+            t0, st = t0 + bt * st, st * 2
+        return out
+
+    def phase(self):
+        return int(torch.randint(2, (1,))), None
+
+    def z(self, batch, latent, device):
+        return torch.randn(batch, latent).to(device, non_blocking=True)
+
+    def alpha(self, b, ndim, device):
+        return torch.rand(b, *([1] * (ndim - 1))).reshape(b).to(device=device, dtype=torch.float32)
+
+
+class StaticDraws(object):
+    def __init__(self, device, batch, latent, n_levels, n_gen_phases=3, gp=True, subsample_input=True):
+        self.device, self.batch, self.latent = device, batch, latent
+        self.n_levels, self.n_gen, self.gp, self.sub = n_levels, n_gen_phases, gp, subsample_input
+        self.bs = [batch]
+        for _ in range(n_levels - 1):
+            self.bs.append((self.bs[-1] + 1) // 2)
+        self.h_int = torch.zeros(n_levels + n_gen_phases, dtype=torch.int32).pin_memory()
+        self.d_int = torch.zeros(n_levels + n_gen_phases, dtype=torch.int32, device=device)
+        self.h_z = torch.zeros(batch, latent).pin_memory()
+        self.d_z = torch.zeros(batch, latent, device=device)
+        self.h_a = torch.zeros(sum(self.bs)).pin_memory()
+        self.d_a = torch.zeros(sum(self.bs), device=device)
+        self._i = self._a = 0
+
+    def begin_step(self):
+        """All host draws of one iteration, reference order: n_levels Subsample phases, z, the generator's
+        phases, the GP alphas per level; then three small H2D copies on the current stream."""
+        t0, st = 0, 1
+        for l in range(self.n_levels):
+            self.h_int[l] = t0
+            if self.sub:
+                bt = int(torch.randint(2, (1,)))
+                t0, st = t0 + bt * st, st * 2
+        self.h_z.copy_(torch.randn(self.batch, self.latent))
+        for k in range(self.n_gen):
+            self.h_int[self.n_levels + k] = int(torch.randint(2, (1,)))
+        if self.gp:
+            off = 0
+            for b in self.bs:
+                self.h_a[off:off + b] = torch.rand(b, 1, 1, 1, 1).reshape(b)
+                off += b
+        self.d_int.copy_(self.h_int, non_blocking=True)
+        self.d_z.copy_(self.h_z, non_blocking=True)
+        self.d_a.copy_(self.h_a, non_blocking=True)
+        self._i = self._a = 0
+
+    def multiscale_t0(self, n):
+        assert n == self.n_levels
+        return [(0, self.d_int[l:l + 1]) for l in range(n)]
+
+    def phase(self):
+        k = self._i
+        self._i += 1
+        return 0, self.d_int[self.n_levels + k:self.n_levels + k + 1]
+
+    def z(self, batch, latent, device):
+        return self.d_z
+
+    def alpha(self, b, ndim, device):
+        off = self._a
+        self._a += b
+        return self.d_a[off:off + b]
+
+    def rewind(self):
+        self._i = self._a = 0
+
+
+draws = HostDraws()
+
+
+def set_draws(d):
+    global draws
+    draws = d

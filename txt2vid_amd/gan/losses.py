@@ -70,8 +70,9 @@ def _gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xb
         raise NotImplementedError('sample mappings (TCWYT baseline) are outside the hot path')
     b = real_x.size(0)
     if alpha is None:
-        alpha = torch.rand(b, *([1] * (real_x.dim() - 1)))
-    a_dev = alpha.reshape(b).to(device=real_x.device, dtype=torch.float32)
+        a_dev = TF.draws.alpha(b, real_x.dim(), real_x.device)      # U[0,1)^b from the HOST generator
+    else:
+        a_dev = alpha.reshape(b).to(device=real_x.device, dtype=torch.float32)
     xh = TF.lerp_rows(a_dev, real_x.detach(), fake_x.detach()).requires_grad_(True)
     ch = None
     if real_cond is not None and fake_cond is not None:

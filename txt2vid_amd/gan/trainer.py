@@ -43,76 +43,168 @@ def add_params_to_parser(parser):
 def multiscale_data(x, cond, frame_sizes, subsample_input=True):
     """Real-data pyramid — trainer.py:131-165. x: [B,C,T,H,W] on the device. Level i is the nearest
     resize of the (progressively batch/time sub-sampled) clip to frame_sizes[i]; one gather kernel per
-    level does sub-sampling and resize in a single pass over the source."""
+    level does sub-sampling and resize in a single pass over the source. The Subsample phases come from
+    `TF.draws` (host generator; device-resident under graph replay)."""
     n = len(frame_sizes)
     if n == 1:
         return [x], (None if cond is None else [cond])
     B, Cc, T, H, W = x.shape
+    if subsample_input:
+        t0s = TF.draws.multiscale_t0(n)
+    else:
+        t0s = [(0, None)] * n
     xs, conds = [], []
-    sb, st, t0 = 1, 1, 0           # level tensor == x[::sb, :, t0::st]
+    sb, st = 1, 1                  # level tensor == x[::sb, :, t0::st]
     Bl, Tl = B, T
     for i in range(n):
         fs = frame_sizes[i] if i != n - 1 else None
         Ho, Wo = (fs, fs) if fs is not None else (H, W)
+        t0, t0_dev = t0s[i]
         if sb == 1 and st == 1 and Ho == H and Wo == W:
             xs.append(x)
         else:
-            xs.append(TF.pyramid_gather(x, Bl, Tl, Ho, Wo, sb, st, t0))
+            xs.append(TF.pyramid_gather(x, Bl, Tl, Ho, Wo, sb, st, t0, t0_dev))
         if cond is not None:
             conds.append(cond)
         if subsample_input:
-            bt = int(torch.randint(2, (1,)))                 # Subsample.forward draw (layers.py:108)
-            t0, st, sb = t0 + bt * st, st * 2, sb * 2
-            Bl, Tl = (Bl + 1) // 2, (Tl - bt + 1) // 2
+            if Tl % 2:
+                raise ValueError('subsample_input needs a frame count divisible by 2**levels')
+            st, sb = st * 2, sb * 2
+            Bl, Tl = (Bl + 1) // 2, Tl // 2
             if cond is not None:
                 cond = TF.stride_rows(cond, 2)
     return xs, (conds if conds else None)
 
 
+class TrainStep(object):
+    """The loop body trainer.py:199-267 after data loading, cut at the two points where data-parallel
+    ranks exchange gradients:  part_d (pyramid, G forward, D loss + GP, D backward)  |sync D grads|
+    part_g (Adam on D, real_pred, G loss, G backward)  |sync G grads|  part_end (Adam on G).
+    Eager mode runs the three parts back to back; `GraphedTrainStep` captures each part as a HIP graph."""
+
+    def __init__(self, gan, optD, optG, losses, params, device, end2end=False, grad_sync=None):
+        if params.discrim_steps != 1 or params.gen_steps != 1:
+            raise NotImplementedError('the canonical 1 D step : 1 G step schedule (scripts/run_tganv2*.sh) is built')
+        self.gan, self.optD, self.optG, self.losses, self.params = gan, optD, optG, losses, params
+        self.device, self.end2end, self.grad_sync = device, end2end, grad_sync
+        self.lD = self.lG = self.fake = self.xs = self.conds = None
+
+    def part_d(self, x, cond):
+        p = self.params
+        self.xs, self.conds = multiscale_data(x, cond, p.frame_sizes, p.subsample_input)
+        z = TF.draws.z(x.size(0), self.gan.gen.latent_size, self.device)       # CPU generator, then copy (parity)
+        self.fake = self.gan(z, cond=self.conds[0] if self.conds is not None else None)
+        loss = self.gan.discrim_step(real=self.xs, fake=[f.detach() for f in self.fake], cond=self.conds,
+                                     loss=self.losses.discrim_loss, gp_lambda=p.gp_lambda)
+        loss.backward(retain_graph=self.end2end)
+        self.lD = loss.detach()
+
+    def part_g(self):
+        self.optD.step()
+        # D after its update, on the real batch (trainer.py:247). Its graph is only needed when the text
+        # encoder trains end-to-end; otherwise nothing upstream of these predictions receives a gradient
+        # that is ever used, so none is recorded (identical results, SURVEY §7 "wasted work").
+        if self.end2end:
+            _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
+        else:
+            with torch.no_grad():
+                _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
+        loss = self.gan.gen_step(fake=self.fake, real_pred=real_pred, cond=self.conds, loss=self.losses.gen_loss)
+        loss.backward()
+        self.lG = loss.detach()
+
+    def part_end(self):
+        self.optG.step()
+
+    def run(self, x, cond=None):
+        self.part_d(x, cond)
+        if self.grad_sync is not None:
+            self.grad_sync('D')
+        self.part_g()
+        if self.grad_sync is not None:
+            self.grad_sync('G')
+        self.part_end()
+        return self.lD, self.lG, self.fake, self.xs
+
+
 def train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=False, z=None, grad_sync=None):
-    """One pass of the loop body trainer.py:199-267 after data loading. x: [B,C,T,H,W] device tensor.
-    Returns (lossD, lossG) as 0-d device tensors (no host sync here)."""
-    batch_size = x.size(0)
-    xs, conds = multiscale_data(x, cond, params.frame_sizes, params.subsample_input)
-    if z is None:
-        z = torch.randn(batch_size, gan.gen.latent_size)          # CPU generator, then copy (parity)
-    z = z.to(device, non_blocking=True)
-    fake = gan(z, cond=conds[0] if conds is not None else None)
+    """One eager pass of the loop body. x: [B,C,T,H,W] device tensor. Returns (lossD, lossG, fake, xs);
+    the losses are 0-d device tensors (no host sync here)."""
+    return TrainStep(gan, optD, optG, losses, params, device, end2end, grad_sync).run(x, cond)
 
-    total_d = None
-    for j in range(params.discrim_steps):
-        loss = gan.discrim_step(real=xs, fake=[f.detach() for f in fake], cond=conds, loss=losses.discrim_loss,
-                                gp_lambda=params.gp_lambda)
-        if not params.no_mean_discrim_loss:
-            loss = TF.scalar_sum([loss], [1.0 / params.discrim_steps])
-        loss.backward(retain_graph=(j != params.discrim_steps - 1) or end2end)
-        if grad_sync is not None:
-            grad_sync('D')
-        optD.step()
-        total_d = loss.detach() if total_d is None else TF.scalar_sum([total_d, loss.detach()])
 
-    # D after its update, on the real batch (trainer.py:247). Its graph is only needed when the text
-    # encoder trains end-to-end; otherwise nothing upstream of these predictions receives a gradient
-    # that is ever used, so no graph is recorded (identical results, SURVEY §7 "wasted work").
-    if end2end:
-        _, _, real_pred = gan.all_discrim_forward(real=xs, cond=conds, fake=None, loss=None)
-    else:
-        with torch.no_grad():
-            _, _, real_pred = gan.all_discrim_forward(real=xs, cond=conds, fake=None, loss=None)
+class GraphedTrainStep(object):
+    """HIP-graph replay of the training iteration (unconditional path): after `warmup` eager iterations
+    the three parts of `TrainStep` are captured once (shared memory pool) and every later iteration is
+    3 graph launches + the eager gradient exchange between them. All per-iteration randomness is drawn
+    on the host in the reference's order and uploaded into fixed buffers before the replay
+    (`functional.StaticDraws`); the batch is copied into a fixed input buffer."""
 
-    total_g = None
-    for j in range(params.gen_steps):
-        if j != 0:
-            fake = gan(z, cond=conds[0] if conds is not None else None)
-        loss = gan.gen_step(fake=fake, real_pred=real_pred, cond=conds, loss=losses.gen_loss)
-        if not params.no_mean_gen_loss:
-            loss = TF.scalar_sum([loss], [1.0 / params.gen_steps])
-        loss.backward(retain_graph=j != params.gen_steps - 1)
-        if grad_sync is not None:
-            grad_sync('G')
-        optG.step()
-        total_g = loss.detach() if total_g is None else TF.scalar_sum([total_g, loss.detach()])
-    return total_d, total_g, fake, xs
+    def __init__(self, gan, optD, optG, losses, params, device, batch_shape, grad_sync=None, warmup=3):
+        self.ts = TrainStep(gan, optD, optG, losses, params, device, False, grad_sync)
+        self.device, self.grad_sync, self.warmup = device, grad_sync, warmup
+        n_levels = len(params.frame_sizes)
+        self.draws = TF.StaticDraws(device, batch_shape[0], gan.gen.latent_size, n_levels, n_gen_phases=n_levels - 1,
+                                    gp=params.gp_lambda > 0, subsample_input=params.subsample_input)
+        self.x = torch.empty(batch_shape, device=device, dtype=torch.float32)
+        self.graphs = None
+        self.n = 0
+        # warm-up and capture run on ONE side stream (the autograd graph's AccumulateGrad nodes remember
+        # the stream they were created on; capture must see the same one)
+        self.side = torch.cuda.Stream(device=device)
+
+    def _eager(self):
+        self.ts.run(self.x, None)
+
+    def _capture(self):
+        for opt in (self.ts.optD, self.ts.optG):
+            opt.make_capturable(self.device)
+        # drop every reference into the previous iteration's autograd graph before capturing
+        self.ts.lD = self.ts.lG = self.ts.fake = self.ts.xs = self.ts.conds = None
+        torch.cuda.synchronize()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.draws.rewind()
+        with torch.cuda.graph(g1, stream=self.side):
+            self.ts.part_d(self.x, None)
+        if self.grad_sync is not None:
+            self.grad_sync('D')
+        with torch.cuda.graph(g2, pool=g1.pool(), stream=self.side):
+            self.ts.part_g()
+        if self.grad_sync is not None:
+            self.grad_sync('G')
+        with torch.cuda.graph(g3, pool=g1.pool(), stream=self.side):
+            self.ts.part_end()
+        torch.cuda.synchronize()
+        self.graphs = (g1, g2, g3)
+
+    def step(self, x):
+        """x: [B,C,T,H,W] device (or pinned host) tensor. Returns (lossD, lossG) 0-d device tensors that are
+        overwritten by the next call."""
+        old = TF.draws
+        TF.set_draws(self.draws)
+        try:
+            self.x.copy_(x, non_blocking=True)
+            self.draws.begin_step()
+            if self.graphs is None and self.n >= self.warmup:
+                self._capture()          # the capture pass also executes nothing: replay right after
+            if self.graphs is None:
+                cur = torch.cuda.current_stream(self.device)
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    self._eager()
+                cur.wait_stream(self.side)
+            else:
+                self.graphs[0].replay()
+                if self.grad_sync is not None:
+                    self.grad_sync('D')
+                self.graphs[1].replay()
+                if self.grad_sync is not None:
+                    self.grad_sync('G')
+                self.graphs[2].replay()
+            self.n += 1
+        finally:
+            TF.set_draws(old)
+        return self.ts.lD, self.ts.lG
 
 
 def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=None, params=None, vocab=None, losses=None,

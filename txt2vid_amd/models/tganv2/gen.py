@@ -80,5 +80,5 @@ class MultiScaleGen(nn.Module):
         """`Subsample` applied on the merged-frames layout: keeps samples ::2 and frames bt::2
         (gen.py:98-106). bt is drawn from the CPU generator exactly like the reference."""
         from ... import functional as TF
-        bt = torch.randint(self.subsample.st, (1,))
-        return TF.subsample_frames(x, num_frames, int(bt)), bt
+        bt, bt_dev = TF.draws.phase()
+        return TF.subsample_frames(x, num_frames, bt, bt_dev), bt

@@ -11,9 +11,22 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError('the hot path uses no weight decay')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self.step_dev = None          # device-resident step counter (set by `make_capturable`)
+
+    def make_capturable(self, device):
+        """Keep the step number on the device so that a captured HIP graph applies the right bias
+        corrections on every replay (all parameters of this optimiser step together)."""
+        steps = [int(self.state[p]['step']) for g in self.param_groups for p in g['params'] if p in self.state and self.state[p]]
+        if len({tuple(g['betas']) for g in self.param_groups}) != 1:
+            raise NotImplementedError('graph capture: one (beta1, beta2) per optimiser')
+        self.step_dev = torch.tensor([float(max(steps) if steps else 0), 0.0, 0.0], device=device, dtype=torch.float32)
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self.step_dev is not None:
+            b1, b2 = self.param_groups[0]['betas']
+            TF.check(TF.lib().t2v_adam_tick(TF._p(self.step_dev), b1, b2, TF._stream()), 't2v_adam_tick')
+        touched = []
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:
@@ -27,6 +40,8 @@ class Adam(torch.optim.Optimizer):
                 st['step'] = int(st['step']) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 TF.adam_step(p, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], b1, b2, group['eps'], st['step'],
-                             self.grad_scale)
-        TF.bump_weight_epoch()          # packed-weight caches are now stale
+                             self.grad_scale, self.step_dev)
+                touched.append(p)
+        TF.bump_weight_epoch()          # packed weights are stale ...
+        TF.repack_params(touched)       # ... refresh them in place right away (same addresses for graph replay)
         return None
