@@ -438,6 +438,45 @@ def gen_loss(P, prefix, fake, real_pred, conds=None):
 
 
 # --------------------------------------------------------------------------------------------
+# text encoder — txt2vid/models/txt/basic.py:49-70 (Embedding -> packed 4-layer Bi-LSTM -> last hidden)
+# --------------------------------------------------------------------------------------------
+
+def text_encoder_shapes(vocab_size, embed=256, hidden=256, layers=4, prefix='encoder.'):
+    """Keys of `Seq2Seq(vocab_size).state_dict()` restricted to the encoder (decoder is the same object)."""
+    s = {prefix + 'embed.weight': (vocab_size, embed)}
+    h = hidden // 2
+    for l in range(layers):
+        for suf in ('', '_reverse'):
+            s[prefix + 'lstm.weight_ih_l%d%s' % (l, suf)] = (4 * h, embed if l == 0 else hidden)
+            s[prefix + 'lstm.weight_hh_l%d%s' % (l, suf)] = (4 * h, h)
+            s[prefix + 'lstm.bias_ih_l%d%s' % (l, suf)] = (4 * h,)
+            s[prefix + 'lstm.bias_hh_l%d%s' % (l, suf)] = (4 * h,)
+    s[prefix + 'to_vocab.weight'] = (vocab_size, hidden)
+    s[prefix + 'to_vocab.bias'] = (vocab_size,)
+    return s
+
+
+_LSTM_CACHE = {}
+
+
+def text_encode(P, tokens, lengths, prefix='encoder.', hidden=256, layers=4):
+    """`RecurrentModel.forward(...)[2]`: cat(h_fwd[-1], h_bwd[-1]) of a packed Bi-LSTM."""
+    from torch.nn.utils.rnn import pack_padded_sequence
+    key = id(P)
+    if key not in _LSTM_CACHE:
+        emb = P[prefix + 'embed.weight']
+        with torch.random.fork_rng():        # the constructor's default init must not consume the global stream
+            lstm = torch.nn.LSTM(emb.shape[1], hidden // 2, layers, batch_first=True, bidirectional=True)
+        lstm.load_state_dict({k[len(prefix + 'lstm.'):]: v.detach() for k, v in P.items() if k.startswith(prefix + 'lstm.')})
+        _LSTM_CACHE[key] = lstm
+    lstm = _LSTM_CACHE[key]
+    e = F.embedding(tokens, P[prefix + 'embed.weight'])
+    _, (hn, _) = lstm(pack_padded_sequence(e, [int(l) for l in lengths], batch_first=True))
+    hn = hn.view(layers, 2, -1, hidden // 2)
+    return torch.cat((hn[-1, 0], hn[-1, 1]), dim=1)
+
+
+# --------------------------------------------------------------------------------------------
 # the training iteration — txt2vid/gan/trainer.py:190-267
 # --------------------------------------------------------------------------------------------
 

@@ -294,6 +294,67 @@ def golden_steps():
     save('steps_uncond', **out)
 
 
+def golden_steps_cond():
+    """Text-conditioned TGANv2 (Bi-LSTM cond 256-d, non-local blocks on), B=4: the reference's own
+    `discrim_step` / `all_discrim_forward` / `gen_step` (cond_gan.py:90-164) for 3 iterations."""
+    out = {}
+    B, V = 4, 21
+    g = pour(GenC(width=64, height=64, num_channels=1, cond_dim=256))
+    d = pour(DisC(num_channels=1, cond_dim=256))
+    txt = Seq2Seq(vocab_size=V)          # encoder and decoder are ONE module: both key prefixes alias the same tensors
+    txt.load_state_dict({k: recipe_tensor('encoder.' + k.split('.', 1)[1], v.shape) for k, v in txt.state_dict().items()})
+    g.train()
+    d.train()
+    seed = 100
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    gan = CondGan(gen=g, discrims=[d], cond_encoder=txt, discrim_names=['video'])
+    losses = MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss())
+    optD = torch.optim.Adam([{'params': d.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = torch.optim.Adam([{'params': g.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    ss = Subsample()
+    fs = [8, 16, 32, 64]
+    tg = torch.Generator()
+    tg.manual_seed(1234)
+    tokens = torch.randint(4, V, (B, 8), generator=tg)
+    tokens[:, 0], tokens[:, -1] = 1, 2
+    lengths = [8] * B
+    out['tokens'] = tokens.numpy()
+    lD_all, lG_all = [], []
+    for it in range(3):
+        x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
+        _, _, cond = gan.cond_encoder.encode(tokens, lengths)
+        cond = cond.detach()
+        if it == 0:
+            out['cond0'] = npy(cond)
+        xs, conds = [], []
+        for i in range(4):
+            xs.append(F.interpolate(x, size=(x.size(2), fs[i], fs[i])) if i != 3 else x)
+            conds.append(cond)
+            x, _ = ss(x)
+            cond = cond[::2]
+        z = torch.randn(B, g.latent_size)
+        fake = gan(z, cond=conds[0])
+        lD = gan.discrim_step(real=xs, fake=[f.detach() for f in fake], cond=conds, loss=losses.discrim_loss, gp_lambda=0.5)
+        lD.backward()
+        if it == 0:
+            pack_norms('it0_D_gn', grad_norms(d), out)
+        optD.step()
+        _, _, real_pred = gan.all_discrim_forward(real=xs, cond=conds, fake=None, loss=None)
+        lG = gan.gen_step(fake=fake, real_pred=real_pred, cond=conds, loss=losses.gen_loss)
+        lG.backward()
+        if it == 0:
+            pack_norms('it0_G_gn', grad_norms(g), out)
+        optG.step()
+        lD_all.append(float(lD))
+        lG_all.append(float(lG))
+        print('cond it', it, float(lD), float(lG))
+    out['lossD'] = np.array(lD_all, dtype=np.float64)
+    out['lossG'] = np.array(lG_all, dtype=np.float64)
+    save('steps_cond', **out)
+
+
 def golden_init():
     """Checksums of `init(model, 'xavier')` after seeding 100 and constructing G then D
     (train/setup.py:7-14, train/gan.py:60-70, util/torch/init.py:4-39)."""
@@ -315,7 +376,7 @@ def golden_init():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init']
+    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond']
     if 'layers' in which:
         golden_layers()
     if 'resnet3d' in which:
@@ -326,3 +387,5 @@ if __name__ == '__main__':
         golden_init()
     if 'steps' in which:
         golden_steps()
+    if 'steps_cond' in which:
+        golden_steps_cond()

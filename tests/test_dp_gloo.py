@@ -1,0 +1,88 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange of txt2vid_amd.dist, and the
+global-batch semantics of SURVEY §8(e) (BCE terms are batch means, the multi-scale GP is a batch SUM and
+is therefore scaled by world_size before gradient averaging) checked with the CPU oracle."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tganv2_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _arena_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from txt2vid_amd import dist as tdist
+    r, w = tdist.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2))]
+    params[0].grad = torch.full((3, 4), float(rank + 1))
+    params[1].grad = torch.arange(5.0) * (rank + 1)
+    params[2].grad = None                                     # never reached on this rank: counts as zero
+
+    class Opt(object):
+        grad_scale = 1.0
+    arena = tdist.GradArena(params)
+    opt = Opt()
+    sync = tdist.make_grad_sync({'D': arena}, {'D': opt}, world)
+    sync('D')
+    q.put((rank, [p.grad.clone() for p in params], opt.grad_scale, arena.numel))
+    dist.destroy_process_group()
+
+
+def test_grad_arena_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, grads, scale, numel in res:
+        assert numel == 12 + 5 + 4 and scale == 0.5
+        assert torch.equal(grads[0], torch.full((3, 4), 3.0))            # 1 + 2, SUM; the optimiser applies 1/world
+        assert torch.equal(grads[1], torch.arange(5.0) * 3)
+        assert torch.equal(grads[2], torch.zeros(2, 2))
+
+
+def test_dp_semantics_equal_global_batch_with_oracle():
+    """Two replicas x local batch 2 with averaged gradients == one replica x global batch 4, provided the
+    GP (a batch sum) is scaled by world_size locally. Single pyramid level, identical alphas."""
+    torch.manual_seed(0)
+    P = O.recipe_state(O.resnet3d_shapes('', 1, 64, 0))
+    keys = [k for k, v in P.items() if v.dtype.is_floating_point]
+    for k in keys:
+        P[k].requires_grad_(True)
+    real, fake = torch.randn(4, 1, 4, 8, 8), torch.randn(4, 1, 4, 8, 8)
+    alpha = torch.rand(4, 1, 1, 1, 1)
+
+    def loss_on(sl, gp_scale):
+        r, f, a = real[sl], fake[sl], alpha[sl]
+        ur, uf = O.resnet3d(P, r)[0], O.resnet3d(P, f)[0]
+        return O.rsgan_discrim_loss(uf, ur) + 0.5 * gp_scale * O.gp_level(P, '', r, f, alpha=a)
+
+    def grads(l):
+        for k in keys:
+            P[k].grad = None
+        l.backward()
+        return {k: (P[k].grad.clone() if P[k].grad is not None else torch.zeros_like(P[k])) for k in keys}
+    g_global = grads(loss_on(slice(0, 4), 1.0))
+    g0 = grads(loss_on(slice(0, 2), 2.0))
+    g1 = grads(loss_on(slice(2, 4), 2.0))
+    for k in keys:
+        avg = 0.5 * (g0[k] + g1[k])
+        assert torch.allclose(avg, g_global[k], rtol=2e-3, atol=1e-5 * max(1.0, float(g_global[k].abs().max()))), k

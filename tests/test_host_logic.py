@@ -1,0 +1,138 @@
+"""CPU: host-side logic of the drop-in surface (no kernels): reflection, init parity with the reference,
+state_dict layout, random-draw bookkeeping, data contract, checkpoint key matching."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tganv2_oracle as O
+
+
+def test_reflection_aliases_reference_names():
+    from txt2vid_amd.util.reflection import create_object, get_class
+    from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
+    assert get_class('txt2vid.models.tganv2_cond.gen.MultiScaleGen') is MultiScaleGen
+    loss = create_object('txt2vid.gan.losses.RSGANLoss')
+    assert loss.__class__.__name__ == 'RSGANLoss'
+    d = create_object({'class': 'txt2vid.models.tganv2.discrim.MultiScaleDiscrim', 'args': {'num_channels': 1}}, cond_dim=0)
+    assert len(d.sub_discrims) == 4
+    ds = create_object({'class': 'txt2vid.data.my_dataset', 'args': {'data': '/nonexistent/videos', 'num_frames': 16}}, vocab=None)
+    v, c = ds[0]
+    assert tuple(v.shape) == (16, 1, 64, 64) and len(c) == 8 and float(v.min()) == -1.0
+
+
+@pytest.mark.parametrize('which', ['uncond', 'cond'])
+def test_state_dict_layout_matches_reference(which):
+    """Checkpoint interchange contract: key names and shapes equal the reference's."""
+    if which == 'uncond':
+        from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+        g, d = MultiScaleGen(width=64, height=64, num_channels=1), MultiScaleDiscrim(num_channels=1)
+        gs, ds_ = O.gen_shapes(num_channels=1), O.resnet3d_shapes('single_discrim.', 1, 64, 0)
+    else:
+        from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2_cond.discrim import MultiScaleDiscrim
+        g, d = MultiScaleGen(width=64, height=64, num_channels=1, cond_dim=256), MultiScaleDiscrim(num_channels=1, cond_dim=256)
+        gs = O.gen_shapes(num_channels=1, cond_dim=256, cond_variant=True)
+        ds_ = O.resnet3d_shapes('single_discrim.module.', 1, 64, 256)
+    for mod, shapes in ((g, gs), (d, ds_)):
+        sd = mod.state_dict()
+        assert set(sd.keys()) == set(shapes.keys())
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k]), k
+
+
+def test_xavier_init_reproduces_reference(golden):
+    """seed 100 -> construct G then D -> init(..., 'xavier'): per-key checksums equal those recorded from
+    the reference (train/setup.py:7-14, train/gan.py:60-70, util/torch/init.py:4-39)."""
+    from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+    from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+    from txt2vid_amd.util.torch.init import init
+    g = golden('init_xavier')
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    gen = MultiScaleGen(width=64, height=64, num_channels=1)
+    dis = MultiScaleDiscrim(num_channels=1)
+    init(gen, 'xavier')
+    init(dis, 'xavier')
+    for tag, m in (('G', gen), ('D', dis)):
+        sd = m.state_dict()
+        for k, s, a in zip([str(k) for k in g[tag + '_keys']], g[tag + '_sum'], g[tag + '_abs']):
+            assert abs(float(sd[k].double().sum()) - s) <= 1e-6 * max(1.0, a), k
+            assert abs(float(sd[k].double().abs().sum()) - a) <= 1e-6 * max(1.0, a), k
+
+
+def test_gen_perm_and_metrics():
+    from txt2vid_amd.util.misc import gen_perm
+    from txt2vid_amd.util.metrics import RollingAvg
+    np.random.seed(0)
+    for n in (2, 3, 8):
+        p = gen_perm(n)
+        assert sorted(p.tolist()) == list(range(n)) and not (p == np.arange(n)).all()
+    with pytest.raises(ValueError):
+        gen_perm(1)
+    np.random.seed(3)
+    a = gen_perm(6)
+    np.random.seed(3)
+    b = O.gen_perm(6)
+    assert (a == b).all()
+    r = RollingAvg(window_size=3)
+    for v in (1, 2, 3, 4):
+        r.update(v)
+    assert r.get() == 3.0
+
+
+def test_draw_sources_follow_the_reference_order():
+    """HostDraws (eager) and StaticDraws (graph replay) consume the CPU generator identically, and the
+    cumulative phases equal composing `x[::2, :, bt::2]` level by level (trainer.py:157-158)."""
+    from txt2vid_amd import functional as TF
+    torch.manual_seed(9)
+    h = TF.HostDraws()
+    t0s = [t for t, _ in h.multiscale_t0(4)]
+    z = torch.randn(4, 8)
+    ph = [int(torch.randint(2, (1,))) for _ in range(3)]
+    al = [torch.rand(b, 1, 1, 1, 1).reshape(b) for b in (4, 2, 1, 1)]
+    # same seed, oracle-style composition of Subsample
+    torch.manual_seed(9)
+    x = torch.arange(16).view(1, 1, 16, 1, 1).float()
+    lv = []
+    for i in range(4):
+        lv.append(x)
+        x, _ = O.subsample(x)
+    for i in range(4):
+        assert int(lv[i][0, 0, 0, 0, 0]) == t0s[i]
+        assert lv[i].shape[2] == 16 // 2 ** i
+    # StaticDraws needs pinned memory + a device; exercised on the GPU in test_models_gpu.py
+
+
+def test_data_contract():
+    from txt2vid_amd.data import SyntheticMovingDigits, collate_fn, Vocab
+    ds = SyntheticMovingDigits(length=8)
+    vids, toks, lens = collate_fn([ds[i] for i in range(4)])
+    assert tuple(vids.shape) == (4, 16, 1, 64, 64) and toks.dtype == torch.long and lens == sorted(lens, reverse=True)
+    assert float(vids.max()) <= 1.0 and float(vids.min()) == -1.0
+    v = Vocab()
+    assert len(v) == 21 and v.to_words(toks[0]).startswith('<start> digit')
+    a, _ = ds[2]
+    b, _ = SyntheticMovingDigits(length=8)[2]
+    assert torch.equal(a, b)
+
+
+def test_checkpoint_key_styles_interchange():
+    """`single_discrim.*` (uncond) <-> `single_discrim.module.*` (cond wrapper) — SURVEY §5."""
+    from txt2vid_amd.gan.cond_gan import _match_keys
+    want = ['single_discrim.module.fc.weight', 'single_discrim.module.fc.bias']
+    sd = {'single_discrim.fc.weight': 1, 'single_discrim.fc.bias': 2}
+    out = _match_keys(sd, want)
+    assert out == {'single_discrim.module.fc.weight': 1, 'single_discrim.module.fc.bias': 2}
+    assert _match_keys({k: 0 for k in want}, want) == {k: 0 for k in want}
+
+
+def test_cli_flags_match_reference():
+    import argparse
+    from txt2vid_amd.gan.trainer import add_params_to_parser
+    p = add_params_to_parser(argparse.ArgumentParser())
+    a = p.parse_args(['--gp_lambda', '.5', '--subsample_input', '--no_mean_discrim_loss'])
+    assert a.gp_lambda == 0.5 and a.subsample_input and a.no_mean_discrim_loss is False and a.no_mean_gen_loss is True

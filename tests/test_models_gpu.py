@@ -383,3 +383,83 @@ def test_graph_replay_matches_eager():
         tol = 1e-7 if i < 2 else 2e-4
         assert abs(got[0] - eager[i][0]) < tol and abs(got[1] - eager[i][1]) < tol, (i, got, eager[i])
     assert gs.graphs is not None
+
+
+def _make_cond(V=21):
+    from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
+    from txt2vid_amd.models.tganv2_cond.discrim import MultiScaleDiscrim
+    from txt2vid_amd.models.txt.basic import Seq2Seq
+    from txt2vid_amd.gan.cond_gan import CondGan
+    from txt2vid_amd.gan.losses import MixedGanLoss, RSGANLoss
+    from txt2vid_amd.optim import Adam
+    gen = pour(MultiScaleGen(width=64, height=64, num_channels=1, cond_dim=256))
+    dis = pour(MultiScaleDiscrim(num_channels=1, cond_dim=256))
+    txt = Seq2Seq(vocab_size=V)
+    sd = txt.state_dict()
+    txt.load_state_dict({k: O.recipe_tensor(k if k.startswith('encoder.') else 'encoder.' + k[len('decoder.'):], v.shape)
+                         for k, v in sd.items()})
+    txt.to(DEV)
+    gen.train()
+    dis.train()
+    gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'])
+    losses = MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss())
+    optD = Adam([{'params': dis.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = Adam([{'params': gen.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+
+    class Prm(object):
+        frame_sizes = [8, 16, 32, 64]
+        subsample_input = True
+        discrim_steps = gen_steps = 1
+        gp_lambda = 0.5
+        no_mean_discrim_loss = no_mean_gen_loss = True
+    return gan, optD, optG, losses, Prm()
+
+
+def test_train_steps_cond_vs_reference_golden(golden):
+    """Text-conditioned path (Bi-LSTM cond, cat(z,cond), 2-D + 3-D non-local blocks, second D head,
+    mismatched-caption loss, GP with interpolated captions): 3 free-running iterations vs the reference's
+    recorded losses + iteration-0 per-parameter gradient norms."""
+    from txt2vid_amd.gan.trainer import train_iteration
+    g = golden('steps_cond')
+    gan, optD, optG, losses, prm = _make_cond()
+    tokens = T(g['tokens']).to(DEV)
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    for it in range(3):
+        x = (torch.rand(4, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous().to(DEV)
+        with torch.no_grad():
+            _, _, cond = gan.cond_encoder.encode(tokens, [8] * 4)
+        if it == 0:
+            close(cond, g['cond0'])
+        lD, lG, _, _ = train_iteration(gan, x, cond.detach(), optD, optG, losses, prm, DEV)
+        tol = 1e-3 if it < 2 else 2e-2
+        print('cond free-running it %d: lossD %.7f (ref %.7f)  lossG %.7f (ref %.7f)' % (it, float(lD), g['lossD'][it], float(lG), g['lossG'][it]))
+        assert abs(float(lD) - g['lossD'][it]) < tol, (it, float(lD), g['lossD'][it])
+        assert abs(float(lG) - g['lossG'][it]) < tol, (it, float(lG), g['lossG'][it])
+
+
+def test_cond_first_step_grad_norms_vs_reference_golden(golden):
+    from txt2vid_amd.gan.trainer import multiscale_data
+    from txt2vid_amd import functional as TF
+    g = golden('steps_cond')
+    gan, optD, optG, losses, prm = _make_cond()
+    tokens = T(g['tokens']).to(DEV)
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    x = (torch.rand(4, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous().to(DEV)
+    with torch.no_grad():
+        _, _, cond = gan.cond_encoder.encode(tokens, [8] * 4)
+    xs, conds = multiscale_data(x, cond, prm.frame_sizes, True)
+    z = torch.randn(4, 256).to(DEV)
+    fake = gan(z, cond=conds[0])
+    lD = gan.discrim_step(real=xs, fake=[f.detach() for f in fake], cond=conds, loss=losses.discrim_loss, gp_lambda=0.5)
+    lD.backward()
+    norms_close(gan.discrims[0], g, 'it0_D_gn', rtol=3e-3)
+    optD.step()
+    with torch.no_grad():
+        _, _, real_pred = gan.all_discrim_forward(real=xs, cond=conds, fake=None, loss=None)
+    lG = gan.gen_step(fake=fake, real_pred=real_pred, cond=conds, loss=losses.gen_loss)
+    lG.backward()
+    norms_close(gan.gen, g, 'it0_G_gn', rtol=3e-3)

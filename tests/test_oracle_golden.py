@@ -230,3 +230,28 @@ def test_train_steps_uncond(golden):
         lD, lG = tr.step(x)
         assert abs(lD - g['lossD'][it]) < 1e-3, (it, lD, g['lossD'][it])
         assert abs(lG - g['lossG'][it]) < 1e-3, (it, lG, g['lossG'][it])
+
+
+def test_train_steps_cond(golden):
+    """Text-conditioned iterations (joint cond/uncond RSGAN loss with mismatched captions + GP) vs the
+    reference's recorded losses; also pins the oracle's Bi-LSTM encoder output."""
+    import random
+    g = golden('steps_cond')
+    V = 21
+    PG = O.recipe_state(O.gen_shapes(num_channels=1, cond_dim=256, cond_variant=True))
+    PD = O.recipe_state(O.resnet3d_shapes('single_discrim.module.', 1, 64, 256))
+    PT = O.recipe_state(O.text_encoder_shapes(V))
+    tokens = torch.from_numpy(g['tokens'])
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    tr = O.OracleTrainer(PG, PD, d_prefix='single_discrim.module.')
+    for it in range(3):
+        x = (torch.rand(4, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
+        with torch.no_grad():
+            cond = O.text_encode(PT, tokens, [8] * 4)
+        if it == 0:
+            close(cond, g['cond0'], rtol=1e-4, atol=1e-5)
+        lD, lG = tr.step(x, cond=cond)
+        assert abs(lD - g['lossD'][it]) < 1e-3, (it, lD, g['lossD'][it])
+        assert abs(lG - g['lossG'][it]) < 1e-3, (it, lG, g['lossG'][it])

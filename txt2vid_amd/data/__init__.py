@@ -83,6 +83,7 @@ def my_dataset(data=None, vocab=None, anno=None, transform=None, num_frames=16, 
     import os
     if data is not None and data != 'synthetic' and os.path.isdir(str(data)):
         raise NotImplementedError('frame-folder datasets are SURVEY §8(f)-1 (not built yet); use data="synthetic"')
+    args.pop('transform', None)
     return SyntheticMovingDigits(num_frames=num_frames, vocab=vocab, **args)
 
 

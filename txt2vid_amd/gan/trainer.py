@@ -207,6 +207,34 @@ class GraphedTrainStep(object):
         return self.ts.lD, self.ts.lG
 
 
+def test(gan=None, num_samples=1, dataset=None, device=None, params=None, channel_first=True, vocab=None):
+    """Sampling path — trainer.py:44-90: eval-mode generator renders one full [B,C,16,S,S] clip per latent
+    (no sub-sampling, last level only); real and generated grids (+ captions) are written per batch."""
+    from .samples import save_frames, save_sentences
+    from ..data import DevicePrefetcher
+    ensure_exists(params.out_samples)
+    gan.gen.eval()
+    with torch.no_grad():
+        for i in range(num_samples):
+            pre = DevicePrefetcher(dataset, device)
+            j = 0
+            x, y = pre.next()
+            while x is not None:
+                x = TF.video_to_channel_first(x)
+                cond = None
+                if gan.cond_encoder is not None and len(y) >= 2:
+                    _, _, cond = gan.cond_encoder.encode(y[0], y[1])
+                z = torch.randn(x.size(0), gan.gen.latent_size).to(device)
+                fake = gan(z, cond=cond)
+                save_frames(x, '%s/real_%d_%d.png' % (params.out_samples, i, j))
+                save_frames(fake[-1], '%s/fake_%d_%d.png' % (params.out_samples, i, j))
+                if cond is not None and vocab is not None:
+                    save_sentences(y[0], path='%s/sentences_%d_%d.txt' % (params.out_samples, i, j), vocab=vocab)
+                x, y = pre.next()
+                j += 1
+    gan.gen.train()
+
+
 def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=None, params=None, vocab=None, losses=None,
           channel_first=True, end2end=True, grad_sync=None, max_iters=None):
     """txt2vid/gan/trainer.py:111-333. `dataset` yields (videos [B,T,C,H,W], tokens, lengths) batches

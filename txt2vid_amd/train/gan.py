@@ -1,0 +1,144 @@
+"""CLI entry of the TGANv2 hot path — flag-for-flag txt2vid/train/gan.py:28-221 (+ trainer.py:15-42), so
+`scripts/run_tganv2*.sh` / `config/*.json` drive this build. One process per GPU: launched under
+`torch.distributed.run` it trains data-parallel over RCCL (the reference's `--ngpu` was never read).
+
+    python -m txt2vid_amd.train.gan --data config/synth.json --G txt2vid.models.tganv2.gen.MultiScaleGen ...
+"""
+import argparse
+import os
+
+import torch
+
+from .. import data
+from ..gan.cond_gan import CondGan
+from ..gan.losses import MixedGanLoss
+from ..gan.trainer import add_params_to_parser, train, test
+from ..optim import Adam
+from ..util.log import status
+from ..util.pick import load
+from ..util.reflection import create_object
+from ..util.torch.init import init
+from .setup import setup
+
+
+def _model(spec, args, **kw):
+    """`create_object(spec, cond_dim=...)` like the reference; convenience: a bare class name also gets
+    `num_channels=--num_channels` (the reference needs a JSON spec for anything but its 3-channel default)."""
+    if isinstance(spec, str) and not os.path.exists(spec):
+        kw.setdefault('num_channels', args.num_channels)
+    return create_object(spec, **kw)
+
+
+def main(args):
+    from .. import dist as tdist
+    rank, world = tdist.init_from_env('nccl')
+    seed, device = setup(args)
+    status('%d cuda devices available; rank %d of %d' % (torch.cuda.device_count(), rank, world))
+    vocab = load(args.vocab) if args.vocab else data.Vocab()
+    txt_encoder = None
+    if not args.dont_use_sent:
+        if args.sent_weights:
+            txt_encoder = torch.load(args.sent_weights, weights_only=False)
+            if isinstance(txt_encoder, dict) and 'txt' in txt_encoder:
+                txt_encoder = txt_encoder['txt']
+            txt_encoder = txt_encoder.to(device)
+        else:
+            txt_encoder = create_object(args.sent, vocab_size=len(vocab)).to(device)
+            init(txt_encoder, init_method=args.sent_init_method or args.init_method)
+    cond_dim = txt_encoder.encoder.encoding_size if txt_encoder is not None else 0
+    gen = _model(args.G, args, cond_dim=cond_dim)
+    discrims = [_model(d, args, cond_dim=cond_dim) for d in args.D]
+    init(gen, init_method=args.init_method)
+    for d in discrims:
+        init(d, init_method=args.init_method)
+    gen.to(device)
+    discrims = [d.to(device) for d in discrims]
+    if args.M:
+        raise NotImplementedError('--M sample mappings (TCWYT baseline) are outside the hot path')
+    if args.sgd:
+        raise NotImplementedError('--sgd is outside the hot path (canonical runs use Adam)')
+    D_params = [{'params': d.parameters()} for d in discrims]
+    G_params = [{'params': gen.parameters()}]
+    if args.end2end and txt_encoder is not None:
+        raise NotImplementedError('--end2end (training the text encoder through the GAN) is not built yet')
+    optD = Adam(D_params, lr=args.D_lr, betas=(args.D_beta1, args.D_beta2))
+    optG = Adam(G_params, lr=args.G_lr, betas=(args.G_beta1, args.G_beta2))
+    gan = CondGan(gen=gen, discrims=discrims, cond_encoder=txt_encoder, discrim_names=args.D_names,
+                  discrim_lambdas=args.D_lambdas, gp_scale=float(world))
+    if args.weights is not None:
+        to_load = torch.load(args.weights, map_location=device, weights_only=False)
+        gan.load_from_dict(to_load)
+        if 'optD' in to_load:
+            optD.load_state_dict(to_load['optD'])
+        if 'optG' in to_load:
+            optG.load_state_dict(to_load['optG'])
+        del to_load
+    dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=None, size=args.frame_sizes[-1],
+                         channels=args.num_channels, seed=(args.seed or 0) + rank)
+    dataset = data.get_loader(dset=dset, batch_size=args.batch_size, val=False, num_workers=args.workers)
+    status('GAN has %d parameters' % gan.count_params())
+    if args.G_loss is None:
+        args.G_loss = args.D_loss
+    losses = MixedGanLoss(g_loss=create_object(args.G_loss), d_loss=create_object(args.D_loss))
+    grad_sync = None
+    if world > 1:
+        from .. import functional as TF
+        arenas = {'D': tdist.GradArena([p for d in discrims for p in d.parameters()], TF.copy_into),
+                  'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
+        grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
+    if args.test:
+        test(gan=gan, num_samples=args.num_samples, dataset=dataset, device=device, params=args,
+             channel_first=not args.sequence_first, vocab=vocab)
+    else:
+        train(gan=gan, num_epoch=args.epochs, dataset=dataset, device=device, optD=optD, optG=optG, params=args,
+              losses=losses, vocab=vocab, channel_first=not args.sequence_first, end2end=args.end2end,
+              grad_sync=grad_sync, max_iters=args.max_iters)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    add_params_to_parser(p)
+    p.add_argument('--test', action='store_true')
+    p.add_argument('--num_samples', type=int, default=1)
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--cuda', action='store_true')
+    p.add_argument('--workers', type=int, default=2)
+    p.add_argument('--ngpu', type=int, default=1)
+    p.add_argument('--frame_sizes', type=int, nargs='+', default=[64])
+    p.add_argument('--num_channels', type=int, default=1)
+    p.add_argument('--random_frames', type=int, default=0)
+    p.add_argument('--opt_level', type=str, default='O2')
+    p.add_argument('--epochs', type=int, default=5)
+    p.add_argument('--batch_size', type=int, default=64)
+    p.add_argument('--init_method', type=str, default='xavier')
+    p.add_argument('--G_loss', type=str, default=None)
+    p.add_argument('--G_lr', type=float, default=0.0001)
+    p.add_argument('--G_beta1', type=float, default=0.5)
+    p.add_argument('--G_beta2', type=float, default=0.9)
+    p.add_argument('--D_loss', type=str, default='txt2vid.gan.losses.VanillaGanLoss')
+    p.add_argument('--D_lr', type=float, default=0.0001)
+    p.add_argument('--D_beta1', type=float, default=0.5)
+    p.add_argument('--D_beta2', type=float, default=0.9)
+    p.add_argument('--weights', type=str, default=None)
+    p.add_argument('--sent_weights', type=str, default=None)
+    p.add_argument('--data', type=str, required=True)
+    p.add_argument('--anno', type=str, default=None)
+    p.add_argument('--vocab', type=str, default=None)
+    p.add_argument('--M', type=str, default=None)
+    p.add_argument('--G', type=str, default=None, required=True)
+    p.add_argument('--D', type=str, default=None, nargs='+', required=True)
+    p.add_argument('--D_names', type=str, default=None, nargs='+')
+    p.add_argument('--D_lambdas', type=float, default=None, nargs='+')
+    p.add_argument('--sent', type=str, default=None)
+    p.add_argument('--sent_init_method', type=str, default=None)
+    p.add_argument('--dont_use_sent', action='store_true', default=False)
+    p.add_argument('--end2end', action='store_true', default=False)
+    p.add_argument('--sgd', action='store_true', default=False)
+    p.add_argument('--sequence_first', action='store_true', default=False)
+    p.add_argument('--debug', action='store_true', default=False)
+    p.add_argument('--max_iters', type=int, default=None, help='(new) stop after this many iterations')
+    return p
+
+
+if __name__ == '__main__':
+    main(build_parser().parse_args())
