@@ -39,6 +39,18 @@ typedef struct {
     int8_t pad_[3];
 } t2v_conv_geom;
 
+/* One member of a GROUPED convolution: tensors that share the weights but not the geometry (the pyramid
+ * levels of the multi-scale discriminator, models/tganv2/discrim.py:23-31 forward loop) are convolved by ONE launch.
+ * Tap j of this member has offset (dz,dy,dx)[j] and reads slot widx[j] of the packed weight. */
+#define T2V_MAX_GROUPS 8
+typedef struct {
+    const float* x;      /* input  [N,Cin,D,H,W]                      (wgrad: the layer input)      */
+    float* y;            /* output [N,Cout,D,H,W]                     (wgrad: dL/dy, read only)     */
+    int32_t N, D, H, W;
+    int32_t ntaps;
+    int8_t dz[T2V_MAX_TAPS], dy[T2V_MAX_TAPS], dx[T2V_MAX_TAPS], widx[T2V_MAX_TAPS];
+} t2v_conv_group;
+
 #define T2V_CONV_BIAS 1      /* add bias[Cout] in the epilogue                                   */
 #define T2V_CONV_RELU_IN 2   /* apply max(.,0) to the input while gathering (ReLU->conv fusion)  */
 #define T2V_CONV_ACCUM 4     /* y += result instead of y = result                                */
@@ -65,9 +77,20 @@ int64_t t2v_conv_fwd_ws_floats(const t2v_conv_geom* g);
  * `slab` is a workspace of t2v_conv_wgrad_slab_floats(g, T) floats (split-K partial sums, reduced
  * deterministically by a second kernel).  `taps`: HOST array, original tap index of geom tap j.
  * flags: T2V_CONV_RELU_IN applies max(.,0) to x; T2V_CONV_ACCUM adds into dw. */
-int64_t t2v_conv_wgrad_slab_floats(const t2v_conv_geom* g);
+int64_t t2v_conv_wgrad_slab_floats(const t2v_conv_geom* g, int T);
 int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float* slab, const t2v_conv_geom* g,
                    const int32_t* taps, int T, int flags, void* stream);
+
+/* Grouped forms: one launch for all members (same Cin/Cout/kernel). wp must hold every slot the members
+ * reference. The weight gradient is the SUM over all members (what autograd would otherwise accumulate
+ * level by level); its kernel extent is given explicitly and every live tap is computed. */
+int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout);
+int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp,
+                         const float* bias, float* ws, int flags, void* stream);
+int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
+                                           int kH, int kW);
+int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                           float* dw, float* slab, int flags, void* stream);
 
 /* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
 int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S);   /* floats of `ws` needed (0: none) */

@@ -21,6 +21,14 @@ class ConvGeom(C.Structure):
                 ('pad_', C.c_int8 * 3)]
 
 
+class ConvGroup(C.Structure):
+    """Mirror of `t2v_conv_group` (include/t2v_hip.h)."""
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('N', C.c_int32), ('D', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('ntaps', C.c_int32),
+                ('dz', C.c_int8 * MAX_TAPS), ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS), ('widx', C.c_int8 * MAX_TAPS)]
+
+
+MAX_GROUPS = 8
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -33,7 +41,11 @@ SIGNATURES = {
     't2v_pack_weight': [_P, _P, _I, _I, _I, _I3, _I, _I, _P],
     't2v_conv_fwd': [_P, _P, _P, _P, _P, _G, _I, _P],
     't2v_conv_fwd_ws_floats': [_G],
-    't2v_conv_wgrad_slab_floats': [_G],
+    't2v_conv_wgrad_slab_floats': [_G, _I],
+    't2v_conv_fwd_grouped_ws_floats': [_P, _I, _I, _I],
+    't2v_conv_fwd_grouped': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
+    't2v_conv_wgrad_grouped_slab_floats': [_P, _I, _I, _I, _I, _I, _I],
+    't2v_conv_wgrad_grouped': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     't2v_conv_wgrad': [_P, _P, _P, _P, _G, _I3, _I, _I, _P],
     't2v_channel_sum_ws_floats': [_I, _I, _L],
     't2v_channel_sum': [_P, _P, _P, _I, _I, _L, _I, _P],
@@ -85,7 +97,8 @@ SIGNATURES = {
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
-_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
+_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
+            't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None
 

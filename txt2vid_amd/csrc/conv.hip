@@ -131,7 +131,10 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / dgrad implicit GEMM
+// forward / dgrad implicit GEMM — GROUPED: one launch convolves up to T2V_MAX_GROUPS tensors that share
+// the weights but not the geometry (the 4 pyramid levels of the multi-scale discriminator). A workgroup
+// owns one BM x BN tile of ONE group (looked up from the tile prefix table); everything per-group
+// (pointers, extents, valid taps, packed-weight slot of each tap) comes from the group descriptor.
 //   tile BM (voxels) x BN (output channels), K consumed in chunks of BKT (one tap x BKT channels on the
 //   FAST path), 4 waves, each owning (BN/WAVES_CO) x (BM/WAVES_M) as 32x32 MFMA tiles.
 //   Global -> registers (issued one chunk ahead, right after the barrier) -> LDS -> MFMA.
@@ -140,11 +143,17 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
 //   voxels and K of several thousand (the deep discriminator blocks, the ConvLSTM) are otherwise a
 //   handful of workgroups each walking K serially at memory latency.
 // ------------------------------------------------------------------------------------------------
+struct GroupTable {
+    t2v_conv_group g[T2V_MAX_GROUPS];
+    int32_t tile_start[T2V_MAX_GROUPS + 1];   // first m-tile of each group (prefix sum)
+    int64_t out_start[T2V_MAX_GROUPS + 1];    // first element of each group in the virtual concatenated output
+    int32_t n;
+};
+
 template <int BM, int BN, int WAVES_CO, int BKT, bool FAST, bool VECB>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                         float* __restrict__ slab, const t2v_conv_geom g, const int flags,
-                                                         const int chunks_per_split) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                         const float* __restrict__ bias, float* __restrict__ slab,
+                                                         const int Cin, const int Cout, const int flags, const int nsplit) {
     constexpr int WAVES_M = 4 / WAVES_CO;
     constexpr int WCO = BN / WAVES_CO;      // co extent per wave
     constexpr int WM = BM / WAVES_M;        // m extent per wave
@@ -161,19 +170,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float As[BKT * BM];
     __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
     __shared__ int s_off[T2V_MAX_TAPS];
+    __shared__ int s_widx[T2V_MAX_TAPS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
 
-    const int D = g.D, H = g.H, W = g.W, Cin = g.Cin, Cout = g.Cout;
+    // ---- which group does this m-tile belong to (block-uniform scan of <= 8 entries)
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const float* __restrict__ x = gd.x;
+    const int D = gd.D, H = gd.H, W = gd.W;
     const int HW = H * W, DHW = D * HW;
-    const int M = g.N * DHW;
-    const int m0 = blockIdx.x * BM, co0 = blockIdx.y * BN;
-    const int ntaps = g.ntaps;
+    const int M = gd.N * DHW;
+    const int m0 = ((int)blockIdx.x - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
 
-    if (tid < ntaps) s_off[tid] = g.dz[tid] * HW + g.dy[tid] * W + g.dx[tid];
+    if (tid < ntaps) {
+        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        s_widx[tid] = gd.widx[tid];
+    }
 
     // ---- per-thread gather coordinates (fixed m for the whole K loop)
     const int ma_l = tid % BM, ka_l = tid / BM;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
         int h = r / W, w_ = r - h * W;
         xbase = (size_t)n * Cin * DHW + sp;
         for (int t = 0; t < ntaps; ++t) {
-            int dd = d + g.dz[t], hh = h + g.dy[t], ww = w_ + g.dx[t];
+            int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
             if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) tapmask |= 1u << t;
         }
     }
@@ -209,10 +229,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     float4 rbv[VECB ? LBV : 1];
     const int Ktot = ntaps * Cin;
     const int nchunks = FAST ? ntaps * (Cin / BKT) : (Ktot + BKT - 1) / BKT;
-    const int q0 = blockIdx.z * chunks_per_split;
-    int q1 = q0 + chunks_per_split;
+    const int cps = (nchunks + nsplit - 1) / nsplit;          // this group's chunks per split
+    const int q0 = blockIdx.z * cps;
+    int q1 = q0 + cps;
     if (q1 > nchunks) q1 = nchunks;
-    __syncthreads();   // s_off visible
+    __syncthreads();   // s_off / s_widx visible
 
     auto load_chunk = [&](int q, int t, int c0) {
         if (FAST) {
@@ -224,12 +245,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
                 ra[j] = relu_in ? fmaxf(val, 0.f) : val;
             }
             if (VECB) {
-                const float* pw = wp + ((size_t)t * Cin + c0 + kv_l) * Cout + co0 + cv_l;
+                const float* pw = wp + ((size_t)s_widx[t] * Cin + c0 + kv_l) * Cout + co0 + cv_l;
 #pragma unroll
                 for (int j = 0; j < LBV; ++j)
                     rbv[j] = co_ok ? *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                const float* pw = wp + ((size_t)t * Cin + c0 + kb_l) * Cout + co0 + cob_l;
+                const float* pw = wp + ((size_t)s_widx[t] * Cin + c0 + kb_l) * Cout + co0 + cob_l;
 #pragma unroll
                 for (int j = 0; j < LB; ++j) rb[j] = co_ok ? pw[(size_t)j * KSB * Cout] : 0.f;
             }
@@ -247,7 +268,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
                 int kk = q * BKT + kb_l + j * KSB;
-                rb[j] = (co_ok && kk < Ktot) ? wp[(size_t)kk * Cout + co0 + cob_l] : 0.f;
+                float val = 0.f;
+                if (co_ok && kk < Ktot) {
+                    int tt = kk / Cin, ci = kk - tt * Cin;
+                    val = wp[((size_t)s_widx[tt] * Cin + ci) * Cout + co0 + cob_l];
+                }
+                rb[j] = val;
             }
         }
     };
@@ -296,10 +322,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     }
 
     // ---- epilogue: rows (registers) = co, columns (lanes) = m
-    const bool split = gridDim.z > 1;
+    const bool split = nsplit > 1;
     const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
     const bool accum = !split && (flags & T2V_CONV_ACCUM);
-    float* out = split ? slab + (size_t)blockIdx.z * ((size_t)M * Cout) : y;
+    float* out = split ? slab + (size_t)blockIdx.z * (size_t)tab.out_start[tab.n] + (size_t)tab.out_start[gi] : gd.y;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
         const int m = m0 + wm * WM + j * 32 + l31;
@@ -322,156 +348,232 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     }
 }
 
-// y = (accum ? y : 0) + bias[co] + sum_s slab[s]   (fixed summation order)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
-                                                            float* __restrict__ y, long total, int S, int Cout, int DHW, int flags) {
+// y_g = (accum ? y_g : 0) + bias[co] + sum_s slab[s]   (fixed summation order), for every group
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GroupTable tab, const float* __restrict__ slab,
+                                                            const float* __restrict__ bias, int S, int Cout, int flags) {
     const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
     const bool accum = flags & T2V_CONV_ACCUM;
+    const long total = tab.out_start[tab.n];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && i >= tab.out_start[k]) gi = k;
+        const long li = i - tab.out_start[gi];
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + i];
-        if (has_bias) v += bias[(i / DHW) % Cout];
-        y[i] = accum ? y[i] + v : v;
+        if (has_bias) {
+            const int DHW = tab.g[gi].D * tab.g[gi].H * tab.g[gi].W;
+            v += bias[(li / DHW) % Cout];
+        }
+        float* y = tab.g[gi].y;
+        y[li] = accum ? y[li] + v : v;
     }
 }
 
-struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S, cps; long tiles; };
+struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; };
 
-static ConvPlan conv_plan(const t2v_conv_geom& g) {
-    ConvPlan p;
-    const long M = (long)g.N * g.D * g.H * g.W;
-    p.bk = (g.Cin % 64 == 0) ? 64 : (g.Cin % 32 == 0) ? 32 : 16;
-    p.fast = (g.Cin % 16 == 0);
-    p.vecb = (g.Cout % 4 == 0);
-    if (g.Cout <= 32) { p.bm = 128; p.bn = 32; if (p.bk > 32) p.bk = 32; }
-    else {
-        p.bn = 64;
-        const long t128 = ((M + 127) / 128) * ((g.Cout + 63) / 64);
-        p.bm = (t128 >= 768) ? 128 : 64;
-        if (p.bm == 128 && p.bk > 32) p.bk = 32;
-    }
-    p.tiles = ((M + p.bm - 1) / p.bm) * ((g.Cout + p.bn - 1) / p.bn);
-    const long K = (long)g.ntaps * g.Cin;
-    const long nchunks = p.fast ? (long)g.ntaps * (g.Cin / p.bk) : (K + p.bk - 1) / p.bk;
-    long S = 1;
-    if (p.tiles < 384) {
-        S = (768 + p.tiles - 1) / p.tiles;
-        long maxS = nchunks / 2;                       // >= 2 chunks per split
-        if (S > maxS) S = maxS;
-        if (S > 64) S = 64;
-        while (S > 1 && (double)S * M * g.Cout * 4.0 > 256e6) --S;   // keep the slab small (L2/MALL resident)
-        if (S < 1) S = 1;
-    }
-    p.cps = (int)((nchunks + S - 1) / S);
-    p.S = (int)((nchunks + p.cps - 1) / p.cps);
-    return p;
-}
-
-template <int BM, int BN, int WAVES_CO, int BKT>
-static void launch_conv_t(const float* x, const float* wp, const float* bias, float* y, float* slab, const t2v_conv_geom& g,
-                          int flags, const ConvPlan& p, hipStream_t s) {
-    const long M = (long)g.N * g.D * g.H * g.W;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((g.Cout + BN - 1) / BN), (unsigned)p.S);
-    if (p.fast) {
-        if (p.vecb) T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
-        else T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
-    } else {
-        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, x, wp, bias, y, slab, g, flags, p.cps);
-    }
-}
-
-static bool geom_ok(const t2v_conv_geom* g) {
-    if (!g) return false;
-    if (g->N < 1 || g->Cin < 1 || g->Cout < 1 || g->D < 1 || g->H < 1 || g->W < 1) return false;
-    if (g->ntaps < 1 || g->ntaps > T2V_MAX_TAPS) return false;
-    long M = (long)g->N * g->D * g->H * g->W;
-    if (M * (long)(g->Cin > g->Cout ? g->Cin : g->Cout) >= (1L << 31)) return false;   // 32-bit voxel indices
-    for (int t = 0; t < g->ntaps; ++t) {
-        if (g->dz[t] < -1 || g->dz[t] > 1 || g->dy[t] < -1 || g->dy[t] > 1 || g->dx[t] < -1 || g->dx[t] > 1) return false;
+static bool group_ok(const t2v_conv_group& g, bool need_ptrs) {
+    if (need_ptrs && (!g.x || !g.y)) return false;
+    if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.ntaps < 1 || g.ntaps > T2V_MAX_TAPS) return false;
+    for (int t = 0; t < g.ntaps; ++t) {
+        if (g.dz[t] < -1 || g.dz[t] > 1 || g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+        if (g.widx[t] < 0 || g.widx[t] >= T2V_MAX_TAPS) return false;
     }
     return true;
 }
 
-extern "C" int64_t t2v_conv_fwd_ws_floats(const t2v_conv_geom* g) {
-    if (!geom_ok(g)) return T2V_EINVAL;
-    ConvPlan p = conv_plan(*g);
-    if (p.S <= 1) return 0;
-    return (int64_t)p.S * g->N * g->D * g->H * g->W * g->Cout;
+static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, bool need_ptrs, GroupTable& tab,
+                        ConvPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
+    long Mtot = 0, Mmax = 0;
+    int min_chunk_taps = T2V_MAX_TAPS;
+    for (int i = 0; i < ngroups; ++i) {
+        if (!group_ok(groups[i], need_ptrs)) return false;
+        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;     // 32-bit voxel indices
+        Mtot += M;
+        if (M > Mmax) Mmax = M;
+        if (groups[i].ntaps < min_chunk_taps) min_chunk_taps = groups[i].ntaps;
+    }
+    p.bk = (Cin % 64 == 0) ? 64 : (Cin % 32 == 0) ? 32 : 16;
+    p.fast = (Cin % 16 == 0);
+    p.vecb = (Cout % 4 == 0);
+    if (Cout <= 32) { p.bm = 128; p.bn = 32; if (p.bk > 32) p.bk = 32; }
+    else {
+        p.bn = 64;
+        const long t128 = ((Mtot + 127) / 128) * ((Cout + 63) / 64);
+        p.bm = (t128 >= 768) ? 128 : 64;
+        if (p.bm == 128 && p.bk > 32) p.bk = 32;
+    }
+    if (!p.fast) p.bk = 16;
+    long mt = 0, ot = 0;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        tab.g[i] = groups[i];
+        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        tab.tile_start[i] = (int32_t)mt;
+        tab.out_start[i] = ot;
+        mt += (M + p.bm - 1) / p.bm;
+        ot += M * Cout;
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) { tab.tile_start[i] = (int32_t)mt; tab.out_start[i] = ot; }
+    tab.tile_start[ngroups] = (int32_t)mt;
+    tab.out_start[ngroups] = ot;
+    p.tiles = mt * ((Cout + p.bn - 1) / p.bn);
+    // split-K: every group must keep >= 2 chunks per split
+    const long min_chunks = p.fast ? (long)min_chunk_taps * (Cin / p.bk) : ((long)min_chunk_taps * Cin + p.bk - 1) / p.bk;
+    long S = 1;
+    if (p.tiles < 384) {
+        S = (768 + p.tiles - 1) / p.tiles;
+        long maxS = min_chunks / 2;
+        if (S > maxS) S = maxS;
+        if (S > 64) S = 64;
+        while (S > 1 && (double)S * ot * 4.0 > 256e6) --S;   // keep the slab small (L2 / MALL resident)
+        if (S < 1) S = 1;
+    }
+    p.S = (int)S;
+    return true;
 }
 
-extern "C" int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, float* ws, const t2v_conv_geom* g,
-                            int flags, void* stream) {
-    if (!x || !wp || !y || !geom_ok(g)) return T2V_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const ConvPlan p = conv_plan(*g);
+template <int BM, int BN, int WAVES_CO, int BKT>
+static void launch_conv_t(const GroupTable& tab, const float* wp, const float* bias, float* slab, int Cin, int Cout, int flags,
+                          const ConvPlan& p, hipStream_t s) {
+    dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
+    if (p.fast) {
+        if (p.vecb) T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        else T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+    } else {
+        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+    }
+}
+
+extern "C" int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout) {
+    GroupTable tab;
+    ConvPlan p;
+    if (!build_table(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    return p.S > 1 ? (int64_t)p.S * tab.out_start[ngroups] : 0;
+}
+
+extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp,
+                                    const float* bias, float* ws, int flags, void* stream) {
+    GroupTable tab;
+    ConvPlan p;
+    if (!wp || !build_table(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
     if (p.S > 1 && !ws) return T2V_EINVAL;
-    const long M = (long)g->N * g->D * g->H * g->W;
-    {
-        ProfScope prof(0, 2.0 * (double)M * g->Cout * g->Cin * g->ntaps, s);      // executed (non-padding-tap) MACs x 2
-        const int bk = p.fast ? p.bk : 16;
-        if (p.bn == 32) {
-            if (bk == 32) launch_conv_t<128, 32, 1, 32>(x, wp, bias, y, ws, *g, flags, p, s);
-            else launch_conv_t<128, 32, 1, 16>(x, wp, bias, y, ws, *g, flags, p, s);
-        } else if (p.bm == 128) {
-            if (bk == 32) launch_conv_t<128, 64, 2, 32>(x, wp, bias, y, ws, *g, flags, p, s);
-            else launch_conv_t<128, 64, 2, 16>(x, wp, bias, y, ws, *g, flags, p, s);
-        } else {
-            if (bk == 64) launch_conv_t<64, 64, 2, 64>(x, wp, bias, y, ws, *g, flags, p, s);
-            else if (bk == 32) launch_conv_t<64, 64, 2, 32>(x, wp, bias, y, ws, *g, flags, p, s);
-            else launch_conv_t<64, 64, 2, 16>(x, wp, bias, y, ws, *g, flags, p, s);
-        }
-        int st = launch_status();
-        if (st) return st;
-        if (p.S > 1) {
-            const long total = M * g->Cout;
-            long blocks = (total + 255) / 256;
-            if (blocks > 2048) blocks = 2048;
-            T2V_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, bias, y, total, p.S, g->Cout,
-                       g->D * g->H * g->W, flags);
-        }
+    hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    for (int i = 0; i < ngroups; ++i)
+        flops += 2.0 * (double)groups[i].N * groups[i].D * groups[i].H * groups[i].W * Cout * Cin * groups[i].ntaps;
+    ProfScope prof(0, flops, s);      // executed (non-padding-tap) MACs x 2
+    const int bk = p.bk;
+    if (p.bn == 32) {
+        if (bk == 32) launch_conv_t<128, 32, 1, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+        else launch_conv_t<128, 32, 1, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+    } else if (p.bm == 128) {
+        if (bk == 32) launch_conv_t<128, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+        else launch_conv_t<128, 64, 2, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+    } else {
+        if (bk == 64) launch_conv_t<64, 64, 2, 64>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+        else if (bk == 32) launch_conv_t<64, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+        else launch_conv_t<64, 64, 2, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+    }
+    int st = launch_status();
+    if (st) return st;
+    if (p.S > 1) {
+        long blocks = (tab.out_start[ngroups] + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        T2V_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
     }
     return launch_status();
 }
 
+// single-tensor entry points: a group of one whose tap j sits in packed slot j
+static bool geom_ok(const t2v_conv_geom* g) {
+    if (!g) return false;
+    if (g->N < 1 || g->Cin < 1 || g->Cout < 1 || g->D < 1 || g->H < 1 || g->W < 1) return false;
+    if (g->ntaps < 1 || g->ntaps > T2V_MAX_TAPS) return false;
+    return true;
+}
+static t2v_conv_group group_of(const t2v_conv_geom* g, const float* x, float* y) {
+    t2v_conv_group q;
+    q.x = x; q.y = y;
+    q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps;
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) {
+        q.dz[t] = t < g->ntaps ? g->dz[t] : 0; q.dy[t] = t < g->ntaps ? g->dy[t] : 0; q.dx[t] = t < g->ntaps ? g->dx[t] : 0;
+        q.widx[t] = (int8_t)(t < g->ntaps ? t : 0);
+    }
+    return q;
+}
+extern "C" int64_t t2v_conv_fwd_ws_floats(const t2v_conv_geom* g) {
+    if (!geom_ok(g)) return T2V_EINVAL;
+    t2v_conv_group q = group_of(g, nullptr, nullptr);
+    return t2v_conv_fwd_grouped_ws_floats(&q, 1, g->Cin, g->Cout);
+}
+extern "C" int t2v_conv_fwd(const float* x, const float* wp, const float* bias, float* y, float* ws, const t2v_conv_geom* g,
+                            int flags, void* stream) {
+    if (!x || !wp || !y || !geom_ok(g)) return T2V_EINVAL;
+    t2v_conv_group q = group_of(g, x, y);
+    return t2v_conv_fwd_grouped(&q, 1, g->Cin, g->Cout, wp, bias, ws, flags, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
-// weight gradient: per (tap, co-tile, ci-tile, k-split) a 64x64 tile of dW over a range of voxels
+// weight gradient (GROUPED): dW[co][ci][t] = sum over all groups and their voxels of gy * x_shift.
+// Per (original tap t, co-tile, ci-tile, k-split) a 64x64 tile of dW over a range of 32-voxel chunks of
+// the concatenated chunk list of all groups; groups for which tap t only touches padding are skipped.
 // ------------------------------------------------------------------------------------------------
 #define WG_BK 32
 #define WG_PITCH (WG_BK + 1)
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                         float* __restrict__ slab, const t2v_conv_geom g,
-                                                         const int flags, const int chunks_per_split) {
+struct WGroupTable {
+    t2v_conv_group g[T2V_MAX_GROUPS];          // x = layer input, y = dL/dy (read only here)
+    int32_t chunk_start[T2V_MAX_GROUPS + 1];   // prefix sum of ceil(M_g / 32)
+    int32_t n;
+};
+
+struct LiveTaps { int8_t t[T2V_MAX_TAPS]; int32_t n; };   // slab slot j -> original tap index
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                         const int Cout, const int T, const int kH, const int kW,
+                                                         const int flags, const int chunks_per_split, const LiveTaps live) {
     __shared__ float As[64 * WG_PITCH];   // gy^T tile  [co][m]
     __shared__ float Bs[64 * WG_PITCH];   // x   tile   [ci][m]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave & 1, wci = wave >> 1;
-    const int D = g.D, H = g.H, W = g.W, Cin = g.Cin, Cout = g.Cout;
-    const int HW = H * W, DHW = D * HW, M = g.N * DHW;
     const int nco_t = (Cout + 63) / 64;
     const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
-    const int j = blockIdx.y;           // geometry tap
+    const int t = live.t[blockIdx.y];   // ORIGINAL tap index of slab slot blockIdx.y
     const int split = blockIdx.z;
-    const int dz = g.dz[j], dy = g.dy[j], dx = g.dx[j];
-    const int off = dz * HW + dy * W + dx;
     const bool relu_in = flags & T2V_CONV_RELU_IN;
+    // offset of original tap t (k in {1,3} per dim, centred)
+    const int kD = T / (kH * kW);
+    const int ta = t / (kH * kW), tb = (t / kW) % kH, tc = t % kW;
+    const int dz = ta - kD / 2, dy = tb - kH / 2, dx = tc - kW / 2;
 
     const int ml = tid & 31, rl = tid >> 5;     // 32 m x 8 rows per pass, 8 passes -> 64 rows
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    const int nchunks = (M + WG_BK - 1) / WG_BK;
+    const int nchunks = tab.chunk_start[tab.n];
     const int q0 = split * chunks_per_split;
     int q1 = q0 + chunks_per_split;
     if (q1 > nchunks) q1 = nchunks;
 
     float ra[8], rb[8];
     auto load_chunk = [&](int q) {
-        const int m = q * WG_BK + ml;
-        bool mv = m < M, xv = false;
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+        // a dim of extent 1 keeps its centre tap only (same rule as the forward)
+        const bool tap_live = !((D == 1 && dz) || (H == 1 && dy) || (W == 1 && dx));
+        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
+        bool mv = tap_live && m < M, xv = false;
         size_t gbase = 0, xb = 0;
         if (mv) {
             int n = m / DHW, sp = m - n * DHW;
@@ -480,12 +582,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             gbase = (size_t)n * Cout * DHW + sp;
             int dd = d + dz, hh = h + dy, ww = w_ + dx;
             xv = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            xb = (size_t)n * Cin * DHW + sp + (ptrdiff_t)off;
+            xb = (size_t)n * Cin * DHW + sp + (ptrdiff_t)(dz * HW + dy * W + dx);
         }
+        const float* __restrict__ gy = gd.y;
+        const float* __restrict__ x = gd.x;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
-            ra[p] = (mv && co < Cout) ? gy[gbase + (size_t)co * DHW] : 0.f;
+            ra[p] = (mv && xv && co < Cout) ? gy[gbase + (size_t)co * DHW] : 0.f;
             float v = (xv && ci < Cin) ? x[xb + (size_t)ci * DHW] : 0.f;
             rb[p] = relu_in ? fmaxf(v, 0.f) : v;
         }
@@ -509,10 +613,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         }
         __syncthreads();
     }
-    // slab[((split*ntaps + j)*Cout + co)*Cin + ci]; rows = co (registers), cols = ci (lanes)
+    // slab[((split*nlive + slot)*Cout + co)*Cin + ci]; rows = co (registers), cols = ci (lanes)
     const int ci = ci0 + wci * 32 + l31;
     if (ci < Cin) {
-        float* ps = slab + ((size_t)split * g.ntaps + j) * Cout * Cin + ci;
+        float* ps = slab + ((size_t)split * live.n + blockIdx.y) * Cout * Cin + ci;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -521,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
-struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> geometry tap j or -1
+struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
 
 // dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
 // lane-contiguous along (co,ci); the [i][t] transposition goes through LDS so that the PyTorch-layout
@@ -555,49 +659,114 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (long k = threadIdx.x; k < nval; k += 256) p[k] = accum ? p[k] + tile[k] : tile[k];
 }
 
-static int wgrad_splits(const t2v_conv_geom* g) {
-    const long M = (long)g->N * g->D * g->H * g->W;
-    const long nchunks = (M + WG_BK - 1) / WG_BK;
-    const long base = (long)((g->Cout + 63) / 64) * ((g->Cin + 63) / 64) * g->ntaps;
+struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; };
+
+static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, bool need_ptrs,
+                         WGroupTable& tab, WgradPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
+    if ((kD != 1 && kD != 3) || (kH != 1 && kH != 3) || (kW != 1 && kW != 3)) return false;
+    long nch = 0;
+    p.live = 0;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        const t2v_conv_group& g = groups[i];
+        if (need_ptrs && (!g.x || !g.y)) return false;
+        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1) return false;
+        const long M = (long)g.N * g.D * g.H * g.W;
+        if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;
+        tab.g[i] = g;
+        tab.chunk_start[i] = (int32_t)nch;
+        nch += (M + WG_BK - 1) / WG_BK;
+        for (int a = 0; a < kD; ++a) for (int b = 0; b < kH; ++b) for (int c = 0; c < kW; ++c) {
+            const int dz = a - kD / 2, dy = b - kH / 2, dx = c - kW / 2;
+            if (!((g.D == 1 && dz) || (g.H == 1 && dy) || (g.W == 1 && dx))) p.live |= 1u << ((a * kH + b) * kW + c);
+        }
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.chunk_start[i] = (int32_t)nch;
+    p.nchunks = nch;
+    p.nlive = __builtin_popcount(p.live);
+    const long base = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
     long S = (1536 + base - 1) / base;            // aim at ~6 workgroups per CU
-    long maxS = (nchunks + 7) / 8;                // at least 8 chunks (256 voxels) per split
+    long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     if (S > 256) S = 256;
-    return (int)S;
+    p.cps = (int)((nch + S - 1) / S);
+    p.S = (int)((nch + p.cps - 1) / p.cps);
+    return true;
 }
 
-extern "C" int64_t t2v_conv_wgrad_slab_floats(const t2v_conv_geom* g) {
-    if (!geom_ok(g)) return T2V_EINVAL;
-    return (int64_t)wgrad_splits(g) * g->ntaps * g->Cout * g->Cin;
+extern "C" int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
+                                                      int kH, int kW) {
+    WGroupTable tab;
+    WgradPlan p;
+    if (!build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
+    return (int64_t)p.S * p.nlive * Cout * Cin;
 }
 
-extern "C" int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float* slab, const t2v_conv_geom* g,
-                              const int32_t* taps, int T, int flags, void* stream) {
-    if (!x || !gy || !dw || !slab || !geom_ok(g) || !taps || T < g->ntaps || T > T2V_MAX_TAPS) return T2V_EINVAL;
+extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                                      float* dw, float* slab, int flags, void* stream) {
+    WGroupTable tab;
+    WgradPlan p;
+    if (!dw || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const int T = kD * kH * kW;
     TapMap map;
-    for (int t = 0; t < T2V_MAX_TAPS; ++t) map.j[t] = -1;
-    for (int j = 0; j < g->ntaps; ++j) {
-        if (taps[j] < 0 || taps[j] >= T) return T2V_EINVAL;
-        map.j[taps[j]] = j;
+    LiveTaps live;
+    live.n = 0;
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) {
+        live.t[t] = 0;
+        map.j[t] = -1;
     }
-    const long M = (long)g->N * g->D * g->H * g->W;
-    const int S = wgrad_splits(g);
-    const long nchunks = (M + WG_BK - 1) / WG_BK;
-    const int cps = (int)((nchunks + S - 1) / S);
-    dim3 grid((unsigned)(((g->Cout + 63) / 64) * ((g->Cin + 63) / 64)), (unsigned)g->ntaps, (unsigned)S);
+    for (int t = 0; t < T; ++t)
+        if ((p.live >> t) & 1u) { map.j[t] = live.n; live.t[live.n++] = (int8_t)t; }
+    double flops = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        int live_g = 0;
+        for (int a = 0; a < kD; ++a) for (int b = 0; b < kH; ++b) for (int c = 0; c < kW; ++c) {
+            const int dz = a - kD / 2, dy = b - kH / 2, dx = c - kW / 2;
+            if (!((groups[i].D == 1 && dz) || (groups[i].H == 1 && dy) || (groups[i].W == 1 && dx))) ++live_g;
+        }
+        flops += 2.0 * (double)groups[i].N * groups[i].D * groups[i].H * groups[i].W * Cout * Cin * live_g;
+    }
+    // grid.y runs over the taps at least one member can touch; the others are written as zeros by the reduce
     {
-        ProfScope prof(1, 2.0 * (double)M * g->Cout * g->Cin * g->ntaps, s);
-        T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, x, gy, slab, *g, flags, cps);
+        ProfScope prof(1, flops, s);
+        dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
+        T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
     }
     int st = launch_status();
     if (st) return st;
-    const long CoCi = (long)g->Cout * g->Cin;
+    const long CoCi = (long)Cout * Cin;
     ProfScope prof2(2, 0.0, s);
-    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T,
-                       g->ntaps, S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
+    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
+               (flags & T2V_CONV_ACCUM) ? 1 : 0);
     return launch_status();
+}
+
+// single-tensor entry points
+static void kernel_extent(const t2v_conv_geom* g, int T, int& kD, int& kH, int& kW) {
+    // T in {1, 3, 9, 27} with the singleton dims leading (Linear: 1, 2-D 3x3: 9 = 1x3x3, 3-D: 27)
+    kD = (T == 27) ? 3 : 1;
+    kH = (T >= 9) ? 3 : 1;
+    kW = (T >= 3) ? 3 : 1;
+    (void)g;
+}
+extern "C" int64_t t2v_conv_wgrad_slab_floats(const t2v_conv_geom* g, int T) {
+    if (!geom_ok(g) || (T != 1 && T != 3 && T != 9 && T != 27)) return T2V_EINVAL;
+    t2v_conv_group q = group_of(g, nullptr, nullptr);
+    int kD, kH, kW;
+    kernel_extent(g, T, kD, kH, kW);
+    return t2v_conv_wgrad_grouped_slab_floats(&q, 1, g->Cin, g->Cout, kD, kH, kW);
+}
+extern "C" int t2v_conv_wgrad(const float* x, const float* gy, float* dw, float* slab, const t2v_conv_geom* g,
+                              const int32_t* taps, int T, int flags, void* stream) {
+    if (!x || !gy || !dw || !slab || !geom_ok(g) || (T != 1 && T != 3 && T != 9 && T != 27)) return T2V_EINVAL;
+    (void)taps;
+    t2v_conv_group q = group_of(g, x, const_cast<float*>(gy));
+    int kD, kH, kW;
+    kernel_extent(g, T, kD, kH, kW);
+    return t2v_conv_wgrad_grouped(&q, 1, g->Cin, g->Cout, kD, kH, kW, dw, slab, flags, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

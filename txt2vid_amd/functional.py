@@ -17,7 +17,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import lib, check, ConvGeom, MAX_TAPS
+from ._lib import lib, check, ConvGeom, ConvGroup, MAX_TAPS, MAX_GROUPS
 
 FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM = 1, 2, 4
 
@@ -213,7 +213,7 @@ def conv_dgrad_raw(gy5, w5, out=None, accum=False):
 def conv_wgrad_raw(x5, gy5, wshape, relu_in=False):
     x5, gy5 = _c(x5), _c(gy5)
     g = conv_geom(x5.shape[0], wshape[1], x5.shape[2], x5.shape[3], x5.shape[4], wshape[0], wshape[2], wshape[3], wshape[4])
-    n = lib().t2v_conv_wgrad_slab_floats(C.byref(g.cg))
+    n = lib().t2v_conv_wgrad_slab_floats(C.byref(g.cg), g.T)
     if n <= 0:
         raise RuntimeError('bad wgrad geometry')
     slab = torch.empty((n,), device=x5.device, dtype=torch.float32)
@@ -1436,3 +1436,200 @@ draws = HostDraws()
 def set_draws(d):
     global draws
     draws = d
+
+
+# ------------------------------------------------------------------------------------------------
+# GROUPED convolutions: the pyramid levels of the multi-scale discriminator share weights, so each layer
+# is ONE launch over all levels (and one weight-gradient launch whose result is already the sum over
+# levels — no per-level accumulation). Closed under differentiation like the single-tensor triple.
+# ------------------------------------------------------------------------------------------------
+
+class _TapSet(object):
+    """Stands in for a geometry when packing the union of the taps a group of levels needs."""
+    __slots__ = ('taps', 'taps_c', 'T', 'mask')
+
+
+_tapset_cache = {}
+
+
+def _tapset(T, mask):
+    key = (T, mask)
+    ts = _tapset_cache.get(key)
+    if ts is None:
+        ts = _TapSet()
+        ts.taps = [t for t in range(T) if (mask >> t) & 1]
+        ts.taps_c = (C.c_int32 * len(ts.taps))(*ts.taps)
+        ts.T, ts.mask = T, mask
+        _tapset_cache[key] = ts
+    return ts
+
+
+def _group_table(ins, outs, geoms, slot_of):
+    arr = (ConvGroup * len(ins))()
+    for i, (xi, yi, g) in enumerate(zip(ins, outs, geoms)):
+        a = arr[i]
+        a.x, a.y = xi.data_ptr(), (yi.data_ptr() if yi is not None else 0)
+        a.N, a.D, a.H, a.W, a.ntaps = g.cg.N, g.cg.D, g.cg.H, g.cg.W, g.cg.ntaps
+        for j, t in enumerate(g.taps):
+            a.dz[j], a.dy[j], a.dx[j] = g.cg.dz[j], g.cg.dy[j], g.cg.dx[j]
+            a.widx[j] = slot_of[t] if slot_of is not None else 0
+    return arr
+
+
+def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0):
+    """mode 0: ys[i] = conv(xs[i], w) (+bias); mode 1: data gradient (xs are dL/dy, channels swap roles)."""
+    if len(xs5) > MAX_GROUPS:
+        raise ValueError('at most %d tensors per grouped convolution' % MAX_GROUPS)
+    xs5 = [_c(t) for t in xs5]
+    w5 = _c(w5)
+    Cout_w, Cin_w = w5.shape[0], w5.shape[1]
+    cin, cout = (Cin_w, Cout_w) if mode == 0 else (Cout_w, Cin_w)
+    k = tuple(w5.shape[2:])
+    geoms = [conv_geom(t.shape[0], cin, t.shape[2], t.shape[3], t.shape[4], cout, k[0], k[1], k[2]) for t in xs5]
+    mask = 0
+    for g in geoms:
+        mask |= g.mask
+    ts = _tapset(geoms[0].T, mask)
+    wp = packed_weight(w5, ts, mode)
+    slot_of = {t: j for j, t in enumerate(ts.taps)}
+    ys = [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32) for t in xs5]
+    arr = _group_table(xs5, ys, geoms, slot_of)
+    n = int(lib().t2v_conv_fwd_grouped_ws_floats(arr, len(xs5), cin, cout))
+    if n < 0:
+        raise RuntimeError('bad grouped conv geometry')
+    ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
+    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0)
+    check(lib().t2v_conv_fwd_grouped(arr, len(xs5), cin, cout, _p(wp), _p(bias), _p(ws), flags, _stream()), 't2v_conv_fwd_grouped')
+    return ys
+
+
+def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False):
+    xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
+    Cout, Cin = wshape[0], wshape[1]
+    k = tuple(wshape[2:])
+    geoms = [conv_geom(t.shape[0], Cin, t.shape[2], t.shape[3], t.shape[4], Cout, k[0], k[1], k[2]) for t in xs5]
+    arr = _group_table(xs5, gys5, geoms, None)
+    n = int(lib().t2v_conv_wgrad_grouped_slab_floats(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
+    if n <= 0:
+        raise RuntimeError('bad grouped wgrad geometry')
+    slab = torch.empty((n,), device=xs5[0].device, dtype=torch.float32)
+    dw = torch.empty(tuple(wshape), device=xs5[0].device, dtype=torch.float32)
+    check(lib().t2v_conv_wgrad_grouped(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(slab),
+                                       FLAG_RELU_IN if relu_in else 0, _stream()), 't2v_conv_wgrad_grouped')
+    return dw
+
+
+def _zeros_like(t):
+    out = torch.empty_like(t)
+    check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
+    return out
+
+
+class ConvG(Function):
+    """ys = [conv(relu?(x), w) + b for x in xs] in one launch."""
+
+    @staticmethod
+    def forward(ctx, w, b, relu_in, *xs):
+        ctx.save_for_backward(w, *xs)
+        ctx.has_bias, ctx.relu_in = b is not None, relu_in
+        return tuple(conv_group_raw(xs, w, b, relu_in, 0))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        saved = ctx.saved_tensors
+        w, xs = saved[0], saved[1:]
+        gys = [g if g is not None else _zeros_like(conv_out_like(x, w)) for g, x in zip(gys, xs)]
+        gxs = [None] * len(xs)
+        gw = gb = None
+        if any(ctx.needs_input_grad[3:]):
+            gxs = list(ConvDgradG.apply(w, *gys))
+            if ctx.relu_in:
+                gxs = [ReluMask.apply(g, x) for g, x in zip(gxs, xs)]
+        if _param_grads_enabled:
+            if ctx.needs_input_grad[0]:
+                gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(xs), *(list(xs) + list(gys)))
+            if ctx.has_bias and ctx.needs_input_grad[1]:
+                gb = ChannelSumG.apply(*gys)
+        return (gw, gb, None) + tuple(gxs)
+
+
+def conv_out_like(x, w):
+    return torch.empty((x.shape[0], w.shape[0]) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+
+
+class ConvDgradG(Function):
+    @staticmethod
+    def forward(ctx, w, *gys):
+        ctx.save_for_backward(w, *gys)
+        return tuple(conv_group_raw(gys, w, None, False, 1))
+
+    @staticmethod
+    def backward(ctx, *ggxs):
+        saved = ctx.saved_tensors
+        w, gys = saved[0], saved[1:]
+        ggxs = [g if g is not None else _zeros_like(torch.empty((y.shape[0], w.shape[1]) + tuple(y.shape[2:]), device=y.device))
+                for g, y in zip(ggxs, gys)]
+        d_w = None
+        d_gys = [None] * len(gys)
+        if ctx.needs_input_grad[0] and _param_grads_enabled:
+            d_w = ConvWgradG.apply(tuple(w.shape), False, len(gys), *(list(ggxs) + list(gys)))
+        if any(ctx.needs_input_grad[1:]):
+            d_gys = list(ConvG.apply(w, None, False, *ggxs))
+        return (d_w,) + tuple(d_gys)
+
+
+class ConvWgradG(Function):
+    """gw = sum over the group of wgrad(relu?(x_i), gy_i)."""
+
+    @staticmethod
+    def forward(ctx, wshape, relu_in, n, *xs_gys):
+        xs, gys = xs_gys[:n], xs_gys[n:]
+        ctx.save_for_backward(*xs_gys)
+        ctx.cfg = (wshape, relu_in, n)
+        return conv_group_wgrad_raw(xs, gys, wshape, relu_in)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        wshape, relu_in, n = ctx.cfg
+        saved = ctx.saved_tensors
+        xs, gys = saved[:n], saved[n:]
+        d_xs = [None] * n
+        d_gys = [None] * n
+        if any(ctx.needs_input_grad[3:3 + n]):
+            d_xs = list(ConvDgradG.apply(ggw, *gys))
+            if relu_in:
+                d_xs = [ReluMask.apply(g, x) for g, x in zip(d_xs, xs)]
+        if any(ctx.needs_input_grad[3 + n:]):
+            d_gys = list(ConvG.apply(ggw, None, relu_in, *xs))
+        return (None, None, None) + tuple(d_xs) + tuple(d_gys)
+
+
+class ChannelSumG(Function):
+    """bias gradient of a grouped convolution: sum over every member."""
+
+    @staticmethod
+    def forward(ctx, *gys):
+        out = None
+        for g in gys:
+            g = _c(g)
+            N, Cc = g.shape[0], g.shape[1]
+            S = g.numel() // (N * Cc)
+            if out is None:
+                out = torch.empty((Cc,), device=g.device, dtype=torch.float32)
+                accum = 0
+            else:
+                accum = 1
+            nws = int(lib().t2v_channel_sum_ws_floats(N, Cc, S))
+            ws = torch.empty((nws,), device=g.device, dtype=torch.float32) if nws > 0 else None
+            check(lib().t2v_channel_sum(_p(g), _p(out), _p(ws), N, Cc, S, accum, _stream()), 't2v_channel_sum')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        raise RuntimeError('bias gradients are first-order only on this path')
+
+
+def conv_group(xs, w, b=None, relu_in=False):
+    """[conv(relu?(x), w) + b for x in xs] with ONE kernel launch (5-D tensors sharing w)."""
+    return list(ConvG.apply(w, b, relu_in, *xs))

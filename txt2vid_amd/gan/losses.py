@@ -102,6 +102,27 @@ def gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xba
     """losses.py:188-209: multi-scale discriminators use the zero-centred, sum-combined penalty per
     level, summed over levels. `scale` multiplies the result (data-parallel ranks pass world_size so
     that gradient *averaging* reproduces the global-batch SUM)."""
+    if hasattr(discrim, 'sub_discrims') and getattr(discrim, 'single_discrim', None) is not None and real_x[0].is_cuda \
+            and real_xbar is None:
+        # All levels at once through the shared trunk (grouped launches). Same arithmetic as the per-level
+        # loop below; the alphas are drawn level by level in the same order.
+        n = len(real_x)
+        a_dev = [alphas[i].reshape(real_x[i].size(0)).to(real_x[i].device) if alphas is not None else
+                 TF.draws.alpha(real_x[i].size(0), real_x[i].dim(), real_x[i].device) for i in range(n)]
+        xhs = [TF.lerp_rows(a_dev[i], real_x[i].detach(), fake_x[i].detach()).requires_grad_(True) for i in range(n)]
+        chs = None
+        if real_cond is not None and fake_cond is not None:
+            chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
+        res = discrim(x=xhs, cond=chs, xbar=None)
+        outs = []
+        for u, c, _ in res:
+            outs.append(u)
+            if c is not None:
+                outs.append(c)
+        with TF.input_grads_only():
+            gs = torch.autograd.grad(outputs=outs, inputs=xhs, grad_outputs=[TF.ones_like(o) for o in outs],
+                                     create_graph=True, retain_graph=True, only_inputs=True)
+        return TF.scalar_sum([TF.vec_sum(TF.row_sqnorm(g), scale) for g in gs])
     if hasattr(discrim, 'sub_discrims'):
         gps = []
         for i in range(len(real_x)):

@@ -254,6 +254,16 @@ class DownBlock(nn.Module):
         return self.main(x)
 
 
+def down_block_levels(block, xs):
+    """DownBlock over a list of pyramid levels, layer by layer: each convolution is one grouped launch."""
+    m = block.main.inner_module
+    idm = block.main.identity_map
+    hs = TF.conv_group(xs, m[1].weight, m[1].bias, relu_in=True)
+    hs = TF.conv_group(hs, m[3].weight, m[3].bias, relu_in=True)
+    ss = TF.conv_group(xs, idm[0].weight, idm[0].bias)
+    return [TF.add(idm[1](s_), m[4](h)) for s_, h in zip(ss, hs)]
+
+
 class RenderBlock(nn.Module):
     """BN-ReLU-conv3x3-tanh — layers.py:245-259."""
 

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as TF
-from .layers import ResidualBlock, DownBlock, Attention3d, Conv3d, AvgPool3d, ReLU, Linear
+from .layers import ResidualBlock, DownBlock, Attention3d, Conv3d, AvgPool3d, ReLU, Linear, down_block_levels
 
 
 class Resnet3D(nn.Module):
@@ -38,6 +38,35 @@ class Resnet3D(nn.Module):
             h = TF.relu_conv(h, m[2].weight, m[2].bias)
             return TF.add(self.res_block.identity_map(x), m[3](h))
         return self.res_block(x)
+
+    def groupable(self):
+        m = self.res_block.inner_module
+        return isinstance(m[0], Conv3d) and isinstance(m[2], Conv3d) and all(
+            isinstance(d, (DownBlock, Attention3d)) for d in self.down)
+
+    def forward_levels(self, xs, conds=None):
+        """All pyramid levels through the shared trunk in lock-step: every convolution layer is ONE grouped
+        launch over the levels (same results as level-by-level `forward`, resnet3d.py:38-57)."""
+        m = self.res_block.inner_module
+        idm = self.res_block.identity_map
+        hs = TF.conv_group(xs, m[0].weight, m[0].bias)
+        hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
+        ss = TF.conv_group([idm[0](x) for x in xs], idm[1].weight, idm[1].bias)
+        hs = [TF.add(s_, m[3](h)) for s_, h in zip(ss, hs)]
+        for d in self.down:
+            if isinstance(d, DownBlock):
+                hs = down_block_levels(d, hs)
+            else:
+                hs = [d(h) for h in hs]
+        out = []
+        for i, h in enumerate(hs):
+            feat = TF.sum_spatial(h)
+            u = self.fc_uncond(feat)
+            c = None
+            if conds is not None:
+                c = self.fc(TF.cat_features(feat, conds[i]))
+            out.append((u, c, feat))
+        return out
 
     def forward(self, x=None, cond=None, xbar=None, computed_features=None):
         uncond = None

@@ -24,6 +24,10 @@ class MultiScaleDiscrim(nn.Module):
             self.sub_discrims = nn.ModuleList(subs)
 
     def forward(self, x=None, cond=None, xbar=None, computed_features=None):
+        if self.single_discrim is not None and xbar is None and len(x) > 1 and x[0].is_cuda:
+            trunk = self.single_discrim.module if isinstance(self.single_discrim, _ModuleWrap) else self.single_discrim
+            if hasattr(trunk, 'groupable') and trunk.groupable():
+                return trunk.forward_levels(list(x), None if cond is None else list(cond))
         out = []
         for i, r in enumerate(x):
             c = cond[i] if cond is not None else None
