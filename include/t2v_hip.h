@@ -62,6 +62,13 @@ typedef struct {
 int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
                     int mode, void* stream);
 
+/* Same, into a wider packed matrix: several weights that are applied to the same input (mode 0: side by side
+ * along the output channels, per-tap matrix [dst_rows=Cin][dst_cols=sum Cout], col_off = first output
+ * channel) or summed into the same output (mode 1: stacked, [dst_rows=sum Cout][dst_cols=Cin], row_off)
+ * become ONE GEMM — the four gates of the ConvLSTM cell (conv_lstm.py:19-26,33-37). */
+int t2v_pack_weight_into(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
+                         int mode, int dst_rows, int dst_cols, int row_off, int col_off, void* stream);
+
 /* y[N,Cout,D,H,W] = conv(x[N,Cin,D,H,W], wp) (+bias).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
  * M = N*D*H*W voxels, N = Cout, K = ntaps*Cin.  The same entry point computes the data gradient
  * when given the mode-1 packed weight (x := dL/dy, Cin := Cout_fwd, Cout := Cin_fwd).
@@ -145,8 +152,9 @@ int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* g
                 float* y, int N, int C, int64_t S, float eps, int relu, void* stream);
 
 /* ConvLSTM gate math (conv_lstm.py:32-38, peepholes are constant zeros):
- * pre[4,B,C,S] (gate-major, order i,f,c,o) ; c_prev[B,C,S] -> h, c_new; act saved [4,B,C,S]
- * (i,f,g,o after the non-linearities) for the backward; gpre likewise [4,B,C,S]. */
+ * pre[B,4,C,S] (order i,f,c,o: the NCHW output of one convolution over the 4 side-by-side packed gate
+ * weights) ; c_prev[B,C,S] -> h, c_new; act saved [B,4,C,S] (i,f,g,o after the non-linearities) for the
+ * backward; gpre likewise [B,4,C,S]. */
 int t2v_lstm_gates(const float* pre, const float* c_prev, float* h, float* c_new, float* act,
                    int B, int64_t CS, void* stream);
 int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const float* act, const float* c_prev,

@@ -39,6 +39,7 @@ _G = C.POINTER(ConvGeom)
 # name -> argtypes (restype is int unless stated); must list EVERY symbol of include/t2v_hip.h
 SIGNATURES = {
     't2v_pack_weight': [_P, _P, _I, _I, _I, _I3, _I, _I, _P],
+    't2v_pack_weight_into': [_P, _P, _I, _I, _I, _I3, _I, _I, _I, _I, _I, _I, _P],
     't2v_conv_fwd': [_P, _P, _P, _P, _P, _G, _I, _P],
     't2v_conv_fwd_ws_floats': [_G],
     't2v_conv_wgrad_slab_floats': [_G, _I],

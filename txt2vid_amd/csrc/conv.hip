@@ -32,7 +32,9 @@ static inline int launch_status() {
 // around every conv-GEMM launch while enabled. Off by default; the product path never enables it.
 // ------------------------------------------------------------------------------------------------
 #include <vector>
-struct ProfRec { hipEvent_t e0, e1; double flops; int kind; };
+#include <cstdio>
+#include <cstdlib>
+struct ProfRec { hipEvent_t e0, e1; double flops; int kind; long M; int Cin, Cout, taps, groups, S; };
 static struct {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -42,11 +44,13 @@ static struct {
 struct ProfScope {
     ProfRec* r = nullptr;
     hipStream_t s;
-    ProfScope(int kind, double flops, hipStream_t stream) : s(stream) {
+    ProfScope(int kind, double flops, hipStream_t stream, long M = 0, int Cin = 0, int Cout = 0, int taps = 0, int groups = 0,
+              int S = 0) : s(stream) {
         if (g_prof.on && g_prof.used < g_prof.recs.size()) {
             r = &g_prof.recs[g_prof.used++];
             r->kind = kind;
             r->flops = flops;
+            r->M = M; r->Cin = Cin; r->Cout = Cout; r->taps = taps; r->groups = groups; r->S = S;
             (void)hipEventRecord(r->e0, s);
         }
     }
@@ -71,13 +75,18 @@ extern "C" int t2v_prof_end(double* out, int nkinds) {
     g_prof.on = false;
     if (!out || nkinds < 1) return T2V_EINVAL;
     for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
+    FILE* dump = nullptr;
+    if (const char* path = getenv("T2V_PROF_DUMP")) dump = fopen(path, "w");   // developer aid: one line per launch
+    if (dump) fprintf(dump, "kind,flops,ms,M,Cin,Cout,taps,groups,S\n");
     for (size_t i = 0; i < g_prof.used; ++i) {
         ProfRec& r = g_prof.recs[i];
         if (hipEventSynchronize(r.e1) != hipSuccess) return T2V_ELAUNCH;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return T2V_ELAUNCH;
         if (r.kind >= 0 && r.kind < nkinds) { out[r.kind * 3] += ms; out[r.kind * 3 + 1] += r.flops; out[r.kind * 3 + 2] += 1.0; }
+        if (dump) fprintf(dump, "%d,%.0f,%.6f,%ld,%d,%d,%d,%d,%d\n", r.kind, r.flops, ms, r.M, r.Cin, r.Cout, r.taps, r.groups, r.S);
     }
+    if (dump) fclose(dump);
     int dropped = (g_prof.used >= g_prof.recs.size()) ? 1 : 0;
     g_prof.used = 0;
     return dropped;    // 1: the record pool filled up (totals cover the recorded launches only)
@@ -89,10 +98,12 @@ extern "C" int t2v_prof_end(double* out, int nkinds) {
 struct TapList { int32_t n; int32_t t[T2V_MAX_TAPS]; };
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                          int Cout, int Cin, int T, TapList taps, int mode) {
-    // mode 0: wp[j][ci][co] = w[co][ci][t_j]      (inner = co)
-    // mode 1: wp[j][co][ci] = w[co][ci][T-1-t_j]  (inner = ci)
-    // 32x32 tile transpose of the (co,ci) plane through LDS for mode 0; mode 1 is a strided copy.
+                                                          int Cout, int Cin, int T, TapList taps, int mode, int dst_rows,
+                                                          int dst_cols, int row_off, int col_off) {
+    // mode 0: wp[j][row_off + ci][col_off + co] = w[co][ci][t_j]      (per-tap matrix [dst_rows][dst_cols], inner = co)
+    // mode 1: wp[j][row_off + co][col_off + ci] = w[co][ci][T-1-t_j]  (inner = ci)
+    // dst_rows / dst_cols > the weight's own extents let several weights share one packed matrix (the four
+    // ConvLSTM gates become one GEMM). 32x32 tile transpose of the (co,ci) plane through LDS for mode 0.
     __shared__ float tile[32][33];
     const int j = blockIdx.z;
     const int t = mode ? (T - 1 - taps.t[j]) : taps.t[j];
@@ -106,19 +117,22 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {          // write rows ci, lanes co
             int ci = ci0 + r, co = co0 + tx;
-            if (ci < Cin && co < Cout) wp[((size_t)j * Cin + ci) * Cout + co] = tile[tx][r];
+            if (ci < Cin && co < Cout) wp[((size_t)j * dst_rows + row_off + ci) * dst_cols + col_off + co] = tile[tx][r];
         }
     } else {
         for (int r = ty; r < 32; r += 8) {
             int co = co0 + r, ci = ci0 + tx;
-            if (co < Cout && ci < Cin) wp[((size_t)j * Cout + co) * Cin + ci] = w[((size_t)co * Cin + ci) * T + t];
+            if (co < Cout && ci < Cin)
+                wp[((size_t)j * dst_rows + row_off + co) * dst_cols + col_off + ci] = w[((size_t)co * Cin + ci) * T + t];
         }
     }
 }
 
-extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
-                               int mode, void* stream) {
-    if (!w || !wp || ntaps < 1 || ntaps > T2V_MAX_TAPS || T > T2V_MAX_TAPS) return T2V_EINVAL;
+extern "C" int t2v_pack_weight_into(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
+                                    int mode, int dst_rows, int dst_cols, int row_off, int col_off, void* stream) {
+    if (!w || !wp || ntaps < 1 || ntaps > T2V_MAX_TAPS || T > T2V_MAX_TAPS || row_off < 0 || col_off < 0) return T2V_EINVAL;
+    const int rows = mode ? Cout : Cin, cols = mode ? Cin : Cout;
+    if (row_off + rows > dst_rows || col_off + cols > dst_cols) return T2V_EINVAL;
     TapList tl;
     tl.n = ntaps;
     for (int i = 0; i < ntaps; ++i) {
@@ -126,8 +140,14 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
         tl.t[i] = taps[i];
     }
     dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, ntaps);
-    T2V_LAUNCH(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, T, tl, mode);
+    T2V_LAUNCH(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, T, tl, mode, dst_rows, dst_cols,
+               row_off, col_off);
     return launch_status();
+}
+
+extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
+                               int mode, void* stream) {
+    return t2v_pack_weight_into(w, wp, Cout, Cin, T, taps, ntaps, mode, mode ? Cout : Cin, mode ? Cin : Cout, 0, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,6 +391,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GroupTable tab
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// thin-N convolution: Cout <= 4 (the render blocks' ch -> 1|3 convs, the data gradient of the C -> 64 stem
+// convs, the 1024 -> 1 heads). One MFMA tile would waste >= 28/32 of its columns; here a lane owns one
+// output voxel, the whole packed weight sits in LDS and the input is streamed with lane-contiguous loads:
+// bandwidth-bound on the (cache-served) 27x / 9x re-read of the input.
+// ------------------------------------------------------------------------------------------------
+#define THIN_MAX_W 16384      // floats of LDS for the packed weight (64 KiB)
+
+template <int NC>
+__global__ __launch_bounds__(256) void conv_thin_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, const int Cin, const int Cout,
+                                                        const int nslots, const int flags) {
+    __shared__ float sw[THIN_MAX_W];
+    __shared__ int s_off[T2V_MAX_TAPS];
+    __shared__ int s_widx[T2V_MAX_TAPS];
+    const int tid = threadIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int ntaps = gd.ntaps;
+    for (int i = tid; i < nslots * Cin * Cout; i += 256) sw[i] = wp[i];
+    if (tid < ntaps) {
+        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        s_widx[tid] = gd.widx[tid];
+    }
+    __syncthreads();
+    const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + tid;
+    if (m >= M) return;
+    const int n = m / DHW, sp = m - n * DHW;
+    const int d = sp / HW, r = sp - d * HW;
+    const int h = r / W, w_ = r - h * W;
+    const float* __restrict__ px = gd.x + (size_t)n * Cin * DHW + sp;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    for (int t = 0; t < ntaps; ++t) {
+        const int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
+        if (!((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)) continue;
+        const float* p = px + (ptrdiff_t)s_off[t];
+        const float* wt = sw + (size_t)s_widx[t] * Cin * Cout;
+        int ci = 0;
+        for (; ci + 4 <= Cin; ci += 4) {
+            float v0 = p[(size_t)ci * DHW], v1 = p[(size_t)(ci + 1) * DHW], v2 = p[(size_t)(ci + 2) * DHW], v3 = p[(size_t)(ci + 3) * DHW];
+            if (relu_in) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                acc[c] += v0 * wt[ci * Cout + c] + v1 * wt[(ci + 1) * Cout + c] + v2 * wt[(ci + 2) * Cout + c] + v3 * wt[(ci + 3) * Cout + c];
+        }
+        for (; ci < Cin; ++ci) {
+            float v = p[(size_t)ci * DHW];
+            if (relu_in) v = fmaxf(v, 0.f);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += v * wt[ci * Cout + c];
+        }
+    }
+    const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const bool accum = flags & T2V_CONV_ACCUM;
+    float* py = gd.y + (size_t)n * Cout * DHW + sp;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < Cout) {
+            float v = acc[c] + (has_bias ? bias[c] : 0.f);
+            py[(size_t)c * DHW] = accum ? py[(size_t)c * DHW] + v : v;
+        }
+    }
+}
+
+static bool thin_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int& nslots) {
+    if (Cout > 4) return false;
+    nslots = 0;
+    for (int i = 0; i < ngroups; ++i)
+        for (int t = 0; t < groups[i].ntaps; ++t)
+            if (groups[i].widx[t] + 1 > nslots) nslots = groups[i].widx[t] + 1;
+    return (long)nslots * Cin * Cout <= THIN_MAX_W;
+}
+
 struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; };
 
 static bool group_ok(const t2v_conv_group& g, bool need_ptrs) {
@@ -387,14 +489,14 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
                         ConvPlan& p) {
     if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
     long Mtot = 0, Mmax = 0;
-    int min_chunk_taps = T2V_MAX_TAPS;
+    int max_chunk_taps = 1;
     for (int i = 0; i < ngroups; ++i) {
         if (!group_ok(groups[i], need_ptrs)) return false;
         const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
         if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;     // 32-bit voxel indices
         Mtot += M;
         if (M > Mmax) Mmax = M;
-        if (groups[i].ntaps < min_chunk_taps) min_chunk_taps = groups[i].ntaps;
+        if (groups[i].ntaps > max_chunk_taps) max_chunk_taps = groups[i].ntaps;
     }
     p.bk = (Cin % 64 == 0) ? 64 : (Cin % 32 == 0) ? 32 : 16;
     p.fast = (Cin % 16 == 0);
@@ -421,8 +523,9 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     tab.tile_start[ngroups] = (int32_t)mt;
     tab.out_start[ngroups] = ot;
     p.tiles = mt * ((Cout + p.bn - 1) / p.bn);
-    // split-K: every group must keep >= 2 chunks per split
-    const long min_chunks = p.fast ? (long)min_chunk_taps * (Cin / p.bk) : ((long)min_chunk_taps * Cin + p.bk - 1) / p.bk;
+    // split-K: the member with the longest reduction keeps >= 2 chunks per split; members with fewer chunks
+    // than splits just leave their surplus splits empty (they write zero partial tiles)
+    const long min_chunks = p.fast ? (long)max_chunk_taps * (Cin / p.bk) : ((long)max_chunk_taps * Cin + p.bk - 1) / p.bk;
     long S = 1;
     if (p.tiles < 384) {
         S = (768 + p.tiles - 1) / p.tiles;
@@ -452,6 +555,8 @@ extern "C" int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, 
     GroupTable tab;
     ConvPlan p;
     if (!build_table(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    int nslots;
+    if (thin_ok(groups, ngroups, Cin, Cout, nslots)) return 0;
     return p.S > 1 ? (int64_t)p.S * tab.out_start[ngroups] : 0;
 }
 
@@ -460,12 +565,33 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     GroupTable tab;
     ConvPlan p;
     if (!wp || !build_table(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
-    if (p.S > 1 && !ws) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    int nslots;
+    const bool thin = thin_ok(groups, ngroups, Cin, Cout, nslots);
+    if (!thin && p.S > 1 && !ws) return T2V_EINVAL;
     double flops = 0;
     for (int i = 0; i < ngroups; ++i)
         flops += 2.0 * (double)groups[i].N * groups[i].D * groups[i].H * groups[i].W * Cout * Cin * groups[i].ntaps;
-    ProfScope prof(0, flops, s);      // executed (non-padding-tap) MACs x 2
+    long Mtot_ = 0;
+    int taps_ = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        Mtot_ += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
+    }
+    if (thin) {
+        // re-tile for 256 voxels per workgroup
+        long mt = 0;
+        for (int i = 0; i < ngroups; ++i) {
+            tab.tile_start[i] = (int32_t)mt;
+            mt += ((long)groups[i].N * groups[i].D * groups[i].H * groups[i].W + 255) / 256;
+        }
+        for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
+        ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
+        if (Cout == 1) T2V_LAUNCH(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
+        else T2V_LAUNCH(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
+        return launch_status();
+    }
+    ProfScope prof(0, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);      // executed (non-padding-tap) MACs x 2
     const int bk = p.bk;
     if (p.bn == 32) {
         if (bk == 32) launch_conv_t<128, 32, 1, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
@@ -625,6 +751,105 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
     }
 }
 
+
+// Weight gradient for Cin < 64: the 64 tile columns run over (tap, ci) pairs instead of one tap's channels
+// (C -> 64 stem convs: 27 columns instead of 27 tiles that are 1/64 full).
+__global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                              const int Cout, const int T, const int kH, const int kW,
+                                                              const int flags, const int chunks_per_split, const LiveTaps live) {
+    __shared__ float As[64 * WG_PITCH];   // gy^T tile  [co][m]
+    __shared__ float Bs[64 * WG_PITCH];   // x   tile   [col][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wcl = wave >> 1;
+    const int nco_t = (Cout + 63) / 64;
+    const int co0 = (blockIdx.x % nco_t) * 64, col0 = (blockIdx.x / nco_t) * 64;
+    const int ncols = live.n * Cin;
+    const int split = blockIdx.z;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    const int kD = T / (kH * kW);
+    const int ml = tid & 31, rl = tid >> 5;
+    // this thread's 8 columns: (slot, ci, dz, dy, dx)
+    int c_ci[8], c_dz[8], c_dy[8], c_dx[8];
+    bool c_ok[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int col = col0 + rl + p * 8;
+        c_ok[p] = col < ncols;
+        const int slot = c_ok[p] ? col / Cin : 0;
+        c_ci[p] = c_ok[p] ? col - slot * Cin : 0;
+        const int t = live.t[slot];
+        c_dz[p] = t / (kH * kW) - kD / 2;
+        c_dy[p] = (t / kW) % kH - kH / 2;
+        c_dx[p] = t % kW - kW / 2;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+    float ra[8], rb[8];
+    auto load_chunk = [&](int q) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
+        const bool mv = m < M;
+        int n = 0, sp = 0, d = 0, h = 0, w_ = 0;
+        if (mv) {
+            n = m / DHW; sp = m - n * DHW;
+            d = sp / HW; const int r = sp - d * HW;
+            h = r / W; w_ = r - h * W;
+        }
+        const float* __restrict__ gy = gd.y + (size_t)n * Cout * DHW + sp;
+        const float* __restrict__ x = gd.x + (size_t)n * Cin * DHW + sp;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int co = co0 + rl + p * 8;
+            ra[p] = (mv && co < Cout) ? gy[(size_t)co * DHW] : 0.f;
+            const int dd = d + c_dz[p], hh = h + c_dy[p], ww = w_ + c_dx[p];
+            const bool live_tap = !((D == 1 && c_dz[p]) || (H == 1 && c_dy[p]) || (W == 1 && c_dx[p]));
+            const bool xv = mv && c_ok[p] && live_tap && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            float v = xv ? x[(size_t)c_ci[p] * DHW + (ptrdiff_t)(c_dz[p] * HW + c_dy[p] * W + c_dx[p])] : 0.f;
+            rb[p] = relu_in ? fmaxf(v, 0.f) : v;
+        }
+    };
+    if (q0 < q1) load_chunk(q0);
+    for (int q = q0; q < q1; ++q) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            As[(rl + p * 8) * WG_PITCH + ml] = ra[p];
+            Bs[(rl + p * 8) * WG_PITCH + ml] = rb[p];
+        }
+        __syncthreads();
+        if (q + 1 < q1) load_chunk(q + 1);
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
+            const int kc = k2 * 2 + hi;
+            float a = As[(wco * 32 + l31) * WG_PITCH + kc];
+            float b = Bs[(wcl * 32 + l31) * WG_PITCH + kc];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // column -> (slot, ci): slab[((split*nlive + slot)*Cout + co)*Cin + ci]
+    const int col = col0 + wcl * 32 + l31;
+    if (col < ncols) {
+        const int slot = col / Cin, ci = col - slot * Cin;
+        float* ps = slab + ((size_t)split * live.n + slot) * Cout * Cin + ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) ps[(size_t)co * Cin] = acc[r];
+        }
+    }
+}
+
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
 
 // dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
@@ -685,7 +910,8 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.chunk_start[i] = (int32_t)nch;
     p.nchunks = nch;
     p.nlive = __builtin_popcount(p.live);
-    const long base = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
+    const long base = (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
+                                 : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
     long S = (1536 + base - 1) / base;            // aim at ~6 workgroups per CU
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
@@ -731,9 +957,14 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     }
     // grid.y runs over the taps at least one member can touch; the others are written as zeros by the reduce
     {
-        ProfScope prof(1, flops, s);
-        dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
-        T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+        ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
+        if (Cin < 64) {
+            dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
+            T2V_LAUNCH(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+        } else {
+            dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
+            T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+        }
     }
     int st = launch_status();
     if (st) return st;

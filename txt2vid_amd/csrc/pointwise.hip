@@ -485,30 +485,36 @@ extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, con
 // ---------------------------------------------------------------- ConvLSTM gates
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
-// gate-major layout: pre/act/gpre are [4][B*CS] (i,f,c,o) so that each gate's convolution writes a
-// dense [B,C,h,w] block.
+// pre / act / gpre are [B][4][C*S] (gate order i,f,c,o): exactly the NCHW output of ONE convolution whose 4C output
+// channels are the four gates (their weights are packed side by side).
 __global__ void lstm_gates_k(const float* pre, const float* c_prev, float* h, float* c_new, float* act, int B, long CS) {
     const long n = (long)B * CS;
     GRID_STRIDE(i, n) {
-        const float gi = sigm(pre[i]), gf = sigm(pre[n + i]), gg = tanhf(pre[2 * n + i]), go = sigm(pre[3 * n + i]);
+        const long b = i / CS, r = i - b * CS;
+        const float* pp = pre + b * 4 * CS + r;
+        const float gi = sigm(pp[0]), gf = sigm(pp[CS]), gg = tanhf(pp[2 * CS]), go = sigm(pp[3 * CS]);
         const float cc = gf * c_prev[i] + gi * gg;
         c_new[i] = cc;
         h[i] = go * tanhf(cc);
-        act[i] = gi; act[n + i] = gf; act[2 * n + i] = gg; act[3 * n + i] = go;
+        float* pa = act + b * 4 * CS + r;
+        pa[0] = gi; pa[CS] = gf; pa[2 * CS] = gg; pa[3 * CS] = go;
     }
 }
 __global__ void lstm_gates_bwd_k(const float* gh, const float* gc_in, const float* act, const float* c_prev, const float* c_new,
                                  float* gpre, float* gc_prev, int B, long CS) {
     const long n = (long)B * CS;
     GRID_STRIDE(i, n) {
-        const float gi = act[i], gf = act[n + i], gg = act[2 * n + i], go = act[3 * n + i];
+        const long b = i / CS, r = i - b * CS;
+        const float* pa = act + b * 4 * CS + r;
+        const float gi = pa[0], gf = pa[CS], gg = pa[2 * CS], go = pa[3 * CS];
         const float tc = tanhf(c_new[i]);
         const float dh = gh[i];
         const float dc = dh * go * (1.f - tc * tc) + (gc_in ? gc_in[i] : 0.f);
-        gpre[i] = dc * gg * gi * (1.f - gi);
-        gpre[n + i] = dc * c_prev[i] * gf * (1.f - gf);
-        gpre[2 * n + i] = dc * gi * (1.f - gg * gg);
-        gpre[3 * n + i] = dh * tc * go * (1.f - go);
+        float* pg = gpre + b * 4 * CS + r;
+        pg[0] = dc * gg * gi * (1.f - gi);
+        pg[CS] = dc * c_prev[i] * gf * (1.f - gf);
+        pg[2 * CS] = dc * gi * (1.f - gg * gg);
+        pg[3 * CS] = dh * tc * go * (1.f - go);
         gc_prev[i] = dc * gf;
     }
 }

@@ -150,11 +150,66 @@ def repack_params(params):
         for key, hit in ent.items():
             if hit[0]() is not p:
                 continue
-            shape5, _, mode = key
-            geom = hit[3]
-            check(lib().t2v_pack_weight(_p(p), _p(hit[2]), shape5[0], shape5[1], geom.T, geom.taps_c, len(geom.taps), mode,
-                                        _stream()), 't2v_pack_weight')
+            if callable(hit[3]):
+                hit[3](p)                       # member of a fused (multi-weight) packed matrix
+            else:
+                shape5, _, mode = key
+                geom = hit[3]
+                check(lib().t2v_pack_weight(_p(p), _p(hit[2]), shape5[0], shape5[1], geom.T, geom.taps_c, len(geom.taps), mode,
+                                            _stream()), 't2v_pack_weight')
             hit[1] = (p._version, WEIGHT_EPOCH, p.data_ptr())
+
+
+_fused_cache = {}
+
+
+def packed_fused(ws, ts, mode):
+    """ONE packed matrix for several same-shape weights applied to the same input (mode 0: outputs side by
+    side -> wp[tap][Cin][n*Cout]) or whose data gradients add up (mode 1: wp[tap][n*Cout][Cin]).
+    Persistent and refreshed per member exactly like `packed_weight`."""
+    n = len(ws)
+    Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+    key = (tuple(id(w) for w in ws), ts.mask, mode)
+    hit = _fused_cache.get(key)
+    tag = tuple((w._version, WEIGHT_EPOCH, w.data_ptr()) for w in ws)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
+        if hit[1] != tag:
+            for i, w in enumerate(ws):
+                hit[3][i](w)
+            hit[1] = tag
+        return hit[2]
+    rows, cols = (Cin, n * Cout) if mode == 0 else (n * Cout, Cin)
+    wp = torch.empty((len(ts.taps), rows * cols), device=ws[0].device, dtype=torch.float32)
+    refresh = []
+    for i, w in enumerate(ws):
+        def make(i):
+            def fn(wi):
+                ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
+                check(lib().t2v_pack_weight_into(_p(wi), _p(wp), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode, rows, cols,
+                                                 ro, co, _stream()), 't2v_pack_weight_into')
+                h = _fused_cache.get(key)
+                if h is not None:
+                    h[1] = tuple((x._version, WEIGHT_EPOCH, x.data_ptr()) for x in ws)
+            return fn
+        refresh.append(make(i))
+        refresh[i](w)
+        if isinstance(w, torch.nn.Parameter):
+            _pack_cache.setdefault(id(w), {})[('fused', key, i)] = [weakref.ref(w), (w._version, WEIGHT_EPOCH, w.data_ptr()), wp,
+                                                                    refresh[i]]
+    if all(isinstance(w, torch.nn.Parameter) for w in ws):
+        _fused_cache[key] = [[weakref.ref(w) for w in ws], tag, wp, refresh]
+    return wp
+
+
+def conv_packed_raw(x5, wp, cin, cout, k, bias=None, out=None, accum=False):
+    """Convolution with an explicitly packed weight (fused gates): wp holds the taps of this geometry in order."""
+    x5 = _c(x5)
+    g = conv_geom(x5.shape[0], cin, x5.shape[2], x5.shape[3], x5.shape[4], cout, k[0], k[1], k[2])
+    y = out if out is not None else torch.empty((x5.shape[0], cout) + tuple(x5.shape[2:]), device=x5.device, dtype=torch.float32)
+    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_ACCUM if accum else 0)
+    check(lib().t2v_conv_fwd(_p(x5), _p(wp), _p(bias), _p(y), _p(_conv_ws(g, x5.device)), C.byref(g.cg), flags, _stream()),
+          't2v_conv_fwd')
+    return y, g
 
 
 def _as5(t):
@@ -826,9 +881,10 @@ def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5
 
 class ConvLSTMFn(Function):
     """16-step single-cell ConvLSTM (conv_lstm.py:75-97). x is the input at step 0 and zero afterwards,
-    so the Wx convolutions run once; from step 1 on their contribution is the bias. Each gate's
-    convolution writes one dense block of the gate-major pre-activation buffer [4,B,C,h,w].
-    Back-propagation through time is done here explicitly with the dgrad / wgrad kernels.
+    so the Wx convolutions run once; from step 1 on their contribution is the bias. The four gate weights
+    are packed side by side, so each step is ONE convolution with 4C output channels (and its data
+    gradient ONE convolution with 4C input channels); the weight gradients of all gates and all time
+    steps come from one launch. Back-propagation through time is done here explicitly.
     args: x, steps, then Wx{i,f,c,o}, bx{i,f,c,o}, Wh{i,f,c,o}  (4-D conv weights [C,C,3,3]).
     Returns the stacked hidden states [steps, B, C, h, w]."""
 
@@ -838,19 +894,28 @@ class ConvLSTMFn(Function):
         x = _c(x)
         B, Cc, h, w = x.shape
         CS = Cc * h * w
+        k = (1,) + tuple(wx[0].shape[2:])
         x5 = x.unsqueeze(2)
         dev = x.device
+        g0 = conv_geom(B, Cc, 1, h, w, 4 * Cc, k[0], k[1], k[2])
+        ts = _tapset(g0.T, g0.mask)
+        wx5 = [t.unsqueeze(2) for t in wx]
+        wh5 = [t.unsqueeze(2) for t in wh]
+        wpx = packed_fused(wx5, ts, 0)
+        wph = packed_fused(wh5, ts, 0)
+        bias4 = torch.empty((4 * Cc,), device=dev, dtype=torch.float32)
+        for g in range(4):
+            _copy2d(bx[g], 0, Cc, bias4, g * Cc, Cc, 1, Cc)
         hs = torch.empty((steps, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
         cs = torch.empty((steps + 1, B, Cc, h, w), device=dev, dtype=torch.float32)
-        acts = torch.empty((steps, 4, B, Cc, h, w), device=dev, dtype=torch.float32)
-        pre = torch.empty((4, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+        acts = torch.empty((steps, B, 4 * Cc, h, w), device=dev, dtype=torch.float32)
+        pre = torch.empty((B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         check(lib().t2v_fill(_p(cs[0]), 0.0, B * CS, _stream()), 't2v_fill')
         for t in range(steps):
-            for g in range(4):
-                if t == 0:
-                    conv_fwd_raw(x5, wx[g].unsqueeze(2), bx[g], out=pre[g])      # h0 = 0: the Wh term vanishes
-                else:
-                    conv_fwd_raw(hs[t - 1], wh[g].unsqueeze(2), bx[g], out=pre[g])  # x_t = 0: Wx(x_t) is its bias
+            if t == 0:
+                conv_packed_raw(x5, wpx, Cc, 4 * Cc, k, bias4, out=pre)           # h0 = 0: the Wh term vanishes
+            else:
+                conv_packed_raw(hs[t - 1], wph, Cc, 4 * Cc, k, bias4, out=pre)    # x_t = 0: Wx(x_t) is its bias
             check(lib().t2v_lstm_gates(_p(pre), _p(cs[t]), _p(hs[t]), _p(cs[t + 1]), _p(acts[t]), B, CS, _stream()),
                   't2v_lstm_gates')
         ctx.save_for_backward(x, hs, cs, acts, *params)
@@ -869,43 +934,45 @@ class ConvLSTMFn(Function):
         B, Cc, h, w = x.shape
         CS = Cc * h * w
         dev = x.device
+        k = (1,) + tuple(wx[0].shape[2:])
         x5 = x.unsqueeze(2)
-        gpre = torch.empty((steps, 4, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
+        gt = conv_geom(B, 4 * Cc, 1, h, w, Cc, k[0], k[1], k[2])         # data-gradient geometry (4C -> C)
+        ts = _tapset(gt.T, gt.mask)
+        wx5 = [t.unsqueeze(2) for t in wx]
+        wh5 = [t.unsqueeze(2) for t in wh]
+        wph1 = packed_fused(wh5, ts, 1)
+        gpre = torch.empty((steps, B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         gh_next = None           # dL/dh_t arriving from step t+1
         gc = None
         for t in range(steps - 1, -1, -1):
             if gh_next is None:
                 gh = ghs[t]
             else:
-                gh = torch.empty_like(gh_next)
+                gh = torch.empty((B, Cc, h, w), device=dev, dtype=torch.float32)
                 check(lib().t2v_add(_p(ghs[t]), _p(gh_next), _p(gh), B * CS, _stream()), 't2v_add')
             gcp = torch.empty((B, Cc, h, w), device=dev, dtype=torch.float32)
             check(lib().t2v_lstm_gates_bwd(_p(gh), _p(gc), _p(acts[t]), _p(cs[t]), _p(cs[t + 1]), _p(gpre[t]), _p(gcp),
                                            B, CS, _stream()), 't2v_lstm_gates_bwd')
             gc = gcp
             if t > 0:
-                gh_next = torch.empty((B, Cc, 1, h, w), device=dev, dtype=torch.float32)
-                for g in range(4):
-                    conv_dgrad_raw(gpre[t, g], wh[g].unsqueeze(2), out=gh_next, accum=(g > 0))
+                gh_next, _ = conv_packed_raw(gpre[t], wph1, 4 * Cc, Cc, k)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((B, Cc, 1, h, w), device=dev, dtype=torch.float32)
-            for g in range(4):
-                conv_dgrad_raw(gpre[0, g], wx[g].unsqueeze(2), out=gx, accum=(g > 0))
+            wpx1 = packed_fused(wx5, ts, 1)
+            gx, _ = conv_packed_raw(gpre[0], wpx1, 4 * Cc, Cc, k)
             gx = gx.squeeze(2)
-        gwx, gbx, gwh = [], [], []
-        for g in range(4):
-            gwx.append(conv_wgrad_raw(x5, gpre[0, g], tuple(wx[g].unsqueeze(2).shape)).squeeze(2))
-            # bias: every step contributes -> fold the time axis into the batch
-            gt = gpre[:, g]                                         # [steps,B,C,1,h,w] (strided over gates)
-            gtc = gt.contiguous().view(steps * B, Cc, 1, h, w)
-            gbx.append(channel_sum_raw(gtc))
-            if steps > 1:
-                hin = hs[:steps - 1].reshape((steps - 1) * B, Cc, 1, h, w)
-                gin = gtc[B:]
-                gwh.append(conv_wgrad_raw(hin, gin, tuple(wh[g].unsqueeze(2).shape)).squeeze(2))
-            else:
-                gwh.append(torch.zeros_like(wh[g]))
+        w4shape = (4 * Cc, Cc) + k
+        gwx4 = conv_wgrad_raw(x5, gpre[0], w4shape)                       # all four gates at once
+        gb4 = channel_sum_raw(gpre.view(steps * B, 4 * Cc, 1, h, w))      # every step contributes to the bias
+        if steps > 1:
+            hin = hs[:steps - 1].reshape((steps - 1) * B, Cc, 1, h, w)    # time folded into the batch
+            gin = gpre[1:].reshape((steps - 1) * B, 4 * Cc, 1, h, w)
+            gwh4 = conv_wgrad_raw(hin, gin, w4shape)
+        else:
+            gwh4 = _zeros_like(gwx4)
+        gwx = [gwx4[g * Cc:(g + 1) * Cc].squeeze(2) for g in range(4)]
+        gwh = [gwh4[g * Cc:(g + 1) * Cc].squeeze(2) for g in range(4)]
+        gbx = [gb4[g * Cc:(g + 1) * Cc] for g in range(4)]
         return (gx, None) + tuple(gwx) + tuple(gbx) + tuple(gwh)
 
 

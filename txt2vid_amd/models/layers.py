@@ -107,6 +107,26 @@ def _nonlocal(self, x, pooled_planes):
     return TF.scale_add(self.gamma, o, x)
 
 
+def nonlocal_levels(att, xs):
+    """Attention3d over a list of pyramid levels: the four 1x1x1 convolutions are grouped launches over the
+    levels; the (tiny, per-sample) max-pool / bmm / softmax stay per level."""
+    thetas = TF.conv_group(xs, att.theta.weight, None)
+    phis = TF.conv_group(xs, att.phi.weight, None)
+    gs = TF.conv_group(xs, att.g.weight, None)
+    os_ = []
+    for x, theta, phi, g in zip(xs, thetas, phis, gs):
+        b = x.size(0)
+        phi = TF.max_pool2x2(phi)
+        g = TF.max_pool2x2(g)
+        theta = theta.reshape(b, att.ch // 8, -1)
+        phi = phi.reshape(b, att.ch // 8, -1)
+        g = g.reshape(b, att.ch // 2, -1)
+        beta = TF.softmax_lastdim(TF.bmm(theta, phi, True, False))
+        os_.append(TF.bmm(g, beta, False, True).reshape((b, att.ch // 2) + tuple(x.shape[2:])))
+    os_ = TF.conv_group(os_, att.o.weight, None)
+    return [TF.scale_add(att.gamma, o, x) for o, x in zip(os_, xs)]
+
+
 class Attention(nn.Module):
     """2-D non-local block (SA-GAN style) — layers.py:10-36."""
 

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as TF
-from .layers import ResidualBlock, DownBlock, Attention3d, Conv3d, AvgPool3d, ReLU, Linear, down_block_levels
+from .layers import ResidualBlock, DownBlock, Attention3d, Conv3d, AvgPool3d, ReLU, Linear, down_block_levels, nonlocal_levels
 
 
 class Resnet3D(nn.Module):
@@ -57,7 +57,7 @@ class Resnet3D(nn.Module):
             if isinstance(d, DownBlock):
                 hs = down_block_levels(d, hs)
             else:
-                hs = [d(h) for h in hs]
+                hs = nonlocal_levels(d, hs)
         out = []
         for i, h in enumerate(hs):
             feat = TF.sum_spatial(h)
