@@ -105,7 +105,7 @@ def main():
     rank, world = tdist.init_from_env('nccl')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = tdist.local_device_index()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

@@ -15,6 +15,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// q = m / d for 0 <= m < 2^24 via the float reciprocal (+-1 fix-up): ~8 VALU instead of the ~40 of an
+// integer division. The per-chunk voxel decode of the weight-gradient kernels runs three of these per lane.
+__device__ __forceinline__ int fast_div(int m, int d, float rcp) {
+    int q = (int)((float)m * rcp);
+    int r = m - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 #define BK 16
 
 // hipGetLastError() is sticky per thread and also reports errors of calls the HOST framework made and
@@ -187,8 +197,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     constexpr int KSBV = 1024 / BN;         // k rows covered by one float4 pass of the workgroup
     static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LB >= 1, "tile");
 
-    __shared__ __attribute__((aligned(16))) float As[BKT * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[2 * BKT * BM];     // two stages
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BKT * BN];
     __shared__ int s_off[T2V_MAX_TAPS];
     __shared__ int s_widx[T2V_MAX_TAPS];
 
@@ -255,45 +265,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     if (q1 > nchunks) q1 = nchunks;
     __syncthreads();   // s_off / s_widx visible
 
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
+    // `valid ? *p : 0` select makes hipcc branch around every load and wait for it (s_waitcnt per element),
+    // which serialises the 16 gathers of a chunk at full memory latency.
+    // The masking (and the fused ReLU) is applied when the registers are written to LDS, one chunk later, so
+    // that nothing consumes the loads before the MFMAs of the current chunk have been issued.
+    const float* wp_safe = wp;
+    uint32_t pend_a = 0;           // validity bits of the pending chunk's A elements
     auto load_chunk = [&](int q, int t, int c0) {
         if (FAST) {
             const bool v = (tapmask >> t) & 1u;
-            const float* px = x + xbase + (ptrdiff_t)s_off[t] + (size_t)(c0 + ka_l) * DHW;
+            pend_a = v ? 0xFFFFFFFFu : 0u;
+            const ptrdiff_t off = v ? (ptrdiff_t)s_off[t] : 0;
+            const float* px = x + xbase + off + (size_t)(c0 + ka_l) * DHW;
 #pragma unroll
-            for (int j = 0; j < LA; ++j) {
-                float val = v ? px[(size_t)j * KSA * DHW] : 0.f;
-                ra[j] = relu_in ? fmaxf(val, 0.f) : val;
-            }
+            for (int j = 0; j < LA; ++j) ra[j] = px[(size_t)j * KSA * DHW];
             if (VECB) {
-                const float* pw = wp + ((size_t)s_widx[t] * Cin + c0 + kv_l) * Cout + co0 + cv_l;
+                const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kv_l) * Cout + co0 + cv_l : wp_safe;
 #pragma unroll
-                for (int j = 0; j < LBV; ++j)
-                    rbv[j] = co_ok ? *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < LBV; ++j) rbv[j] = *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout);
             } else {
-                const float* pw = wp + ((size_t)s_widx[t] * Cin + c0 + kb_l) * Cout + co0 + cob_l;
+                const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kb_l) * Cout + co0 + cob_l : wp_safe;
 #pragma unroll
-                for (int j = 0; j < LB; ++j) rb[j] = co_ok ? pw[(size_t)j * KSB * Cout] : 0.f;
+                for (int j = 0; j < LB; ++j) rb[j] = pw[(size_t)j * KSB * Cout];
             }
         } else {
+            pend_a = 0;
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                int kk = q * BKT + ka_l + j * KSA;
-                float val = 0.f;
-                if (kk < Ktot) {
-                    int tt = kk / Cin, ci = kk - tt * Cin;
-                    if ((tapmask >> tt) & 1u) val = x[xbase + (ptrdiff_t)s_off[tt] + (size_t)ci * DHW];
-                }
-                ra[j] = relu_in ? fmaxf(val, 0.f) : val;
+                const int kk = q * BKT + ka_l + j * KSA;
+                const int kc = kk < Ktot ? kk : Ktot - 1;
+                const int tt = kc / Cin, ci = kc - tt * Cin;
+                const bool v = kk < Ktot && ((tapmask >> tt) & 1u);
+                pend_a |= (v ? 1u : 0u) << j;
+                const ptrdiff_t off = v ? (ptrdiff_t)s_off[tt] : 0;
+                ra[j] = x[xbase + off + (size_t)ci * DHW];
             }
 #pragma unroll
             for (int j = 0; j < LB; ++j) {
-                int kk = q * BKT + kb_l + j * KSB;
-                float val = 0.f;
-                if (co_ok && kk < Ktot) {
-                    int tt = kk / Cin, ci = kk - tt * Cin;
-                    val = wp[((size_t)s_widx[tt] * Cin + ci) * Cout + co0 + cob_l];
-                }
-                rb[j] = val;
+                const int kk = q * BKT + kb_l + j * KSB;
+                const int kc = kk < Ktot ? kk : Ktot - 1;
+                const int tt = kc / Cin, ci = kc - tt * Cin;
+                // rows of the K padding (kk >= Ktot) multiply A elements that are masked to zero
+                rb[j] = wp[((size_t)s_widx[tt] * Cin + ci) * Cout + (co_ok ? co0 + cob_l : 0)];
             }
         }
     };
@@ -304,41 +318,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
         t_cur = q0 / cpt;
         c_cur = (q0 - t_cur * cpt) * BKT;
     }
-    if (q0 < q1) load_chunk(q0, t_cur, c_cur);
-    for (int q = q0; q < q1; ++q) {
-        // registers -> LDS
+    auto advance = [&]() {
+        c_cur += BKT;
+        if (FAST && c_cur >= Cin) { c_cur = 0; ++t_cur; }
+    };
+    // registers -> LDS buffer `b` (masking + fused ReLU happen here)
+    auto stage = [&](int b) {
+        float* as = As + b * (BKT * BM);
+        float* bs = Bs + b * (BKT * BN);
 #pragma unroll
-        for (int j = 0; j < LA; ++j) As[(ka_l + j * KSA) * BM + ma_l] = ra[j];
+        for (int j = 0; j < LA; ++j) {
+            float val = ((pend_a >> j) & 1u) ? ra[j] : 0.f;
+            as[(ka_l + j * KSA) * BM + ma_l] = relu_in ? fmaxf(val, 0.f) : val;
+        }
         if (VECB) {
 #pragma unroll
             for (int j = 0; j < LBV; ++j)
-                if (vact) *reinterpret_cast<float4*>(&Bs[(kv_l + j * KSBV) * BN + cv_l]) = rbv[j];
+                if (vact) *reinterpret_cast<float4*>(&bs[(kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rbv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
 #pragma unroll
-            for (int j = 0; j < LB; ++j) Bs[(kb_l + j * KSB) * BN + cob_l] = rb[j];
+            for (int j = 0; j < LB; ++j) bs[(kb_l + j * KSB) * BN + cob_l] = co_ok ? rb[j] : 0.f;
         }
+    };
+    // Two LDS stages, ONE barrier per chunk: while the waves of this workgroup multiply chunk q out of
+    // stage `cur`, chunk q+1 sits in registers (its loads were issued a whole MFMA phase ago) and is written
+    // to the other stage right after this wave's MFMAs; chunk q+2's loads are issued after the barrier.
+    int cur = 0;
+    if (q0 < q1) {
+        load_chunk(q0, t_cur, c_cur);
+        stage(0);
         __syncthreads();
-        // issue the next chunk's global loads before the MFMAs (latency hides under compute)
-        if (q + 1 < q1) {
-            c_cur += BKT;
-            if (FAST && c_cur >= Cin) { c_cur = 0; ++t_cur; }
-            load_chunk(q + 1, t_cur, c_cur);
-        }
+        if (q0 + 1 < q1) { advance(); load_chunk(q0 + 1, t_cur, c_cur); }
+    }
+    for (int q = q0; q < q1; ++q) {
+        const float* as = As + cur * (BKT * BM);
+        const float* bs = Bs + cur * (BKT * BN);
 #pragma unroll 8
         for (int k2 = 0; k2 < BKT / 2; ++k2) {
             float a[NCO], b[NM];
             const int krow = k2 * 2 + hi;
 #pragma unroll
-            for (int i = 0; i < NCO; ++i) a[i] = Bs[krow * BN + wco * WCO + i * 32 + l31];
+            for (int i = 0; i < NCO; ++i) a[i] = bs[krow * BN + wco * WCO + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < NM; ++j) b[j] = As[krow * BM + wm * WM + j * 32 + l31];
+            for (int j = 0; j < NM; ++j) b[j] = as[krow * BM + wm * WM + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < NCO; ++i)
 #pragma unroll
                 for (int j = 0; j < NM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (q + 1 < q1) stage(cur ^ 1);
         __syncthreads();
+        if (q + 2 < q1) { advance(); load_chunk(q + 2, t_cur, c_cur); }
+        cur ^= 1;
     }
 
     // ---- epilogue: rows (registers) = co, columns (lanes) = m
@@ -352,16 +384,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
         if (m >= M) continue;
         const int n = m / DHW, sp = m - n * DHW;
         float* py = out + (size_t)n * Cout * DHW + sp;
+        if (!accum) {                      // (block-uniform) plain stores: no load, no wait in the store tail
 #pragma unroll
-        for (int i = 0; i < NCO; ++i) {
+            for (int i = 0; i < NCO; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (co < Cout) {
-                    float v = acc[i][j][r];
-                    if (has_bias) v += bias[co];
-                    float* p = py + (size_t)co * DHW;
-                    *p = accum ? (*p + v) : v;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < Cout) py[(size_t)co * DHW] = acc[i][j][r] + (has_bias ? bias[co] : 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < Cout) py[(size_t)co * DHW] += acc[i][j][r] + (has_bias ? bias[co] : 0.f);
                 }
             }
         }
@@ -506,7 +544,7 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         p.bn = 64;
         const long t128 = ((Mtot + 127) / 128) * ((Cout + 63) / 64);
         p.bm = (t128 >= 768) ? 128 : 64;
-        if (p.bm == 128 && p.bk > 32) p.bk = 32;
+        if (p.bk > 32) p.bk = 32;                  // two LDS stages: 48 KB (128x64) / 32 KB (64x64) per workgroup
     }
     if (!p.fast) p.bk = 16;
     long mt = 0, ot = 0;
@@ -600,8 +638,7 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         if (bk == 32) launch_conv_t<128, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
         else launch_conv_t<128, 64, 2, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
     } else {
-        if (bk == 64) launch_conv_t<64, 64, 2, 64>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
-        else if (bk == 32) launch_conv_t<64, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+        if (bk == 32) launch_conv_t<64, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
         else launch_conv_t<64, 64, 2, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
     }
     int st = launch_status();
@@ -689,6 +726,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
     if (q1 > nchunks) q1 = nchunks;
 
     float ra[8], rb[8];
+    bool pend_v = false;
     auto load_chunk = [&](int q) {
         int gi = 0;
 #pragma unroll
@@ -699,34 +737,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
         // a dim of extent 1 keeps its centre tap only (same rule as the forward)
         const bool tap_live = !((D == 1 && dz) || (H == 1 && dy) || (W == 1 && dx));
         const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
-        bool mv = tap_live && m < M, xv = false;
-        size_t gbase = 0, xb = 0;
+        const bool mv = tap_live && m < M;
+        bool xv = false;
+        size_t gbase = 0, xb = 0;      // clamped: voxel 0 of sample 0 when this lane has nothing to load
         if (mv) {
-            int n = m / DHW, sp = m - n * DHW;
-            int d = sp / HW, r = sp - d * HW;
-            int h = r / W, w_ = r - h * W;
+            const bool small = M < (1 << 24);
+            int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+            int sp = m - n * DHW;
+            int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            int r = sp - d * HW;
+            int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            int w_ = r - h * W;
             gbase = (size_t)n * Cout * DHW + sp;
             int dd = d + dz, hh = h + dy, ww = w_ + dx;
             xv = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            xb = (size_t)n * Cin * DHW + sp + (ptrdiff_t)(dz * HW + dy * W + dx);
+            xb = (size_t)n * Cin * DHW + sp + (xv ? (ptrdiff_t)(dz * HW + dy * W + dx) : 0);
         }
         const float* __restrict__ gy = gd.y;
         const float* __restrict__ x = gd.x;
+        // unconditional loads from clamped addresses, masked afterwards (no branch + wait per element)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
-            ra[p] = (mv && xv && co < Cout) ? gy[gbase + (size_t)co * DHW] : 0.f;
-            float v = (xv && ci < Cin) ? x[xb + (size_t)ci * DHW] : 0.f;
-            rb[p] = relu_in ? fmaxf(v, 0.f) : v;
+            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
+            rb[p] = x[xb + (size_t)(ci < Cin ? ci : Cin - 1) * DHW];
         }
+        pend_v = xv;
     };
 
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            As[(rl + p * 8) * WG_PITCH + ml] = ra[p];
-            Bs[(rl + p * 8) * WG_PITCH + ml] = rb[p];
+        for (int p = 0; p < 8; ++p) {          // masking + fused ReLU at the LDS write, one chunk after the loads
+            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+            As[(rl + p * 8) * WG_PITCH + ml] = (pend_v && co < Cout) ? ra[p] : 0.f;
+            const float v = (pend_v && ci < Cin) ? rb[p] : 0.f;
+            Bs[(rl + p * 8) * WG_PITCH + ml] = relu_in ? fmaxf(v, 0.f) : v;
         }
         __syncthreads();
         if (q + 1 < q1) load_chunk(q + 1);
@@ -791,6 +837,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
     int q1 = q0 + chunks_per_split;
     if (q1 > nchunks) q1 = nchunks;
     float ra[8], rb[8];
+    bool pend_m = false;
+    uint32_t pend_x = 0;
     auto load_chunk = [&](int q) {
         int gi = 0;
 #pragma unroll
@@ -802,29 +850,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
         const bool mv = m < M;
         int n = 0, sp = 0, d = 0, h = 0, w_ = 0;
         if (mv) {
-            n = m / DHW; sp = m - n * DHW;
-            d = sp / HW; const int r = sp - d * HW;
-            h = r / W; w_ = r - h * W;
+            const bool small = M < (1 << 24);
+            n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+            sp = m - n * DHW;
+            d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            const int r = sp - d * HW;
+            h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            w_ = r - h * W;
         }
         const float* __restrict__ gy = gd.y + (size_t)n * Cout * DHW + sp;
         const float* __restrict__ x = gd.x + (size_t)n * Cin * DHW + sp;
+        bool xv[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < 8; ++p) {          // unconditional loads from clamped addresses
             const int co = co0 + rl + p * 8;
-            ra[p] = (mv && co < Cout) ? gy[(size_t)co * DHW] : 0.f;
+            ra[p] = gy[(size_t)(co < Cout ? co : Cout - 1) * DHW];
             const int dd = d + c_dz[p], hh = h + c_dy[p], ww = w_ + c_dx[p];
             const bool live_tap = !((D == 1 && c_dz[p]) || (H == 1 && c_dy[p]) || (W == 1 && c_dx[p]));
-            const bool xv = mv && c_ok[p] && live_tap && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            float v = xv ? x[(size_t)c_ci[p] * DHW + (ptrdiff_t)(c_dz[p] * HW + c_dy[p] * W + c_dx[p])] : 0.f;
-            rb[p] = relu_in ? fmaxf(v, 0.f) : v;
+            xv[p] = mv && c_ok[p] && live_tap && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            rb[p] = x[(size_t)c_ci[p] * DHW + (xv[p] ? (ptrdiff_t)(c_dz[p] * HW + c_dy[p] * W + c_dx[p]) : 0)];
         }
+        pend_m = mv;
+        pend_x = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) pend_x |= (xv[p] ? 1u : 0u) << p;
     };
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            As[(rl + p * 8) * WG_PITCH + ml] = ra[p];
-            Bs[(rl + p * 8) * WG_PITCH + ml] = rb[p];
+            const int co = co0 + rl + p * 8;
+            As[(rl + p * 8) * WG_PITCH + ml] = (pend_m && co < Cout) ? ra[p] : 0.f;
+            const float v = ((pend_x >> p) & 1u) ? rb[p] : 0.f;
+            Bs[(rl + p * 8) * WG_PITCH + ml] = relu_in ? fmaxf(v, 0.f) : v;
         }
         __syncthreads();
         if (q + 1 < q1) load_chunk(q + 1);

@@ -14,7 +14,9 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world)."""
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world).
+    T2V_DIST_BACKEND overrides the backend (rehearsing the multi-rank path over gloo on one GPU)."""
+    backend = os.environ.get('T2V_DIST_BACKEND', backend)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1 and not dist.is_initialized():
@@ -23,9 +25,16 @@ def init_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+            torch.cuda.set_device(local_device_index())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+def local_device_index():
+    """LOCAL_RANK, or 0 when T2V_SINGLE_DEVICE=1 (several rehearsal ranks sharing one GPU)."""
+    if os.environ.get('T2V_SINGLE_DEVICE', '0') == '1':
+        return 0
+    return int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
 
 
 class GradArena(object):
@@ -65,13 +74,32 @@ class GradArena(object):
             p.grad = v
 
 
+class GradSync(object):
+    """The per-step gradient exchange, split so that `GraphedTrainStep` can capture the device-side parts:
+    pre(which)      p.grad -> arena slices                (kernel launches only: capturable)
+    exchange(which) ONE all_reduce(SUM) of the arena      (collective: stays eager, between graph replays)
+    post(which)     p.grad := arena views, Adam gscale    (host bookkeeping only)
+    `which` is 'D' or 'G'. Calling the object does all three (eager mode)."""
+
+    def __init__(self, arenas, optimizers, world):
+        self.arenas, self.optimizers, self.world = arenas, optimizers, world
+
+    def pre(self, which):
+        self.arenas[which].gather()
+
+    def exchange(self, which):
+        self.arenas[which].all_reduce()
+
+    def post(self, which):
+        self.arenas[which].scatter_as_grads()
+        self.optimizers[which].grad_scale = 1.0 / self.world
+
+    def __call__(self, which):
+        self.pre(which)
+        self.exchange(which)
+        self.post(which)
+
+
 def make_grad_sync(arenas, optimizers, world):
-    """Returns the `grad_sync(which)` callback `train_iteration` calls between backward and step.
-    arenas / optimizers: dicts keyed 'D' / 'G'."""
-    def sync(which):
-        a = arenas[which]
-        a.gather()
-        a.all_reduce()
-        a.scatter_as_grads()
-        optimizers[which].grad_scale = 1.0 / world
-    return sync
+    """arenas / optimizers: dicts keyed 'D' / 'G'."""
+    return GradSync(arenas, optimizers, world)

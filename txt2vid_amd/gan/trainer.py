@@ -164,14 +164,21 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.draws.rewind()
+        gs = self.grad_sync
         with torch.cuda.graph(g1, stream=self.side):
             self.ts.part_d(self.x, None)
-        if self.grad_sync is not None:
-            self.grad_sync('D')
+            if gs is not None:
+                gs.pre('D')                 # p.grad -> arena: captured (the replayed backward rewrites the same buffers)
+        if gs is not None:
+            gs.exchange('D')
+            gs.post('D')                    # Adam (captured next) reads the arena views
         with torch.cuda.graph(g2, pool=g1.pool(), stream=self.side):
             self.ts.part_g()
-        if self.grad_sync is not None:
-            self.grad_sync('G')
+            if gs is not None:
+                gs.pre('G')
+        if gs is not None:
+            gs.exchange('G')
+            gs.post('G')
         with torch.cuda.graph(g3, pool=g1.pool(), stream=self.side):
             self.ts.part_end()
         torch.cuda.synchronize()
@@ -196,10 +203,10 @@ class GraphedTrainStep(object):
             else:
                 self.graphs[0].replay()
                 if self.grad_sync is not None:
-                    self.grad_sync('D')
+                    self.grad_sync.exchange('D')
                 self.graphs[1].replay()
                 if self.grad_sync is not None:
-                    self.grad_sync('G')
+                    self.grad_sync.exchange('G')
                 self.graphs[2].replay()
             self.n += 1
         finally:

@@ -22,7 +22,8 @@ def set_cuda(use_cuda=False):
         warn('cuda is available')
     if not use_cuda:
         raise SystemExit('the MI355X hot path has no CPU training mode: pass --cuda (the reference has none either, SURVEY §8a defect 8)')
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from ..dist import local_device_index
+    local = local_device_index()
     torch.cuda.set_device(local)
     return torch.device('cuda', local)
 
