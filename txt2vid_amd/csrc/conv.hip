@@ -15,6 +15,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// XCD-aware workgroup remap (bijective for any count): the dispatcher deals workgroups round-robin over the 8
+// XCDs, each with a private L2; id -> slot such that the workgroups of ONE XCD own a contiguous range of slots,
+// so that neighbours in the slot order (adjacent voxel tiles sharing halos, the taps of one k-split) share an L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // q = m / d for 0 <= m < 2^24 via the float reciprocal (+-1 fix-up): ~8 VALU instead of the ~40 of an
 // integer division. The per-chunk voxel decode of the weight-gradient kernels runs three of these per lane.
 __device__ __forceinline__ int fast_div(int m, int d, float rcp) {
@@ -208,16 +216,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
 
     // ---- which group does this m-tile belong to (block-uniform scan of <= 8 entries)
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int gi = 0;
 #pragma unroll
     for (int k = 1; k < T2V_MAX_GROUPS; ++k)
-        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
     const t2v_conv_group& gd = tab.g[gi];
     const float* __restrict__ x = gd.x;
     const int D = gd.D, H = gd.H, W = gd.W;
     const int HW = H * W, DHW = D * HW;
     const int M = gd.N * DHW;
-    const int m0 = ((int)blockIdx.x - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
     const int ntaps = gd.ntaps;
 
     if (tid < ntaps) {
@@ -272,7 +281,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     // that nothing consumes the loads before the MFMAs of the current chunk have been issued.
     const float* wp_safe = wp;
     uint32_t pend_a = 0;           // validity bits of the pending chunk's A elements
+    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
     auto load_chunk = [&](int q, int t, int c0) {
+        if (dbg_noload && q != q0) return;
         if (FAST) {
             const bool v = (tapmask >> t) & 1u;
             pend_a = v ? 0xFFFFFFFFu : 0u;
@@ -353,7 +364,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     for (int q = q0; q < q1; ++q) {
         const float* as = As + cur * (BKT * BM);
         const float* bs = Bs + cur * (BKT * BN);
-#pragma unroll 8
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
         for (int k2 = 0; k2 < BKT / 2; ++k2) {
             float a[NCO], b[NM];
             const int krow = k2 * 2 + hi;
@@ -367,7 +379,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
                 for (int j = 0; j < NM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (q + 1 < q1) stage(cur ^ 1);
+        __builtin_amdgcn_s_setprio(0);
+        if (q + 1 < q1 && !dbg_nostage) stage(cur ^ 1);
         __syncthreads();
         if (q + 2 < q1) { advance(); load_chunk(q + 2, t_cur, c_cur); }
         cur ^= 1;
@@ -604,6 +617,9 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     ConvPlan p;
     if (!wp || !build_table(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+#ifdef T2V_ABLATION
+    if (const char* e = getenv("T2V_DEBUG_FLAGS")) flags |= atoi(e);     // developer ablations (wrong results)
+#endif
     int nslots;
     const bool thin = thin_ok(groups, ngroups, Cin, Cout, nslots);
     if (!thin && p.S > 1 && !ws) return T2V_EINVAL;
@@ -686,7 +702,7 @@ extern "C" int t2v_conv_fwd(const float* x, const float* wp, const float* bias, 
 // the concatenated chunk list of all groups; groups for which tap t only touches padding are skipped.
 // ------------------------------------------------------------------------------------------------
 #define WG_BK 32
-#define WG_PITCH (WG_BK + 1)
+#define WG_PITCH (WG_BK + 1)   // odd pitch: conflict-free column reads (ds_read_b32); b128 reads measured 5 % slower
 
 struct WGroupTable {
     t2v_conv_group g[T2V_MAX_GROUPS];          // x = layer input, y = dL/dy (read only here)
@@ -699,16 +715,19 @@ struct LiveTaps { int8_t t[T2V_MAX_TAPS]; int32_t n; };   // slab slot j -> orig
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                          const int Cout, const int T, const int kH, const int kW,
                                                          const int flags, const int chunks_per_split, const LiveTaps live) {
-    __shared__ float As[64 * WG_PITCH];   // gy^T tile  [co][m]
-    __shared__ float Bs[64 * WG_PITCH];   // x   tile   [ci][m]
+    __shared__ __attribute__((aligned(16))) float As[64 * WG_PITCH];   // gy^T tile  [co][m]
+    __shared__ __attribute__((aligned(16))) float Bs[64 * WG_PITCH];   // x   tile   [ci][m]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave & 1, wci = wave >> 1;
     const int nco_t = (Cout + 63) / 64;
     const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
-    const int t = live.t[blockIdx.y];   // ORIGINAL tap index of slab slot blockIdx.y
-    const int split = blockIdx.z;
+    // (slot, split) from an XCD-aware linear id: the taps of one k-split (same x / gy voxels) share an L2
+    const int lin = xcd_remap((int)(blockIdx.y + blockIdx.z * gridDim.y), (int)(gridDim.y * gridDim.z));
+    const int slot = lin % (int)gridDim.y;
+    const int split = lin / (int)gridDim.y;
+    const int t = live.t[slot];         // ORIGINAL tap index of slab slot
     const bool relu_in = flags & T2V_CONV_RELU_IN;
     // offset of original tap t (k in {1,3} per dim, centred)
     const int kD = T / (kH * kW);
@@ -727,7 +746,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 
     float ra[8], rb[8];
     bool pend_v = false;
+    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
     auto load_chunk = [&](int q) {
+        if (dbg_noload && q != q0) return;
         int gi = 0;
 #pragma unroll
         for (int k = 1; k < T2V_MAX_GROUPS; ++k)
@@ -767,6 +788,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
+        if (!(dbg_nostage && q != q0))
 #pragma unroll
         for (int p = 0; p < 8; ++p) {          // masking + fused ReLU at the LDS write, one chunk after the loads
             const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
@@ -788,7 +810,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
     // slab[((split*nlive + slot)*Cout + co)*Cin + ci]; rows = co (registers), cols = ci (lanes)
     const int ci = ci0 + wci * 32 + l31;
     if (ci < Cin) {
-        float* ps = slab + ((size_t)split * live.n + blockIdx.y) * Cout * Cin + ci;
+        float* ps = slab + ((size_t)split * live.n + slot) * Cout * Cin + ci;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -803,8 +825,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                               const int Cout, const int T, const int kH, const int kW,
                                                               const int flags, const int chunks_per_split, const LiveTaps live) {
-    __shared__ float As[64 * WG_PITCH];   // gy^T tile  [co][m]
-    __shared__ float Bs[64 * WG_PITCH];   // x   tile   [col][m]
+    __shared__ __attribute__((aligned(16))) float As[64 * WG_PITCH];   // gy^T tile  [co][m]
+    __shared__ __attribute__((aligned(16))) float Bs[64 * WG_PITCH];   // x   tile   [col][m]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave & 1, wcl = wave >> 1;
@@ -994,6 +1016,9 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     WgradPlan p;
     if (!dw || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+#ifdef T2V_ABLATION
+    if (const char* e = getenv("T2V_DEBUG_FLAGS")) flags |= atoi(e);     // developer ablations (wrong results)
+#endif
     const int T = kD * kH * kW;
     TapMap map;
     LiveTaps live;

@@ -1593,11 +1593,14 @@ def _zeros_like(t):
 
 
 class ConvG(Function):
-    """ys = [conv(relu?(x), w) + b for x in xs] in one launch."""
+    """ys = [conv(relu?(x), w) + b for x in xs] in one launch. The backward only touches the members that
+    actually received a gradient AND need one: members that ride along for the forward only (detached real
+    clips next to the generated ones; the gradient-penalty clips next to the real||fake batch) cost nothing."""
 
     @staticmethod
     def forward(ctx, w, b, relu_in, *xs):
         ctx.save_for_backward(w, *xs)
+        ctx.set_materialize_grads(False)          # members nobody differentiates arrive as None, not as zeros
         ctx.has_bias, ctx.relu_in = b is not None, relu_in
         return tuple(conv_group_raw(xs, w, b, relu_in, 0))
 
@@ -1605,18 +1608,21 @@ class ConvG(Function):
     def backward(ctx, *gys):
         saved = ctx.saved_tensors
         w, xs = saved[0], saved[1:]
-        gys = [g if g is not None else _zeros_like(conv_out_like(x, w)) for g, x in zip(gys, xs)]
+        live = [i for i, g in enumerate(gys) if g is not None]
         gxs = [None] * len(xs)
         gw = gb = None
-        if any(ctx.needs_input_grad[3:]):
-            gxs = list(ConvDgradG.apply(w, *gys))
-            if ctx.relu_in:
-                gxs = [ReluMask.apply(g, x) for g, x in zip(gxs, xs)]
+        if not live:
+            return (None, None, None) + tuple(gxs)
+        need = [i for i in live if ctx.needs_input_grad[3 + i]]
+        if need:
+            res = ConvDgradG.apply(w, *[gys[i] for i in need])
+            for i, r in zip(need, res):
+                gxs[i] = ReluMask.apply(r, xs[i]) if ctx.relu_in else r
         if _param_grads_enabled:
             if ctx.needs_input_grad[0]:
-                gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(xs), *(list(xs) + list(gys)))
+                gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *([xs[i] for i in live] + [gys[i] for i in live]))
             if ctx.has_bias and ctx.needs_input_grad[1]:
-                gb = ChannelSumG.apply(*gys)
+                gb = ChannelSumG.apply(*[gys[i] for i in live])
         return (gw, gb, None) + tuple(gxs)
 
 
@@ -1628,20 +1634,25 @@ class ConvDgradG(Function):
     @staticmethod
     def forward(ctx, w, *gys):
         ctx.save_for_backward(w, *gys)
+        ctx.set_materialize_grads(False)
         return tuple(conv_group_raw(gys, w, None, False, 1))
 
     @staticmethod
     def backward(ctx, *ggxs):
         saved = ctx.saved_tensors
         w, gys = saved[0], saved[1:]
-        ggxs = [g if g is not None else _zeros_like(torch.empty((y.shape[0], w.shape[1]) + tuple(y.shape[2:]), device=y.device))
-                for g, y in zip(ggxs, gys)]
+        live = [i for i, g in enumerate(ggxs) if g is not None]
         d_w = None
         d_gys = [None] * len(gys)
+        if not live:
+            return (None,) + tuple(d_gys)
         if ctx.needs_input_grad[0] and _param_grads_enabled:
-            d_w = ConvWgradG.apply(tuple(w.shape), False, len(gys), *(list(ggxs) + list(gys)))
-        if any(ctx.needs_input_grad[1:]):
-            d_gys = list(ConvG.apply(w, None, False, *ggxs))
+            d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *([ggxs[i] for i in live] + [gys[i] for i in live]))
+        need = [i for i in live if ctx.needs_input_grad[1 + i]]
+        if need:
+            res = ConvG.apply(w, None, False, *[ggxs[i] for i in need])
+            for i, r in zip(need, res):
+                d_gys[i] = r
         return (d_w,) + tuple(d_gys)
 
 
@@ -1662,12 +1673,16 @@ class ConvWgradG(Function):
         xs, gys = saved[:n], saved[n:]
         d_xs = [None] * n
         d_gys = [None] * n
-        if any(ctx.needs_input_grad[3:3 + n]):
-            d_xs = list(ConvDgradG.apply(ggw, *gys))
-            if relu_in:
-                d_xs = [ReluMask.apply(g, x) for g, x in zip(d_xs, xs)]
-        if any(ctx.needs_input_grad[3 + n:]):
-            d_gys = list(ConvG.apply(ggw, None, relu_in, *xs))
+        need_x = [i for i in range(n) if ctx.needs_input_grad[3 + i]]
+        if need_x:
+            res = ConvDgradG.apply(ggw, *[gys[i] for i in need_x])
+            for i, r in zip(need_x, res):
+                d_xs[i] = ReluMask.apply(r, xs[i]) if relu_in else r
+        need_g = [i for i in range(n) if ctx.needs_input_grad[3 + n + i]]
+        if need_g:
+            res = ConvG.apply(ggw, None, relu_in, *[xs[i] for i in need_g])
+            for i, r in zip(need_g, res):
+                d_gys[i] = r
         return (None, None, None) + tuple(d_xs) + tuple(d_gys)
 
 
@@ -1700,3 +1715,33 @@ class ChannelSumG(Function):
 def conv_group(xs, w, b=None, relu_in=False):
     """[conv(relu?(x), w) + b for x in xs] with ONE kernel launch (5-D tensors sharing w)."""
     return list(ConvG.apply(w, b, relu_in, *xs))
+
+
+# ------------------------------------------------------------------------------------------------
+# Undefined gradients stay undefined. A grouped convolution returns None for the members nobody
+# differentiates; by default autograd would turn that None into a zeros tensor at the next per-member node
+# and the whole (useless) backward of that member would run on zeros. Every single-output Function of the
+# discriminator path therefore declares `set_materialize_grads(False)` and passes None straight through.
+# ------------------------------------------------------------------------------------------------
+
+def _pass_none_through(cls):
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx.set_materialize_grads(False)
+        ctx._t2v_n_in = len(args)
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return (None,) * ctx._t2v_n_in
+        return bwd(ctx, *grads)
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
+for _cls in (Conv, ConvDgrad, ConvWgrad, ReluConv, ReluConvWgrad, Relu, ReluMask, Add, AvgPool3d, AvgPool3dBwd, MaxPool2x2,
+             MaxScatter, MaxGather, RowSum, RowBcast, Bmm, Softmax, SoftmaxBwd, Dot, ScaleDev, CatFeatures, SliceCols,
+             EmbedCols, CatBatch, ConvWgradG):
+    _pass_none_through(_cls)

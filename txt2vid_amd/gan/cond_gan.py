@@ -34,6 +34,8 @@ class CondGan(object):
     def discrim_forward(self, name=None, discrim=None, real=None, real_mapping=None, fake=None, fake_mapping=None,
                         real_cond=None, fake_cond=None, loss=None, gp_lambda=-1):
         """cond_gan.py:34-87."""
+        if loss is not None and real is not None and fake is not None and _fusable(discrim, real, fake):
+            return self._discrim_forward_fused(discrim, real, fake, real_cond, fake_cond, loss, gp_lambda)
         fake_pred = real_pred = l = None
         if real_cond is not None and fake_cond is not None:
             real_cc = discrim(x=real, cond=real_cond, xbar=None)
@@ -52,17 +54,10 @@ class CondGan(object):
                 # (lu + (l1 + l2)/2) / 2
                 l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
         else:
-            if real is not None and fake is not None and _can_batch(real, fake):
-                # D has no batch-coupled op (no BatchNorm; the non-local block is per sample), so
-                # D(cat(real, fake)) == cat(D(real), D(fake)): one pass per level instead of two.
-                both = discrim(x=[TF.cat_batch(r, f) for r, f in zip(real, fake)], cond=None, xbar=None)
-                real_pred = [TF.head_rows(o[0], r.size(0)) for o, r in zip(both, real)]
-                fake_pred = [TF.tail_rows(o[0], r.size(0)) for o, r in zip(both, real)]
-            else:
-                if real is not None:
-                    real_pred = [r[0] for r in discrim(x=real, cond=None, xbar=None)]
-                if fake is not None:
-                    fake_pred = [f[0] for f in discrim(x=fake, cond=None, xbar=None)]
+            if real is not None:
+                real_pred = [r[0] for r in discrim(x=real, cond=None, xbar=None)]
+            if fake is not None:
+                fake_pred = [f[0] for f in discrim(x=fake, cond=None, xbar=None)]
             if loss is not None and fake_pred is not None and real_pred is not None:
                 l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(fake_pred, real_pred)])
         if l is not None and gp_lambda > 0:
@@ -70,6 +65,87 @@ class CondGan(object):
                                   scale=self.gp_scale)
             l = TF.scalar_sum([l, gp], weights=[1.0, gp_lambda])
         return l, fake_pred, real_pred
+
+    def _discrim_forward_fused(self, discrim, real, fake, real_cond, fake_cond, loss, gp_lambda):
+        """The whole D-step forward as ONE lock-step pass over up to 8 tensors that share the trunk: the real
+        and generated clips of each pyramid level as one batch (D has no batch-coupled op) and, when the
+        gradient penalty is on, the interpolated clips x_hat of each level. Same arithmetic as the branchy
+        path above; the GP alphas are drawn from the host generator in the same stream position."""
+        n = len(real)
+        cond = real_cond is not None and fake_cond is not None
+        rf = [TF.cat_batch(r, f) for r, f in zip(real, fake)]
+        conds = [TF.cat_batch(c, c) for c in real_cond] if cond else None
+        xhs, chs = [], None
+        if gp_lambda > 0:
+            a_dev = [TF.draws.alpha(real[i].size(0), real[i].dim(), real[i].device) for i in range(n)]
+            xhs = [TF.lerp_rows(a_dev[i], real[i].detach(), fake[i].detach()).requires_grad_(True) for i in range(n)]
+            if cond:
+                chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
+        res = discrim(x=rf + xhs, cond=(conds + chs) if (cond and xhs) else conds, xbar=None)
+        both, gp_res = res[:n], res[n:]
+        b = [r.size(0) for r in real]
+        u_r = [TF.head_rows(o[0], b[i]) for i, o in enumerate(both)]
+        u_f = [TF.tail_rows(o[0], b[i]) for i, o in enumerate(both)]
+        if cond:
+            c_r = [TF.head_rows(o[1], b[i]) for i, o in enumerate(both)]
+            c_f = [TF.tail_rows(o[1], b[i]) for i, o in enumerate(both)]
+            # D(real, mismatched captions): second head on the real half's trunk features
+            trunk = discrim.sub_discrims
+            c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
+            lu = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(u_f, u_r)])
+            l1 = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(c_f, c_r)])
+            l2 = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(c_ic, c_r)])
+            l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
+            real_pred = [(u_r[i], c_r[i], TF.head_rows(both[i][2], b[i])) for i in range(n)]
+            fake_pred = None
+        else:
+            l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(u_f, u_r)])
+            real_pred, fake_pred = u_r, u_f
+        if gp_lambda > 0:
+            outs = []
+            for u, c, _ in gp_res:
+                outs.append(u)
+                if c is not None:
+                    outs.append(c)
+            with TF.input_grads_only():
+                gs = torch.autograd.grad(outputs=outs, inputs=xhs, grad_outputs=[TF.ones_like(o) for o in outs],
+                                         create_graph=True, retain_graph=True, only_inputs=True)
+            gp = TF.scalar_sum([TF.vec_sum(TF.row_sqnorm(g), self.gp_scale) for g in gs])
+            l = TF.scalar_sum([l, gp], weights=[1.0, gp_lambda])
+        return l, fake_pred, real_pred
+
+    def gen_step_fused(self, fake=None, real=None, cond=None, loss=None):
+        """`all_discrim_forward(real)` + `gen_step(fake, real_pred)` (trainer.py:247-263) as ONE lock-step pass
+        of the frozen, freshly updated D over the generated AND the (detached) real clips: identical values,
+        half the launches; the backward only runs through the generated half."""
+        self.gen.zero_grad()
+        if self.cond_encoder is not None:
+            self.cond_encoder.zero_grad()
+        if cond is not None:
+            gen_perm(cond[0].size(0))                 # the reference's all_discrim_forward draws a permutation here
+        losses = []
+        n = len(fake)
+        for name, discrim in zip(self.discrim_names, self.discrims):
+            frozen = [p for p in discrim.parameters() if p.requires_grad]
+            for p in frozen:
+                p.requires_grad_(False)
+            try:
+                res = discrim(x=list(fake) + [r.detach() for r in real], cond=None if cond is None else list(cond) + list(cond),
+                              xbar=None)
+            finally:
+                for p in frozen:
+                    p.requires_grad_(True)
+            fk, rl = res[:n], res[n:]
+            if cond is None:
+                losses.append(TF.scalar_mean([loss(fake=ff[0], real=rr[0].detach()) for ff, rr in zip(fk, rl)]))
+            else:
+                lu = TF.scalar_mean([loss(fake=ff[0], real=rr[0].detach()) for ff, rr in zip(fk, rl)])
+                lc = TF.scalar_mean([loss(fake=ff[1], real=rr[1].detach()) for ff, rr in zip(fk, rl)])
+                losses.append(TF.scalar_sum([lc, lu], weights=[0.5, 0.5]))
+        return self._discrim_weighted_sum(losses)
+
+    def can_fuse_gen_step(self, fake, real):
+        return all(_fusable(d, real, fake) and 2 * len(fake) <= TF.MAX_GROUPS for d in self.discrims)
 
     def gen_step(self, fake=None, real_pred=None, cond=None, loss=None):
         """cond_gan.py:90-118. The uncond branch uses `ff[0]` (the intended semantics; the reference
@@ -158,6 +234,17 @@ class CondGan(object):
 
 def _can_batch(real, fake):
     return all(r.is_cuda and r.shape == f.shape for r, f in zip(real, fake))
+
+
+def _fusable(discrim, real, fake):
+    """Multi-scale discriminator with ONE shared, groupable trunk, device tensors, <= 4 levels."""
+    trunk = getattr(discrim, 'single_discrim', None)
+    if trunk is None or not hasattr(discrim, 'sub_discrims'):
+        return False
+    trunk = getattr(trunk, 'module', trunk)
+    if not (hasattr(trunk, 'groupable') and trunk.groupable()):
+        return False
+    return 1 < len(real) and 2 * len(real) <= TF.MAX_GROUPS and _can_batch(real, fake)
 
 
 def _match_keys(sd, want):

@@ -104,12 +104,15 @@ class TrainStep(object):
         # D after its update, on the real batch (trainer.py:247). Its graph is only needed when the text
         # encoder trains end-to-end; otherwise nothing upstream of these predictions receives a gradient
         # that is ever used, so none is recorded (identical results, SURVEY §7 "wasted work").
-        if self.end2end:
-            _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
+        if not self.end2end and self.gan.can_fuse_gen_step(self.fake, self.xs):
+            loss = self.gan.gen_step_fused(fake=self.fake, real=self.xs, cond=self.conds, loss=self.losses.gen_loss)
         else:
-            with torch.no_grad():
+            if self.end2end:
                 _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
-        loss = self.gan.gen_step(fake=self.fake, real_pred=real_pred, cond=self.conds, loss=self.losses.gen_loss)
+            else:
+                with torch.no_grad():
+                    _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
+            loss = self.gan.gen_step(fake=self.fake, real_pred=real_pred, cond=self.conds, loss=self.losses.gen_loss)
         loss.backward()
         self.lG = loss.detach()
 
