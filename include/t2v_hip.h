@@ -116,7 +116,8 @@ int t2v_tanh_bwd(const float* g, const float* y, float* gx, int64_t n, void* str
 
 /* avg_pool3d with per-dim kernel/stride/pad, count_include_pad=True (layers.py:217, resnet3d.py:16).
  * bwd scatters g/(kd*kh*kw) back (windows never overlap on this path: stride >= kernel). */
-int t2v_avgpool3d(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+/* x2 != NULL: y = pool(x + x2) — the residual add fused into the block's DownSample (layers.py:93-96,217). */
+int t2v_avgpool3d(const float* x, const float* x2, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
                   const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
 int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
                       const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);

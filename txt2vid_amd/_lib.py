@@ -59,7 +59,7 @@ SIGNATURES = {
     't2v_fill': [_P, _F, _L, _P],
     't2v_tanh': [_P, _P, _L, _P],
     't2v_tanh_bwd': [_P, _P, _P, _L, _P],
-    't2v_avgpool3d': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
+    't2v_avgpool3d': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
     't2v_avgpool3d_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
     't2v_maxpool2x2': [_P, _P, _P, _L, _I, _I, _P],
     't2v_maxpool2x2_scatter': [_P, _P, _P, _L, _I, _I, _P],

@@ -515,6 +515,51 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GroupTable tab, co
     }
 }
 
+
+// Linear head with <= 4 outputs (resnet3d.py:33-35: 1024(+cond) -> 1): one WAVE per input row, lanes stride over the
+// features (coalesced), wavefront reduction. (The voxel-per-lane kernel above would walk a 4 KB-strided row per lane.)
+template <int NC>
+__global__ __launch_bounds__(256) void linear_thin_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, const int Cin, const int Cout,
+                                                          const int flags) {
+    const int lane = threadIdx.x & 63;
+    const int row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);     // rows of all members, concatenated
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && row >= tab.tile_start[k]) gi = k;
+    if (row >= tab.tile_start[tab.n]) return;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int r = row - tab.tile_start[gi];
+    const float* __restrict__ px = gd.x + (size_t)r * Cin;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    for (int ci = lane; ci < Cin; ci += 64) {
+        float v = px[ci];
+        if (relu_in) v = fmaxf(v, 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < Cout) acc[c] += v * wp[(size_t)ci * Cout + c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    if (lane == 0) {
+        const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
+        const bool accum = flags & T2V_CONV_ACCUM;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < Cout) {
+                float v = acc[c] + (has_bias ? bias[c] : 0.f);
+                float* p = gd.y + (size_t)r * Cout + c;
+                *p = accum ? *p + v : v;
+            }
+    }
+}
+
 static bool thin_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int& nslots) {
     if (Cout > 4) return false;
     nslots = 0;
@@ -608,6 +653,11 @@ extern "C" int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, 
     if (!build_table(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
     int nslots;
     if (thin_ok(groups, ngroups, Cin, Cout, nslots)) return 0;
+    if (Cout <= 4) {
+        bool pl = true;
+        for (int i = 0; i < ngroups; ++i) pl = pl && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1 && groups[i].ntaps == 1;
+        if (pl) return 0;
+    }
     return p.S > 1 ? (int64_t)p.S * tab.out_start[ngroups] : 0;
 }
 
@@ -631,6 +681,18 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     for (int i = 0; i < ngroups; ++i) {
         Mtot_ += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
         if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
+    }
+    bool pure_linear = Cout <= 4;
+    for (int i = 0; i < ngroups; ++i)
+        pure_linear = pure_linear && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1 && groups[i].ntaps == 1 && groups[i].widx[0] == 0;
+    if (pure_linear) {
+        long rows = 0;
+        for (int i = 0; i < ngroups; ++i) { tab.tile_start[i] = (int32_t)rows; rows += groups[i].N; }
+        for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)rows;
+        ProfScope prof(3, flops, s, Mtot_, Cin, Cout, 1, ngroups, 1);
+        if (Cout == 1) T2V_LAUNCH(linear_thin_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
+        else T2V_LAUNCH(linear_thin_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
+        return launch_status();
     }
     if (thin) {
         // re-tile for 256 voxels per workgroup

@@ -123,7 +123,8 @@ extern "C" int t2v_dot(const float* a, const float* b, float* out, float* ws, in
 // ---------------------------------------------------------------- avg-pool (count_include_pad)
 struct Pool3 { int k[3], s[3], p[3]; };
 
-__global__ void avgpool3d_k(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo, Pool3 q) {
+// x2 != nullptr: y = pool(x + x2) (the residual add of DownBlock fused into its DownSample: pooling is linear)
+__global__ void avgpool3d_k(const float* x, const float* x2, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo, Pool3 q) {
     const long n = (long)NC * Do * Ho * Wo;
     const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
     GRID_STRIDE(i, n) {
@@ -131,6 +132,7 @@ __global__ void avgpool3d_k(const float* x, float* y, int NC, int D, int H, int 
         int ho = r % Ho; r /= Ho;
         int d_o = r % Do; long nc = r / Do;
         const float* px = x + nc * (long)D * H * W;
+        const float* px2 = x2 ? x2 + nc * (long)D * H * W : nullptr;
         float acc = 0.f;
         for (int a = 0; a < q.k[0]; ++a) {
             int d = d_o * q.s[0] - q.p[0] + a;
@@ -141,7 +143,8 @@ __global__ void avgpool3d_k(const float* x, float* y, int NC, int D, int H, int 
                 for (int c = 0; c < q.k[2]; ++c) {
                     int w = wo * q.s[2] - q.p[2] + c;
                     if ((unsigned)w >= (unsigned)W) continue;
-                    acc += px[((long)d * H + h) * W + w];
+                    const long o = ((long)d * H + h) * W + w;
+                    acc += px2 ? px[o] + px2[o] : px[o];
                 }
             }
         }
@@ -181,17 +184,32 @@ __global__ void avgpool3d_bwd_k(const float* gy, float* gx, int NC, int D, int H
         gx[i] = acc * inv;
     }
 }
+// non-overlapping, unpadded windows (kernel <= stride, the only kind on the hot path): every input voxel belongs
+// to at most one window -> one read, no divisibility tests
+__global__ void avgpool3d_bwd_simple_k(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo, Pool3 q) {
+    const long n = (long)NC * D * H * W;
+    const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
+    GRID_STRIDE(i, n) {
+        int w = i % W; long r = i / W;
+        int h = r % H; r /= H;
+        int d = r % D; long nc = r / D;
+        const int d_o = d / q.s[0], ho = h / q.s[1], wo = w / q.s[2];
+        const bool in = (d - d_o * q.s[0] < q.k[0]) && (h - ho * q.s[1] < q.k[1]) && (w - wo * q.s[2] < q.k[2]) &&
+                        d_o < Do && ho < Ho && wo < Wo;
+        gx[i] = in ? gy[((nc * Do + d_o) * Ho + ho) * (long)Wo + wo] * inv : 0.f;
+    }
+}
 static bool pool_ok(const int32_t* k, const int32_t* s, const int32_t* p) {
     for (int i = 0; i < 3; ++i)
         if (k[i] < 1 || k[i] > 4 || s[i] < 1 || p[i] < 0) return false;
     return true;
 }
-extern "C" int t2v_avgpool3d(const float* x, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
+extern "C" int t2v_avgpool3d(const float* x, const float* x2, float* y, int NC, int D, int H, int W, int Do, int Ho, int Wo,
                              const int32_t k[3], const int32_t s[3], const int32_t p[3], void* st) {
     if (!x || !y || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
     Pool3 q;
     for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
-    T2V_LAUNCH(avgpool3d_k, dim3(nblocks((long)NC * Do * Ho * Wo)), dim3(256), 0, S_(st), x, y, NC, D, H, W, Do, Ho, Wo, q);
+    T2V_LAUNCH(avgpool3d_k, dim3(nblocks((long)NC * Do * Ho * Wo)), dim3(256), 0, S_(st), x, x2, y, NC, D, H, W, Do, Ho, Wo, q);
     return launch_status();
 }
 extern "C" int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
@@ -199,7 +217,9 @@ extern "C" int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int 
     if (!gy || !gx || NC < 1 || !pool_ok(k, s, p)) return T2V_EINVAL;
     Pool3 q;
     for (int i = 0; i < 3; ++i) { q.k[i] = k[i]; q.s[i] = s[i]; q.p[i] = p[i]; }
-    T2V_LAUNCH(avgpool3d_bwd_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
+    const bool simple = p[0] == 0 && p[1] == 0 && p[2] == 0 && k[0] <= s[0] && k[1] <= s[1] && k[2] <= s[2];
+    if (simple) T2V_LAUNCH(avgpool3d_bwd_simple_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
+    else T2V_LAUNCH(avgpool3d_bwd_k, dim3(nblocks((long)NC * D * H * W)), dim3(256), 0, S_(st), gy, gx, NC, D, H, W, Do, Ho, Wo, q);
     return launch_status();
 }
 

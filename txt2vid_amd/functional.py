@@ -512,13 +512,38 @@ class AvgPool3d(Function):
         ctx.cfg = (k, s, p, (D, H, W))
         y = torch.empty((N, Cc, Do, Ho, Wo), device=x.device, dtype=torch.float32)
         ka, sa, pa = _pool_args(k, s, p)
-        check(lib().t2v_avgpool3d(_p(x), _p(y), N * Cc, D, H, W, Do, Ho, Wo, ka, sa, pa, _stream()), 't2v_avgpool3d')
+        check(lib().t2v_avgpool3d(_p(x), None, _p(y), N * Cc, D, H, W, Do, Ho, Wo, ka, sa, pa, _stream()), 't2v_avgpool3d')
         return y
 
     @staticmethod
     def backward(ctx, g):
         k, s, p, in_sp = ctx.cfg
         return AvgPool3dBwd.apply(g, k, s, p, in_sp), None, None, None
+
+
+class AddAvgPool3d(Function):
+    """pool(a + b) in one kernel (DownBlock: DownSample(skip) + DownSample(main) == DownSample(skip + main))."""
+
+    @staticmethod
+    def forward(ctx, a, b, k, s, p):
+        a, b = _c(a), _c(b)
+        N, Cc, D, H, W = a.shape
+        Do, Ho, Wo = _pool_out(D, k[0], s[0], p[0]), _pool_out(H, k[1], s[1], p[1]), _pool_out(W, k[2], s[2], p[2])
+        ctx.cfg = (k, s, p, (D, H, W))
+        y = torch.empty((N, Cc, Do, Ho, Wo), device=a.device, dtype=torch.float32)
+        ka, sa, pa = _pool_args(k, s, p)
+        check(lib().t2v_avgpool3d(_p(a), _p(b), _p(y), N * Cc, D, H, W, Do, Ho, Wo, ka, sa, pa, _stream()), 't2v_avgpool3d')
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        k, s, p, in_sp = ctx.cfg
+        gx = AvgPool3dBwd.apply(g, k, s, p, in_sp)
+        return gx, gx, None, None, None
+
+
+def add_avg_pool3d(a, b, k, s, p=(0, 0, 0)):
+    return AddAvgPool3d.apply(a, b, tuple(k), tuple(s), tuple(p))
 
 
 class AvgPool3dBwd(Function):
@@ -1741,7 +1766,7 @@ def _pass_none_through(cls):
     return cls
 
 
-for _cls in (Conv, ConvDgrad, ConvWgrad, ReluConv, ReluConvWgrad, Relu, ReluMask, Add, AvgPool3d, AvgPool3dBwd, MaxPool2x2,
+for _cls in (Conv, ConvDgrad, ConvWgrad, ReluConv, ReluConvWgrad, Relu, ReluMask, Add, AvgPool3d, AddAvgPool3d, AvgPool3dBwd, MaxPool2x2,
              MaxScatter, MaxGather, RowSum, RowBcast, Bmm, Softmax, SoftmaxBwd, Dot, ScaleDev, CatFeatures, SliceCols,
              EmbedCols, CatBatch, ConvWgradG):
     _pass_none_through(_cls)

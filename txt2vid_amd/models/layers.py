@@ -235,18 +235,32 @@ class UpBlock(nn.Module):
         return x
 
 
+def downsample_cfg(x):
+    """kernel / stride / padding of `DownSample` for this tensor — layers.py:202-215."""
+    k, s, p = [1, 1, 1], [1, 1, 1], [0, 0, 0]
+    for i in range(3):
+        n = x.size(i + 2)
+        if n == 1:
+            continue
+        k[i] = s[i] = 2
+        if n % 2:
+            p[i] = 1
+    return k, s, p
+
+
+def downsample_sum(a, b):
+    """DownSample(a) + DownSample(b) == DownSample(a + b) (average pooling is linear): one fused kernel."""
+    k, s, p = downsample_cfg(a)
+    if k == [1, 1, 1]:
+        return TF.add(a, b)
+    return TF.add_avg_pool3d(a, b, k, s, p)
+
+
 class DownSample(nn.Module):
     """Average-pool by 2 every spatial/temporal dim of extent > 1 (pad 1 if odd) — layers.py:197-217."""
 
     def forward(self, x):
-        k, s, p = [1, 1, 1], [1, 1, 1], [0, 0, 0]
-        for i in range(3):
-            n = x.size(i + 2)
-            if n == 1:
-                continue
-            k[i] = s[i] = 2
-            if n % 2:
-                p[i] = 1
+        k, s, p = downsample_cfg(x)
         if k == [1, 1, 1]:
             return x
         return TF.avg_pool3d(x, k, s, p)
@@ -270,7 +284,10 @@ class DownBlock(nn.Module):
         if isinstance(m[1], Conv3d) and isinstance(m[3], Conv3d):
             h = TF.relu_conv(x, m[1].weight, m[1].bias)            # ReLU fused into the conv gather
             h = TF.relu_conv(h, m[3].weight, m[3].bias)
-            return TF.add(self.main.identity_map(x), m[4](h))
+            idm = self.main.identity_map
+            if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
+                return downsample_sum(idm[0](x), h)
+            return TF.add(idm(x), m[4](h))
         return self.main(x)
 
 
@@ -281,6 +298,8 @@ def down_block_levels(block, xs):
     hs = TF.conv_group(xs, m[1].weight, m[1].bias, relu_in=True)
     hs = TF.conv_group(hs, m[3].weight, m[3].bias, relu_in=True)
     ss = TF.conv_group(xs, idm[0].weight, idm[0].bias)
+    if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
+        return [downsample_sum(s_, h) for s_, h in zip(ss, hs)]
     return [TF.add(idm[1](s_), m[4](h)) for s_, h in zip(ss, hs)]
 
 
