@@ -992,6 +992,167 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient, kW = 3: one workgroup computes the three taps dx = -1, 0, +1 of one (dz, dy) kernel row.
+// They multiply the SAME dL/dy tile and x rows that differ by a one-voxel shift, so dL/dy is staged once and x
+// once as a 34-column strip (the 32 voxels of the chunk plus one on either side, by linear index); the three taps
+// read the strip at column offsets 0/1/2 and out-of-row neighbours are zeroed with per-chunk ballot masks.
+// 17 gathers per lane feed 48 MFMAs per wave (the per-tap kernel: 16 gathers per 16 MFMAs).
+// ------------------------------------------------------------------------------------------------
+#define W3_AP (WG_BK + 1)      // dL/dy tile pitch
+#define W3_BP (WG_BK + 3)      // x strip pitch: 34 columns + 1 pad (odd)
+struct LiveRows { int8_t r[9]; int32_t n; };    // slab row slot -> original kernel row (dz,dy) index a*kH + b
+
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                          const int Cout, const int kD, const int kH, const int flags,
+                                                          const int chunks_per_split, const LiveRows live) {
+    __shared__ float As[64 * W3_AP];   // gy^T tile [co][m]
+    __shared__ float Bs[3 * 64 * W3_AP];   // three shifted + masked copies of the x tile: [dx][ci][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int nco_t = (Cout + 63) / 64;
+    const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
+    const int lin = xcd_remap((int)(blockIdx.y + blockIdx.z * gridDim.y), (int)(gridDim.y * gridDim.z));
+    const int rslot = lin % (int)gridDim.y;
+    const int split = lin / (int)gridDim.y;
+    const int krow = live.r[rslot];
+    const int dz = krow / kH - kD / 2, dy = krow % kH - kH / 2;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    const int ml = tid & 31, rl = tid >> 5;
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+
+    float ra[8], rb[8], rh = 0.f;
+    uint32_t pm0 = 0, pm1 = 0, pm2 = 0;       // pending chunk: validity of (voxel, dx) as 32-bit masks
+    int pend_DHW = 1;
+#ifdef T2V_ABLATION
+    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
+#endif
+    auto load_chunk = [&](int q) {
+#ifdef T2V_ABLATION
+        if (dbg_noload && q != q0) return;
+#endif
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
+        const bool mv = m < M;
+        bool vc = false;
+        int w_ = 0;
+        size_t gbase = 0;
+        ptrdiff_t xb = 0;              // element index of x[n, 0, voxel + (dz,dy,0)] (0 when not loadable)
+        if (mv) {
+            const bool small = M < (1 << 24);
+            const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+            const int sp = m - n * DHW;
+            const int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            const int r = sp - d * HW;
+            const int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            w_ = r - h * W;
+            gbase = (size_t)n * Cout * DHW + sp;
+            vc = (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H;
+            xb = vc ? (ptrdiff_t)((size_t)n * Cin * DHW + sp) + (ptrdiff_t)(dz * HW + dy * W) : 0;
+        }
+        // wave-uniform validity masks (every wave sees the same 32 voxels in lanes 0-31)
+        pm0 = (uint32_t)__ballot(vc && w_ >= 1);
+        pm1 = (uint32_t)__ballot(vc);
+        pm2 = (uint32_t)__ballot(vc && w_ + 1 < W);
+        pend_DHW = DHW;
+        const float* __restrict__ gy = gd.y;
+        const float* __restrict__ x = gd.x;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {           // unconditional loads from clamped addresses
+            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
+            rb[p] = x[xb + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
+        }
+        // the two extra strip columns: linear neighbours of voxel 0 (left) and voxel 31 (right) of the chunk
+        const ptrdiff_t xb_l = __shfl(xb, 0, 64), xb_r = __shfl(xb, 31, 64);
+        const bool use_l = (pm0 & 1u) != 0, use_r = (pm2 >> 31) != 0;
+        if (tid < 128) {
+            const int row = tid >> 1, side = tid & 1;
+            const int ci = ci0 + row;
+            const ptrdiff_t base = side ? (use_r ? xb_r + 1 : 0) : (use_l ? xb_l - 1 : 0);
+            rh = x[base + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
+        }
+    };
+
+    // Staging writes THREE shifted + masked copies of the x strip (dx = -1, 0, +1), so the MFMA loop is four plain
+    // LDS reads per three MFMAs with no per-step mask arithmetic on the vector ALU.
+    const bool m_c = true;
+    (void)m_c;
+    if (q0 < q1) load_chunk(q0);
+    for (int q = q0; q < q1; ++q) {
+#ifdef T2V_ABLATION
+        if (!(dbg_nostage && q != q0))
+#endif
+        {
+            const bool v0 = ml + 1 < WG_BK && ((pm0 >> (ml + 1)) & 1u);   // my voxel is the LEFT neighbour of voxel ml+1
+            const bool v1 = (pm1 >> ml) & 1u;
+            const bool v2 = ml >= 1 && ((pm2 >> (ml - 1)) & 1u);          // ... the RIGHT neighbour of voxel ml-1
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = rl + p * 8;
+                const int co = co0 + row, ci = ci0 + row;
+                As[row * W3_AP + ml] = (co < Cout) ? ra[p] : 0.f;
+                float v = (ci < Cin) ? rb[p] : 0.f;
+                v = relu_in ? fmaxf(v, 0.f) : v;
+                Bs[(1 * 64 + row) * W3_AP + ml] = v1 ? v : 0.f;
+                if (ml + 1 < WG_BK) Bs[(0 * 64 + row) * W3_AP + ml + 1] = v0 ? v : 0.f;
+                if (ml >= 1) Bs[(2 * 64 + row) * W3_AP + ml - 1] = v2 ? v : 0.f;
+            }
+            if (tid < 128) {
+                const int row = tid >> 1, side = tid & 1;
+                float v = (ci0 + row < Cin) ? rh : 0.f;
+                v = relu_in ? fmaxf(v, 0.f) : v;
+                if (side) Bs[(2 * 64 + row) * W3_AP + WG_BK - 1] = ((pm2 >> 31) & 1u) ? v : 0.f;
+                else Bs[(0 * 64 + row) * W3_AP + 0] = (pm0 & 1u) ? v : 0.f;
+            }
+        }
+        __syncthreads();
+        if (q + 1 < q1) load_chunk(q + 1);
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
+            const int kc = k2 * 2 + hi;
+            const float a = As[(wco * 32 + l31) * W3_AP + kc];
+            const float b0 = Bs[(0 * 64 + wci * 32 + l31) * W3_AP + kc];
+            const float b1 = Bs[(1 * 64 + wci * 32 + l31) * W3_AP + kc];
+            const float b2 = Bs[(2 * 64 + wci * 32 + l31) * W3_AP + kc];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // slab[((split*nslots + rslot*3 + dx+1)*Cout + co)*Cin + ci]
+    const int ci = ci0 + wci * 32 + l31;
+    if (ci < Cin) {
+        const size_t CoCi = (size_t)Cout * Cin;
+        float* ps = slab + ((size_t)split * (live.n * 3) + (size_t)rslot * 3) * CoCi + ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) {
+                ps[(size_t)co * Cin] = acc0[r];
+                ps[CoCi + (size_t)co * Cin] = acc1[r];
+                ps[2 * CoCi + (size_t)co * Cin] = acc2[r];
+            }
+        }
+    }
+}
+
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
 
 // dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
@@ -1026,7 +1187,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (long k = threadIdx.x; k < nval; k += 256) p[k] = accum ? p[k] + tile[k] : tile[k];
 }
 
-struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; };
+// Small weights with many k-splits (the 64x64 and 64x1 stem convs: 171-256 partial slabs): one workgroup per
+// (64 pairs, tap); the 4 waves each sum a quarter of the splits and combine through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                 long CoCi, int T, int ntaps, int S, TapMap map, int accum) {
+    __shared__ float part[4][64];
+    const int t = blockIdx.y;
+    const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wv = threadIdx.x >> 6;
+    const int j = map.j[t];
+    float v0 = 0.f, v1 = 0.f;
+    if (j >= 0 && i < CoCi) {
+        const float* p = slab + (size_t)j * CoCi + i;
+        const size_t st = (size_t)ntaps * CoCi;
+        int s = wv;
+        for (; s + 4 < S; s += 8) { v0 += p[(size_t)s * st]; v1 += p[(size_t)(s + 4) * st]; }
+        if (s < S) v0 += p[(size_t)s * st];
+    }
+    part[wv][threadIdx.x & 63] = v0 + v1;
+    __syncthreads();
+    if (wv == 0 && i < CoCi) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float* q = dw + (size_t)i * T + t;
+        *q = accum ? *q + v : v;
+    }
+}
+
+struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; };
 
 static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, bool need_ptrs,
                          WGroupTable& tab, WgradPlan& p) {
@@ -1052,7 +1239,17 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.chunk_start[i] = (int32_t)nch;
     p.nchunks = nch;
     p.nlive = __builtin_popcount(p.live);
-    const long base = (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
+    // kW == 3 with at least one member wider than one voxel: the three dx taps of a kernel row share a workgroup
+    bool anyw = false;
+    for (int i = 0; i < ngroups; ++i) anyw = anyw || groups[i].W > 1;
+    p.rows3 = (kW == 3) && anyw && Cin >= 64;
+    p.liverows = 0;
+    for (int r = 0; r < kD * kH; ++r)
+        if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;
+    p.nrows = __builtin_popcount(p.liverows);
+    if (p.rows3) p.nlive = p.nrows * 3;            // slab slots (dead dx taps of a live row are written as zeros)
+    const long base = p.rows3 ? (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows
+                    : (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
     long S = (1536 + base - 1) / base;            // aim at ~6 workgroups per CU
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
@@ -1089,8 +1286,20 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
         live.t[t] = 0;
         map.j[t] = -1;
     }
-    for (int t = 0; t < T; ++t)
-        if ((p.live >> t) & 1u) { map.j[t] = live.n; live.t[live.n++] = (int8_t)t; }
+    LiveRows lrows;
+    lrows.n = 0;
+    for (int r = 0; r < 9; ++r) lrows.r[r] = 0;
+    if (p.rows3) {
+        for (int r = 0; r < kD * kH; ++r)
+            if ((p.liverows >> r) & 1u) {
+                for (int c = 0; c < 3; ++c) map.j[r * 3 + c] = lrows.n * 3 + c;
+                lrows.r[lrows.n++] = (int8_t)r;
+            }
+        live.n = lrows.n * 3;
+    } else {
+        for (int t = 0; t < T; ++t)
+            if ((p.live >> t) & 1u) { map.j[t] = live.n; live.t[live.n++] = (int8_t)t; }
+    }
     double flops = 0;
     for (int i = 0; i < ngroups; ++i) {
         int live_g = 0;
@@ -1103,7 +1312,10 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     // grid.y runs over the taps at least one member can touch; the others are written as zeros by the reduce
     {
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
-        if (Cin < 64) {
+        if (p.rows3) {
+            dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
+            T2V_LAUNCH(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows);
+        } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
             T2V_LAUNCH(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
         } else {
@@ -1114,9 +1326,13 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     int st = launch_status();
     if (st) return st;
     const long CoCi = (long)Cout * Cin;
-    ProfScope prof2(2, 0.0, s);
-    T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
-               (flags & T2V_CONV_ACCUM) ? 1 : 0);
+    ProfScope prof2(2, 0.0, s, CoCi, Cin, Cout, T, live.n, p.S);
+    if (CoCi <= 16384 && p.S >= 16)
+        T2V_LAUNCH(wgrad_reduce_small_kernel, dim3((unsigned)((CoCi + 63) / 64), (unsigned)T), dim3(256), 0, s, slab, dw, CoCi, T,
+                   live.n, p.S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
+    else
+        T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
+                   (flags & T2V_CONV_ACCUM) ? 1 : 0);
     return launch_status();
 }
 
