@@ -69,6 +69,20 @@ int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const i
 int t2v_pack_weight_into(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
                          int mode, int dst_rows, int dst_cols, int row_off, int col_off, void* stream);
 
+/* Multi-tensor form: ONE launch refreshes every packed variant listed in a device-resident job table (what an
+ * optimiser step invalidates: ~170 small packs per step otherwise). Record layout (t2v_pack_job_bytes() bytes): */
+typedef struct {
+    const float* src;     /* w[Cout][Cin][T] */
+    float* dst;           /* packed matrix base */
+    int32_t Cout, Cin, T, ntaps, mode, dst_rows, dst_cols, row_off, col_off;
+    int32_t block_begin;  /* first workgroup of this job */
+    int32_t bx, by;       /* ceil(Cin/32), ceil(Cout/32); the job owns bx*by*ntaps workgroups */
+    int8_t taps[T2V_MAX_TAPS];
+    int8_t pad_[5];
+} t2v_pack_job;
+int t2v_pack_job_bytes(void);
+int t2v_pack_multi(const void* table /* device t2v_pack_job[njobs] */, int njobs, int total_blocks, void* stream);
+
 /* y[N,Cout,D,H,W] = conv(x[N,Cin,D,H,W], wp) (+bias).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
  * M = N*D*H*W voxels, N = Cout, K = ntaps*Cin.  The same entry point computes the data gradient
  * when given the mode-1 packed weight (x := dL/dy, Cin := Cout_fwd, Cout := Cin_fwd).
@@ -102,6 +116,9 @@ int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, i
 /* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
 int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S);   /* floats of `ws` needed (0: none) */
 int t2v_channel_sum(const float* x, float* out, float* ws, int N, int C, int64_t S, int accum, void* stream);
+/* grouped: the sum runs over every member (groups[i].x = [N_i, C, D_i, H_i, W_i]) — bias gradient of a grouped conv */
+int64_t t2v_channel_sum_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int C);
+int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups, int C, float* out, float* ws, int accum, void* stream);
 
 /* ---- pointwise / pooling (txt2vid/models/layers.py, resnet3d.py) ------------------------------ */
 int t2v_relu(const float* x, float* y, int64_t n, void* stream);                 /* layers.py:172,230 */

@@ -352,7 +352,7 @@ def test_graph_replay_matches_eager():
     def batches():
         g = torch.Generator()
         g.manual_seed(11)
-        return [(torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(6)]
+        return [(torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(4)]    # 2 eager + 2 replayed
 
     def seed():
         random.seed(5)
@@ -380,7 +380,7 @@ def test_graph_replay_matches_eager():
         # accumulates the per-level contributions into the shared D weights is the one frozen at capture
         # time (a different but equally valid fp32 summation order): ~1e-7 relative in the gradients,
         # amplified by the dynamics to ~1e-5 in the next loss.
-        tol = 5e-6 if i < 2 else (2e-4 if i < 4 else 1e-2)      # the dynamics amplify ~x5 per iteration
+        tol = 5e-6 if i < 2 else 5e-4                              # the dynamics amplify ~x5-30 per iteration
         assert abs(got[0] - eager[i][0]) < tol and abs(got[1] - eager[i][1]) < tol, (i, got, eager[i])
     assert gs.graphs is not None
 

@@ -28,6 +28,14 @@ class ConvGroup(C.Structure):
                 ('dz', C.c_int8 * MAX_TAPS), ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS), ('widx', C.c_int8 * MAX_TAPS)]
 
 
+class PackJob(C.Structure):
+    """Mirror of `t2v_pack_job` (include/t2v_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('Cout', C.c_int32), ('Cin', C.c_int32), ('T', C.c_int32),
+                ('ntaps', C.c_int32), ('mode', C.c_int32), ('dst_rows', C.c_int32), ('dst_cols', C.c_int32),
+                ('row_off', C.c_int32), ('col_off', C.c_int32), ('block_begin', C.c_int32), ('bx', C.c_int32), ('by', C.c_int32),
+                ('taps', C.c_int8 * MAX_TAPS), ('pad_', C.c_int8 * 5)]
+
+
 MAX_GROUPS = 8
 _P = C.c_void_p
 _I = C.c_int
@@ -39,6 +47,8 @@ _G = C.POINTER(ConvGeom)
 # name -> argtypes (restype is int unless stated); must list EVERY symbol of include/t2v_hip.h
 SIGNATURES = {
     't2v_pack_weight': [_P, _P, _I, _I, _I, _I3, _I, _I, _P],
+    't2v_pack_job_bytes': [],
+    't2v_pack_multi': [_P, _I, _I, _P],
     't2v_pack_weight_into': [_P, _P, _I, _I, _I, _I3, _I, _I, _I, _I, _I, _I, _P],
     't2v_conv_fwd': [_P, _P, _P, _P, _P, _G, _I, _P],
     't2v_conv_fwd_ws_floats': [_G],
@@ -50,6 +60,8 @@ SIGNATURES = {
     't2v_conv_wgrad': [_P, _P, _P, _P, _G, _I3, _I, _I, _P],
     't2v_channel_sum_ws_floats': [_I, _I, _L],
     't2v_channel_sum': [_P, _P, _P, _I, _I, _L, _I, _P],
+    't2v_channel_sum_grouped_ws_floats': [_P, _I, _I],
+    't2v_channel_sum_grouped': [_P, _I, _I, _P, _P, _I, _P],
     't2v_relu': [_P, _P, _L, _P],
     't2v_relu_mask': [_P, _P, _P, _L, _P],
     't2v_add': [_P, _P, _P, _L, _P],
@@ -99,7 +111,7 @@ SIGNATURES = {
     't2v_version': [],
 }
 _RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
-            't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
+            't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_channel_sum_grouped_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None
 

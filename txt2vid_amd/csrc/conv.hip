@@ -168,6 +168,68 @@ extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int
     return t2v_pack_weight_into(w, wp, Cout, Cin, T, taps, ntaps, mode, mode ? Cout : Cin, mode ? Cin : Cout, 0, 0, stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor pack: every packed variant of every weight an optimiser just updated, in ONE launch.
+// `table` is a device array of PackJob; workgroup b serves the job whose [block_begin, next) range holds b.
+// ------------------------------------------------------------------------------------------------
+struct PackJob {
+    const float* src;
+    float* dst;
+    int32_t Cout, Cin, T, ntaps, mode, dst_rows, dst_cols, row_off, col_off, block_begin, bx, by;
+    int8_t taps[T2V_MAX_TAPS];
+    int8_t pad_[5];
+};
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ table, int njobs) {
+    __shared__ float tile[32][33];
+    __shared__ PackJob job;
+    // binary search: last job with block_begin <= blockIdx.x
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        job = table[lo];
+    }
+    __syncthreads();
+    const int b = (int)blockIdx.x - job.block_begin;
+    const int bxi = b % job.bx, byi = (b / job.bx) % job.by, j = b / (job.bx * job.by);
+    const int Cout = job.Cout, Cin = job.Cin, T = job.T;
+    const int t = job.mode ? (T - 1 - job.taps[j]) : job.taps[j];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int co0 = byi * 32, ci0 = bxi * 32;
+    const float* __restrict__ w = job.src;
+    float* __restrict__ wp = job.dst;
+    if (job.mode == 0) {
+        for (int r = ty; r < 32; r += 8) {
+            int co = co0 + r, ci = ci0 + tx;
+            tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            int ci = ci0 + r, co = co0 + tx;
+            if (ci < Cin && co < Cout) wp[((size_t)j * job.dst_rows + job.row_off + ci) * job.dst_cols + job.col_off + co] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            int co = co0 + r, ci = ci0 + tx;
+            if (co < Cout && ci < Cin)
+                wp[((size_t)j * job.dst_rows + job.row_off + co) * job.dst_cols + job.col_off + ci] = w[((size_t)co * Cin + ci) * T + t];
+        }
+    }
+}
+
+extern "C" int t2v_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+
+// `table`: DEVICE array of njobs PackJob records (layout: t2v_pack_job in the header); total_blocks = sum of bx*by*ntaps
+extern "C" int t2v_pack_multi(const void* table, int njobs, int total_blocks, void* stream) {
+    if (!table || njobs < 1 || total_blocks < 1) return T2V_EINVAL;
+    T2V_LAUNCH(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)table, njobs);
+    return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad implicit GEMM — GROUPED: one launch convolves up to T2V_MAX_GROUPS tensors that share
 // the weights but not the geometry (the 4 pyramid levels of the multi-scale discriminator). A workgroup
@@ -1416,6 +1478,71 @@ extern "C" int t2v_channel_sum(const float* x, float* out, float* ws, int N, int
     const int sp = channel_split(N, C, S);
     if (sp > 1 && !ws) return T2V_EINVAL;
     T2V_LAUNCH(channel_sum_kernel, dim3(C, sp), dim3(256), 0, (hipStream_t)stream, x, out, N, C, (long)S, accum, sp, ws);
+    if (sp > 1) T2V_LAUNCH(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, out, C, sp, accum);
+    return launch_status();
+}
+
+// bias gradient of a grouped convolution: out[c] = sum over all members, samples and voxels — one launch
+struct CSumTable { const float* p[T2V_MAX_GROUPS]; int32_t N[T2V_MAX_GROUPS]; int64_t S[T2V_MAX_GROUPS]; int64_t start[T2V_MAX_GROUPS + 1]; int32_t n; };
+
+__global__ __launch_bounds__(256) void channel_sum_grouped_kernel(const CSumTable tab, float* __restrict__ out, int C, int accum,
+                                                                  int split, float* __restrict__ ws) {
+    const int c = blockIdx.x;
+    const long total = tab.start[tab.n];
+    const long per = (total + split - 1) / split;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    float acc = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && e >= tab.start[k]) gi = k;
+        const long le = e - tab.start[gi];
+        const long S = tab.S[gi];
+        const long n = le / S, sp = le - n * S;
+        acc += tab.p[gi][((size_t)n * C + c) * S + sp];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (split > 1) ws[(size_t)c * split + blockIdx.y] = red[0];
+        else out[c] = accum ? out[c] + red[0] : red[0];
+    }
+}
+
+extern "C" int64_t t2v_channel_sum_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int C) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || C < 1) return T2V_EINVAL;
+    long total = 0;
+    for (int i = 0; i < ngroups; ++i) total += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+    const int sp = channel_split(1, C, total);
+    return sp > 1 ? (int64_t)C * sp : 0;
+}
+// members: groups[i].x = tensor [N, C, D, H, W]
+extern "C" int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups, int C, float* out, float* ws, int accum,
+                                       void* stream) {
+    if (!groups || !out || ngroups < 1 || ngroups > T2V_MAX_GROUPS || C < 1) return T2V_EINVAL;
+    CSumTable tab;
+    long total = 0;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        if (!groups[i].x || groups[i].N < 1) return T2V_EINVAL;
+        tab.p[i] = groups[i].x;
+        tab.N[i] = groups[i].N;
+        tab.S[i] = (int64_t)groups[i].D * groups[i].H * groups[i].W;
+        tab.start[i] = total;
+        total += (long)groups[i].N * tab.S[i];
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.start[i] = total;
+    const int sp = channel_split(1, C, total);
+    if (sp > 1 && !ws) return T2V_EINVAL;
+    T2V_LAUNCH(channel_sum_grouped_kernel, dim3(C, sp), dim3(256), 0, (hipStream_t)stream, tab, out, C, accum, sp, ws);
     if (sp > 1) T2V_LAUNCH(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, out, C, sp, accum);
     return launch_status();
 }

@@ -17,7 +17,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import lib, check, ConvGeom, ConvGroup, MAX_TAPS, MAX_GROUPS
+from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, MAX_TAPS, MAX_GROUPS
 
 FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM = 1, 2, 4
 
@@ -140,24 +140,61 @@ def packed_weight(w5, geom, mode):
     return wp
 
 
+_repack_tables = {}
+
+
+def _pack_job_of(p, key, hit):
+    """(src, dst, Cout, Cin, T, taps, mode, dst_rows, dst_cols, row_off, col_off) of one cached packed variant."""
+    if callable(hit[3]):
+        return hit[4]                    # member of a fused matrix: its job tuple was recorded at creation
+    shape5, _, mode = key
+    geom = hit[3]
+    Cout, Cin = shape5[0], shape5[1]
+    return (p, hit[2], Cout, Cin, geom.T, list(geom.taps), mode, (Cout if mode else Cin), (Cin if mode else Cout), 0, 0)
+
+
 def repack_params(params):
-    """Refresh every packed variant of these parameters in place (called by the optimiser after its
-    in-place update, inside the captured graph when graphs are in use)."""
+    """Refresh every packed variant of these parameters in place, in ONE launch (`t2v_pack_multi`) driven by a
+    device-resident job table that is rebuilt only when the set of cached variants changes. Called by the
+    optimiser right after its in-place update (inside the captured graph when graphs are in use)."""
+    params = list(params)
+    jobs = []
     for p in params:
         ent = _pack_cache.get(id(p))
         if not ent:
             continue
         for key, hit in ent.items():
-            if hit[0]() is not p:
-                continue
-            if callable(hit[3]):
-                hit[3](p)                       # member of a fused (multi-weight) packed matrix
-            else:
-                shape5, _, mode = key
-                geom = hit[3]
-                check(lib().t2v_pack_weight(_p(p), _p(hit[2]), shape5[0], shape5[1], geom.T, geom.taps_c, len(geom.taps), mode,
-                                            _stream()), 't2v_pack_weight')
-            hit[1] = (p._version, WEIGHT_EPOCH, p.data_ptr())
+            if hit[0]() is p:
+                jobs.append((p, key, hit))
+    if not jobs:
+        return
+    sig = tuple((id(p), key, hit[2].data_ptr(), p.data_ptr()) for p, key, hit in jobs)
+    tkey = tuple(id(p) for p in params)
+    tab = _repack_tables.get(tkey)
+    if tab is None or tab[0] != sig:
+        assert C.sizeof(PackJob) == lib().t2v_pack_job_bytes()
+        arr = (PackJob * len(jobs))()
+        blocks = 0
+        for a, (p, key, hit) in zip(arr, jobs):
+            src, dst, Cout, Cin, T, taps, mode, rows, cols, ro, co = _pack_job_of(p, key, hit)
+            a.src, a.dst = src.data_ptr(), dst.data_ptr()
+            a.Cout, a.Cin, a.T, a.ntaps, a.mode = Cout, Cin, T, len(taps), mode
+            a.dst_rows, a.dst_cols, a.row_off, a.col_off = rows, cols, ro, co
+            a.bx, a.by = (Cin + 31) // 32, (Cout + 31) // 32
+            a.block_begin = blocks
+            for j, t in enumerate(taps):
+                a.taps[j] = t
+            blocks += a.bx * a.by * len(taps)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        dev = host.to(params[0].device)
+        tab = (sig, dev, len(jobs), blocks)
+        _repack_tables[tkey] = tab
+    check(lib().t2v_pack_multi(_p(tab[1]), tab[2], tab[3], _stream()), 't2v_pack_multi')
+    for p, key, hit in jobs:
+        hit[1] = (p._version, WEIGHT_EPOCH, p.data_ptr())
+    for fkey, fh in _fused_cache.items():
+        if any(r() is p for r in fh[0] for p in params):
+            fh[1] = tuple((w()._version, WEIGHT_EPOCH, w().data_ptr()) for w in fh[0] if w() is not None)
 
 
 _fused_cache = {}
@@ -194,8 +231,10 @@ def packed_fused(ws, ts, mode):
         refresh.append(make(i))
         refresh[i](w)
         if isinstance(w, torch.nn.Parameter):
+            ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
             _pack_cache.setdefault(id(w), {})[('fused', key, i)] = [weakref.ref(w), (w._version, WEIGHT_EPOCH, w.data_ptr()), wp,
-                                                                    refresh[i]]
+                                                                    refresh[i],
+                                                                    (w, wp, Cout, Cin, ts.T, list(ts.taps), mode, rows, cols, ro, co)]
     if all(isinstance(w, torch.nn.Parameter) for w in ws):
         _fused_cache[key] = [[weakref.ref(w) for w in ws], tag, wp, refresh]
     return wp
@@ -1712,23 +1751,20 @@ class ConvWgradG(Function):
 
 
 class ChannelSumG(Function):
-    """bias gradient of a grouped convolution: sum over every member."""
+    """bias gradient of a grouped convolution: sum over every member, one launch."""
 
     @staticmethod
     def forward(ctx, *gys):
-        out = None
-        for g in gys:
-            g = _c(g)
-            N, Cc = g.shape[0], g.shape[1]
-            S = g.numel() // (N * Cc)
-            if out is None:
-                out = torch.empty((Cc,), device=g.device, dtype=torch.float32)
-                accum = 0
-            else:
-                accum = 1
-            nws = int(lib().t2v_channel_sum_ws_floats(N, Cc, S))
-            ws = torch.empty((nws,), device=g.device, dtype=torch.float32) if nws > 0 else None
-            check(lib().t2v_channel_sum(_p(g), _p(out), _p(ws), N, Cc, S, accum, _stream()), 't2v_channel_sum')
+        gys = [_c(g) for g in gys]
+        Cc = gys[0].shape[1]
+        arr = (ConvGroup * len(gys))()
+        for a, g in zip(arr, gys):
+            a.x, a.N = g.data_ptr(), g.shape[0]
+            a.D, a.H, a.W = g.shape[2], g.shape[3], g.shape[4]
+        out = torch.empty((Cc,), device=gys[0].device, dtype=torch.float32)
+        nws = int(lib().t2v_channel_sum_grouped_ws_floats(arr, len(gys), Cc))
+        ws = torch.empty((nws,), device=out.device, dtype=torch.float32) if nws > 0 else None
+        check(lib().t2v_channel_sum_grouped(arr, len(gys), Cc, _p(out), _p(ws), 0, _stream()), 't2v_channel_sum_grouped')
         return out
 
     @staticmethod
