@@ -65,24 +65,63 @@ def synthetic_batches(batch, n, seed, dev):
     return out
 
 
-def cpu_baseline(threads):
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate `--pmc` runs of tools/conv_micro.py; a PMC pass cannot run inside this
+    process). Returns (bytes, note) or (None, None)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        for k, v in d['kernels'].items():
+            if 'conv_igemm_kernel' in k:
+                b = (v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
+                return b, ('profiles/r01_pmc_traffic.json: %s, per launch; algorithmic %.0f MB; FETCH_SIZE may under-count '
+                           'streaming reads by up to 2x on gfx950' % (d['workload'].split(':')[1].split(',')[0].strip(),
+                                                                      d['algorithmic_bytes_per_launch']['igemm (x + y + w)'] / 1e6))
+    except Exception:
+        pass
+    return None, None
+
+
+def host_threads():
+    """Cores this process may actually run on (cgroup / affinity aware), not the machine's logical CPU count."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:                                      # cgroup v2 quota, e.g. "1600000 100000" = 16 cores
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(threads, budget_s=45.0):
     """The CPU oracle (== reference semantics, pinned by tests/test_oracle_golden.py) on the host cores:
-    BASELINE config-1 shape (uncond, B=4, GP on), 1 warm-up + 2 timed iterations."""
+    BASELINE config-1 shape (uncond, B=4, GP on). One warm-up iteration, then timed iterations until the
+    time budget is spent (at least 1, at most 3)."""
     from oracle import tganv2_oracle as O
     torch.set_num_threads(threads)
     PG = O.recipe_state(O.gen_shapes(num_channels=1), attn_gamma=0.0)
     PD = O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0), attn_gamma=0.0)
     tr = O.OracleTrainer(PG, PD)
     B = 4
-    xs = [(torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4) for _ in range(3)]
-    tr.step(xs[0])
+
+    def batch():
+        return (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
     t0 = time.time()
-    for x in xs[1:]:
-        tr.step(x)
-    dt = (time.time() - t0) / 2
+    tr.step(batch())
+    warm = time.time() - t0
+    times = []
+    while len(times) < 3 and (not times or time.time() - t0 + (sum(times) / len(times)) < budget_s):
+        t1 = time.time()
+        tr.step(batch())
+        times.append(time.time() - t1)
+    dt = sum(times) / len(times)
     return {'value': B / dt, 'unit': 'videos/s', 'cores': threads, 'kind': 'port',
             'sample': 'CPU oracle (plain fp32 PyTorch restatement), uncond TGANv2 16x64x64x1, B=4, RSGAN+GP, '
-                      '2 timed iterations after 1 warm-up, %.2f s/iter' % dt,
+                      '%d timed iteration(s) after 1 warm-up (%.1f s), %.2f s/iter' % (len(times), warm, dt),
             'steps_per_sec': 1.0 / dt}
 
 
@@ -188,7 +227,7 @@ def main():
         if cnt > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic()[0], 'traffic_note': pmc_traffic()[1],
                     'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2; '
                               'includes its split-K reduce pass)',
                     'launches_per_step': cnt / prof_steps, 'avg_launch_us': ms * 1e3 / cnt,
@@ -220,7 +259,8 @@ def main():
     if roof is not None:
         res['roofline'] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+        log('timing the CPU oracle on %d host threads' % host_threads())
+        res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
