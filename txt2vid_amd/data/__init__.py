@@ -1,6 +1,7 @@
 """Input side of the hot path: the batch *contract* of txt2vid/data/__init__.py (`Dataset` :158-258,
-`collate_fn` :326-355, `my_dataset` :376-377) on synthetic Moving-MNIST-shaped clips (no dataset, no
-network, no cv2 / DALI), plus the pinned-memory prefetcher that replaces `data_prefetcher` (:131-156).
+`Vocab` :260-316, `collate_fn` :326-355, `default_transform` :357-370, `my_dataset` :376-377): the
+frame-folder reader (PIL only: no cv2 / DALI / torchvision / lmdb), synthetic Moving-MNIST-shaped clips for
+machines without a dataset, and the pinned-memory prefetcher that replaces `data_prefetcher` (:131-156).
 
 A batch is (videos [B,T,C,H,W] float32 in [-1,1], tokens [B,L] int64 zero-padded, lengths list desc).
 """
@@ -16,20 +17,140 @@ MOTIONS = [('left', 'right'), ('right', 'left'), ('top', 'bottom'), ('bottom', '
 
 
 class Vocab(object):
-    """Minimal stand-in for `txt2vid.data.Vocab` (:260-316): word <-> id, `to_words`."""
+    """Word <-> id table with the interface of `txt2vid.data.Vocab` (:260-316): ids 0..3 are
+    <pad> <start> <end> <unk>, words are lower-cased, unknown words map to <unk>. Built with no arguments it
+    holds the synthetic captions' 21 words (the reference builds it from a sentence pickle, `build_vocab`)."""
+    START, END, UNKNOWN, PAD = '<start>', '<end>', '<unk>', '<pad>'
 
     def __init__(self, words=WORDS):
-        self.words = list(words)
-        self.index = {w: i for i, w in enumerate(self.words)}
+        self.word2idx, self.idx2word, self.idx = {}, {}, 0
+        for w in (self.PAD, self.START, self.END, self.UNKNOWN):
+            self.add_word(w)
+        for w in words or ():
+            self.add_word(w)
+
+    def add_word(self, word):
+        word = word.lower()
+        if word not in self.word2idx:
+            self.word2idx[word] = self.idx
+            self.idx2word[self.idx] = word
+            self.idx += 1
+
+    def get_word(self, idx):
+        return self.idx2word.get(idx, self.UNKNOWN)
+
+    def __call__(self, word):
+        return self.word2idx.get(word.lower(), self.word2idx[self.UNKNOWN])
 
     def __len__(self):
-        return len(self.words)
+        return len(self.word2idx)
 
-    def __call__(self, w):
-        return self.index.get(w, self.index['<unk>'])
+    def tokenize(self, sentence):
+        """<start>, then the whitespace-split words; a word ending in '.' yields the word and <end>."""
+        yield self.START
+        for word in sentence.split():
+            if word.endswith('.'):
+                yield word[:-1]
+                yield self.END
+            else:
+                yield word
 
-    def to_words(self, ids):
-        return ' '.join(self.words[int(i)] for i in ids if int(i) != 0)
+    def to_words(self, tokens):
+        out = []
+        for i, tok in enumerate(tokens):
+            word = self.get_word(int(tok))
+            out.append(word if (i == 0 or word == self.END) else ' ' + word)
+        return ''.join(out)
+
+
+def build_vocab(sentences):
+    """data/__init__.py:318-324."""
+    vocab = Vocab(words=None)
+    for sent in sentences:
+        for word in vocab.tokenize(sent):
+            vocab.add_word(word)
+    return vocab
+
+
+def pick_frames(frame_ids, num_frames=16, random=False, rng=None):
+    """Evenly strided pick (`frame_ids[(len // num_frames) * i]`), or `num_frames` random ids kept in
+    order — data/__init__.py:108-129 (whose random branch cannot run as written; this is its intent)."""
+    if not random:
+        step = len(frame_ids) // num_frames
+        return [frame_ids[step * i] for i in range(num_frames)]
+    assert len(frame_ids) >= num_frames
+    rng = rng or np.random
+    keep = np.sort(rng.permutation(len(frame_ids))[:num_frames])
+    return [frame_ids[i] for i in keep]
+
+
+def default_transform(frame_size=None, num_channels=3):
+    """PIL image -> float32 [C,h,w] in [-1,1]: centre crop, (grey), /255, (x-0.5)/0.5 — the torchvision
+    pipeline of data/__init__.py:357-370 without torchvision (absent here)."""
+    fs = list(frame_size) if isinstance(frame_size, (list, tuple)) else [frame_size]
+    if len(fs) == 1:
+        fs.append(fs[0])
+    ch, cw = int(fs[0]), int(fs[1])
+
+    def transform(img):
+        w, h = img.size
+        left, top = int(round((w - cw) / 2.0)), int(round((h - ch) / 2.0))
+        img = img.crop((left, top, left + cw, top + ch))            # PIL zero-fills outside, like CenterCrop's pad
+        img = img.convert('RGB' if num_channels == 3 else 'L')
+        a = np.asarray(img, dtype=np.float32) / 255.0
+        a = a[None] if a.ndim == 2 else a.transpose(2, 0, 1)
+        return torch.from_numpy(np.ascontiguousarray((a - 0.5) / 0.5))
+    return transform
+
+
+class Dataset(torch.utils.data.Dataset):
+    """Frame-folder reader with the contract of `txt2vid.data.Dataset` (:158-258), minus cv2 / DALI / lmdb:
+    `captions` is a pickle {video id -> [sentence, ...]}; `video_dir/<id>/<n>.jpg|png` are the frames
+    (n integer, sorted numerically). One item per (video, sentence): (frames [T,C,h,w], token ids float)."""
+
+    def __init__(self, video_dir=None, vocab=None, captions=None, transform=None, random_frames=0, num_frames=16,
+                 use_lmdb=False):
+        if use_lmdb:
+            raise NotImplementedError('the caffe2-LMDB cache is not part of this build (no lmdb here)')
+        import os
+        from ..util.pick import load
+        self.video_dir, self.vocab, self.transform = str(video_dir), vocab, transform
+        self.random_frames, self.num_frames = int(random_frames or 0), num_frames
+        table = load(captions) if isinstance(captions, (str, os.PathLike)) else captions
+        self.video_ids, self.captions, self.missing = [], [], 0
+        for vid in table:
+            if not os.path.isdir(os.path.join(self.video_dir, str(vid))):
+                self.missing += 1
+                continue
+            for cap in table[vid]:
+                self.video_ids.append(vid)
+                self.captions.append(cap)
+
+    def __len__(self):
+        return len(self.captions)
+
+    def __getitem__(self, idx):
+        import os
+        from PIL import Image
+        folder = os.path.join(self.video_dir, str(self.video_ids[idx]))
+        ext = {}
+        for name in os.listdir(folder):
+            stem, suffix = os.path.splitext(name)
+            if suffix in ('.jpg', '.png') and stem.isdigit():
+                ext[int(stem)] = name
+        ids = sorted(ext)
+        n = self.random_frames if self.random_frames else self.num_frames
+        picked = pick_frames(ids, num_frames=n, random=bool(self.random_frames))
+        frames = []
+        for i in picked:
+            with Image.open(os.path.join(folder, ext[i])) as img:
+                img.load()
+                frames.append(self.transform(img) if self.transform else img)
+        frames = torch.stack(frames)
+        toks = [self.vocab(t) for t in self.vocab.tokenize(self.captions[idx])]
+        if toks[-1] != self.vocab(self.vocab.END):
+            toks.append(self.vocab(self.vocab.END))
+        return frames, torch.tensor(toks, dtype=torch.float32)
 
 
 class SyntheticMovingDigits(torch.utils.data.Dataset):
@@ -76,21 +197,32 @@ def collate_fn(data):
     return vids, toks, lengths
 
 
-def my_dataset(data=None, vocab=None, anno=None, transform=None, num_frames=16, **args):
-    """Factory named by config/*.json (`"class": "txt2vid.data.my_dataset"`, data/__init__.py:376-377).
-    There is no dataset on disk in this build: a `data` path that does not exist (or 'synthetic')
-    yields the synthetic clips; reading real frame folders is SURVEY §8(f) item 1 (next)."""
+def my_dataset(data=None, vocab=None, anno=None, transform=None, random_frames=False, num_frames=16, use_lmdb=False,
+               **synthetic_args):
+    """Factory named by config/*.json (`"class": "txt2vid.data.my_dataset"`, data/__init__.py:376-377): a
+    frame-folder `Dataset` when `data` is a directory (captions pickle = `--anno`); `data="synthetic"` (or a
+    path that does not exist, e.g. the reference's own config/synth.json on a machine without the files)
+    yields the synthetic clips, with `size= channels= length= seed=` forwarded."""
     import os
     if data is not None and data != 'synthetic' and os.path.isdir(str(data)):
-        raise NotImplementedError('frame-folder datasets are SURVEY §8(f)-1 (not built yet); use data="synthetic"')
-    args.pop('transform', None)
-    return SyntheticMovingDigits(num_frames=num_frames, vocab=vocab, **args)
+        if anno is None:
+            raise ValueError('a frame-folder dataset needs the captions pickle (--anno)')
+        if transform is None:
+            transform = default_transform([synthetic_args.get('size', 64)], synthetic_args.get('channels', 3))
+        return Dataset(video_dir=data, vocab=vocab, captions=anno, transform=transform, random_frames=random_frames,
+                       num_frames=num_frames, use_lmdb=use_lmdb)
+    return SyntheticMovingDigits(num_frames=num_frames, vocab=vocab, **synthetic_args)
 
 
-def get_loader(dset=None, batch_size=64, val=False, num_workers=0, has_captions=True):
-    """data/__init__.py:379-383."""
-    return torch.utils.data.DataLoader(dset, batch_size=batch_size, shuffle=not val, num_workers=num_workers,
-                                       collate_fn=collate_fn, drop_last=True, pin_memory=True)
+def get_loader(dset=None, batch_size=64, val=False, num_workers=0, has_captions=True, rank=0, world=1, seed=0):
+    """data/__init__.py:379-383. With `world` > 1 every rank reads its own 1/world of each epoch's
+    permutation (one process per GPU; the reference's single-process DataParallel split one big batch)."""
+    sampler = None
+    if world > 1 and not isinstance(dset, SyntheticMovingDigits):     # synthetic clips already differ per rank (seed+rank)
+        sampler = torch.utils.data.distributed.DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=not val,
+                                                                  seed=int(seed), drop_last=True)
+    return torch.utils.data.DataLoader(dset, batch_size=batch_size, shuffle=(not val) and sampler is None, sampler=sampler,
+                                       num_workers=num_workers, collate_fn=collate_fn, drop_last=True, pin_memory=True)
 
 
 class DevicePrefetcher(object):

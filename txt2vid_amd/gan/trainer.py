@@ -266,6 +266,8 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
             status('Epoch %d started' % (epoch + 1))
         load_watch.start()
         iter_watch.start()
+        if hasattr(getattr(dataset, 'sampler', None), 'set_epoch'):
+            dataset.sampler.set_epoch(epoch)                 # a new permutation per epoch on every rank
         pre = DevicePrefetcher(dataset, device)
         i = 0
         x, y = pre.next()

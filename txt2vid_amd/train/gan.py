@@ -73,9 +73,11 @@ def main(args):
         if 'optG' in to_load:
             optG.load_state_dict(to_load['optG'])
         del to_load
-    dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=None, size=args.frame_sizes[-1],
+    transform = data.default_transform(frame_size=[args.frame_sizes[-1]], num_channels=args.num_channels)
+    dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=transform, size=args.frame_sizes[-1],
                          channels=args.num_channels, seed=(args.seed or 0) + rank)
-    dataset = data.get_loader(dset=dset, batch_size=args.batch_size, val=False, num_workers=args.workers)
+    dataset = data.get_loader(dset=dset, batch_size=args.batch_size, val=False, num_workers=args.workers, rank=rank,
+                              world=world, seed=seed)
     status('GAN has %d parameters' % gan.count_params())
     if args.G_loss is None:
         args.G_loss = args.D_loss
