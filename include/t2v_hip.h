@@ -191,6 +191,15 @@ int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, floa
 /* RSGAN (losses.py:79-85): loss = mean softplus(-(a-b)) ; ga = -sigmoid(-(a-b))/n * gscale, gb = -ga. */
 int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* stream);
 int t2v_rsgan_bwd(const float* a, const float* b, const float* gloss, float* ga, float* gb, int n, void* stream);
+/* The rest of the loss zoo on D's logits (losses.py:19-68,87-133). kind: 1 VanillaGanLoss (BCE, labels wired as
+   losses.py:27-28: fake->1, real->0), 2 HingeGanLoss(margin), 3 WassersteinGanLoss, 4 RaSGANLoss, 5 RaLSGANLoss;
+   side 0 = discrim_loss, 1 = gen_loss. `real` may be NULL where the loss ignores it (gen side of kinds 1-3).
+   Forward writes the scalar loss; backward writes d loss/d real, d loss/d fake (either may be NULL) times gloss[0]. */
+enum { T2V_LOSS_VANILLA = 1, T2V_LOSS_HINGE = 2, T2V_LOSS_WASSERSTEIN = 3, T2V_LOSS_RASGAN = 4, T2V_LOSS_RALSGAN = 5 };
+int t2v_gan_loss(const float* real, const float* fake, float* loss, int n_real, int n_fake, int kind, int side,
+                 float margin, void* stream);
+int t2v_gan_loss_bwd(const float* real, const float* fake, const float* gloss, float* g_real, float* g_fake, int n_real,
+                     int n_fake, int kind, int side, float margin, void* stream);
 /* GP (losses.py:135-186): xhat = alpha[b]*xr + (1-alpha[b])*xf ; sq[b] = sum g^2 ; scale rows. */
 int t2v_lerp_rows(const float* alpha, const float* xr, const float* xf, float* y, int rows, int64_t S, void* stream);
 int t2v_row_sqnorm(const float* g, float* out, int rows, int64_t S, void* stream);

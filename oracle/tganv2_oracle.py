@@ -378,6 +378,27 @@ def rsgan_gen_loss(fake, real):
     return F.binary_cross_entropy_with_logits(fake - real, torch.ones_like(fake))
 
 
+def zoo_loss(kind, side, fake, real, margin=2.0):
+    """The rest of txt2vid/gan/losses.py on D's logits, numpy-style closed forms (side 0 = discrim_loss, 1 = gen_loss):
+    vanilla (:19-46; `LabelledGanLoss` stores its labels crossed at :27-28, so D sees fake->1, real->0 and G fake->0),
+    hinge (:48-52, `HingeEmbeddingLoss(margin)`: label 1 -> mean x, label -1 -> mean relu(margin - x); fake->1, real->-1),
+    wasserstein (:55-68), rasgan (:87-110 with the labels it means, 0/1 — as written it raises AttributeError),
+    ralsgan (:113-133)."""
+    sp = F.softplus
+    if kind == 'vanilla':
+        return sp(-fake).mean() + sp(real).mean() if side == 0 else sp(fake).mean()
+    if kind == 'hinge':
+        return fake.mean() + F.relu(margin - real).mean() if side == 0 else F.relu(margin - fake).mean()
+    if kind == 'wasserstein':
+        return -(real.mean() - fake.mean()) if side == 0 else -fake.mean()
+    u, v = real - fake.mean(), fake - real.mean()
+    if kind == 'rasgan':
+        return (sp(-u).mean() + sp(v).mean()) / 2 if side == 0 else (sp(u).mean() + sp(-v).mean()) / 2
+    if kind == 'ralsgan':
+        return (((u - 1) ** 2).mean() + ((v + 1) ** 2).mean()) / 2 if side == 0 else (((u + 1) ** 2).mean() + ((v - 1) ** 2).mean()) / 2
+    raise KeyError(kind)
+
+
 def gp_level(P, prefix, real_x, fake_x, real_c=None, fake_c=None, alpha=None):
     """`_gradient_penalty(..., zero_center=True, combine=torch.sum)` for one pyramid level —
     txt2vid/gan/losses.py:135-186 as called from :203. `alpha` [b] ~ U[0,1) from the global CPU

@@ -375,8 +375,31 @@ def golden_init():
     save('init_xavier', **out)
 
 
+def golden_losses():
+    """The loss zoo (gan/losses.py:19-133) on [12,1] logits: both sides' values and their gradients w.r.t. the real and
+    the fake logits. RaSGANLoss as written reads attributes it never sets (`fake_labels` :95); they are SET on the
+    instance here (0 / 1, the values its constructor stores under the singular names), nothing is patched."""
+    out = {'real': npy(rnd(71, 12, 1) * 2.0), 'fake': npy(rnd(72, 12, 1) * 2.0 + 0.3)}
+    ra = RL.RaSGANLoss()
+    ra.fake_labels, ra.real_labels = ra.fake_label, ra.real_label
+    zoo = {'vanilla': RL.VanillaGanLoss(), 'hinge': RL.HingeGanLoss(), 'hinge3': RL.HingeGanLoss(margin=3.0),
+           'wasserstein': RL.WassersteinGanLoss(), 'rasgan': ra, 'ralsgan': RL.RaLSGANLoss(), 'rsgan': RL.RSGANLoss()}
+    for name, obj in zoo.items():
+        for side, fn in ((0, obj.discrim_loss), (1, obj.gen_loss)):
+            r = torch.tensor(out['real'], requires_grad=True)
+            f = torch.tensor(out['fake'], requires_grad=True)
+            loss = fn(fake=f, real=r)
+            gr, gf = torch.autograd.grad(loss, [r, f], allow_unused=True)
+            out['%s.%d.loss' % (name, side)] = npy(loss)
+            out['%s.%d.g_real' % (name, side)] = npy(gr if gr is not None else torch.zeros_like(r))
+            out['%s.%d.g_fake' % (name, side)] = npy(gf if gf is not None else torch.zeros_like(f))
+    save('losses', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond']
+    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond', 'losses']
+    if 'losses' in which:
+        golden_losses()
     if 'layers' in which:
         golden_layers()
     if 'resnet3d' in which:

@@ -239,6 +239,40 @@ def test_losses_and_gp_helpers():
     close(gd_.grad, gr_.grad)
 
 
+@pytest.mark.parametrize('name', ['vanilla', 'hinge', 'hinge3', 'wasserstein', 'rasgan', 'ralsgan'])
+def test_loss_zoo_matches_reference_goldens_and_oracle(name):
+    """gan/losses.py:19-133 through `t2v_gan_loss(_bwd)`: the committed reference outputs on [12,1] logits, then the
+    oracle on ragged / large heads (n = 1, 255, 257, 4099) with a non-unit upstream gradient."""
+    import os
+    from oracle import tganv2_oracle as O
+    from txt2vid_amd.gan import losses as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'losses.npz'))
+    obj = {'vanilla': L.VanillaGanLoss(), 'hinge': L.HingeGanLoss(), 'hinge3': L.HingeGanLoss(margin=3.0),
+           'wasserstein': L.WassersteinGanLoss(), 'rasgan': L.RaSGANLoss(), 'ralsgan': L.RaLSGANLoss()}[name]
+    kind, margin = ('hinge', 3.0) if name == 'hinge3' else (name, 2.0)
+    for side, fn in ((0, obj.discrim_loss), (1, obj.gen_loss)):
+        r = torch.tensor(g['real']).to(dev()).requires_grad_(True)
+        f = torch.tensor(g['fake']).to(dev()).requires_grad_(True)
+        loss = fn(fake=f, real=r)
+        loss.backward()
+        zero = torch.zeros(12, 1)
+        close(loss, torch.tensor(g['%s.%d.loss' % (name, side)]), rtol=1e-5, atol=1e-6)
+        close(r.grad if r.grad is not None else zero, torch.tensor(g['%s.%d.g_real' % (name, side)]), rtol=1e-5, atol=1e-6)
+        close(f.grad if f.grad is not None else zero, torch.tensor(g['%s.%d.g_fake' % (name, side)]), rtol=1e-5, atol=1e-6)
+        for n in (1, 255, 257, 4099):
+            r0, f0 = rnd(10 + n, n, 1) * 3, rnd(20 + n, n, 1) * 3 - 0.5
+            ro, fo = r0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+            lo = O.zoo_loss(kind, side, fo, ro, margin=margin)
+            (lo * -2.5).backward()
+            rd, fd = r0.to(dev()).requires_grad_(True), f0.to(dev()).requires_grad_(True)
+            ld = fn(fake=fd, real=rd)
+            (ld * -2.5).backward()
+            close(ld, lo, rtol=2e-5, atol=2e-6)
+            close(rd.grad if rd.grad is not None else torch.zeros(n, 1), ro.grad if ro.grad is not None else torch.zeros(n, 1),
+                  rtol=1e-4, atol=1e-7)
+            close(fd.grad if fd.grad is not None else torch.zeros(n, 1), fo.grad, rtol=1e-4, atol=1e-7)
+
+
 def test_adam_matches_torch():
     from txt2vid_amd import functional as TF
     p, g1, g2 = rnd(1, 1000), rnd(2, 1000), rnd(3, 1000)

@@ -255,3 +255,20 @@ def test_train_steps_cond(golden):
         lD, lG = tr.step(x, cond=cond)
         assert abs(lD - g['lossD'][it]) < 1e-3, (it, lD, g['lossD'][it])
         assert abs(lG - g['lossG'][it]) < 1e-3, (it, lG, g['lossG'][it])
+
+
+ZOO = ['vanilla', 'hinge', 'hinge3', 'wasserstein', 'rasgan', 'ralsgan']
+
+
+@pytest.mark.parametrize('name', ZOO)
+def test_loss_zoo(golden, name):
+    """oracle.zoo_loss == the reference's loss classes (values and both logit gradients), losses.py:19-133."""
+    g = golden('losses')
+    kind, margin = ('hinge', 3.0) if name == 'hinge3' else (name, 2.0)
+    for side in (0, 1):
+        r, f = T(g['real']).requires_grad_(True), T(g['fake']).requires_grad_(True)
+        loss = O.zoo_loss(kind, side, f, r, margin=margin)
+        gr, gf = torch.autograd.grad(loss, [r, f], allow_unused=True)
+        close(loss, g['%s.%d.loss' % (name, side)], rtol=1e-6, atol=1e-7)
+        close(gr if gr is not None else torch.zeros_like(r), g['%s.%d.g_real' % (name, side)], rtol=1e-5, atol=1e-8)
+        close(gf if gf is not None else torch.zeros_like(f), g['%s.%d.g_fake' % (name, side)], rtol=1e-5, atol=1e-8)

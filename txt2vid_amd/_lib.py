@@ -93,6 +93,8 @@ SIGNATURES = {
     't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
     't2v_rsgan': [_P, _P, _P, _I, _P],
     't2v_rsgan_bwd': [_P, _P, _P, _P, _P, _I, _P],
+    't2v_gan_loss': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    't2v_gan_loss_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     't2v_lerp_rows': [_P, _P, _P, _P, _I, _L, _P],
     't2v_row_sqnorm': [_P, _P, _I, _L, _P],
     't2v_row_scale': [_P, _F, _P, _P, _I, _L, _P],

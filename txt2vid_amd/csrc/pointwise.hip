@@ -668,6 +668,106 @@ extern "C" int t2v_rsgan_bwd(const float* a, const float* b, const float* gl, fl
     return launch_status();
 }
 
+// ---- the loss zoo (gan/losses.py:19-133) on D's logits. One block: n is batch x heads (<= a few thousand).
+// Every loss has the form  w * [ mean_i p1(u_i) + mean_i p2(v_i) ]  with  u = r - cr*mean(f),  v = f - cf*mean(r)
+// (cr = cf = 0 for the non-averaged kinds).  kind: 0 RSGAN (handled by rsgan_k), 1 vanilla BCE, 2 hinge, 3 Wasserstein,
+// 4 RaSGAN, 5 RaLSGAN;  side 0 = discriminator loss, 1 = generator loss.
+struct LossTerm { int fn; float sign, shift; };      // fn: 0 none, 1 softplus(sign*t), 2 sign*t, 3 relu(shift - t), 4 (t + shift)^2
+struct LossSpec { LossTerm r, f; float rel, w; };
+__host__ __device__ inline LossSpec loss_spec(int kind, int side, float margin) {
+    LossSpec s = {{0, 0.f, 0.f}, {0, 0.f, 0.f}, 0.f, 1.f};
+    if (kind == 1) {            // labels as the reference wires them (losses.py:27-28): fake -> 1, real -> 0
+        if (side == 0) { s.r = {1, 1.f, 0.f}; s.f = {1, -1.f, 0.f}; } else { s.f = {1, 1.f, 0.f}; }
+    } else if (kind == 2) {     // HingeEmbedding(margin): label 1 -> t, label -1 -> relu(margin - t); fake -> 1, real -> -1
+        if (side == 0) { s.r = {3, 0.f, margin}; s.f = {2, 1.f, 0.f}; } else { s.f = {3, 0.f, margin}; }
+    } else if (kind == 3) {
+        if (side == 0) { s.r = {2, -1.f, 0.f}; s.f = {2, 1.f, 0.f}; } else { s.f = {2, -1.f, 0.f}; }
+    } else if (kind == 4) {
+        s.rel = 1.f; s.w = 0.5f;
+        if (side == 0) { s.r = {1, -1.f, 0.f}; s.f = {1, 1.f, 0.f}; } else { s.r = {1, 1.f, 0.f}; s.f = {1, -1.f, 0.f}; }
+    } else if (kind == 5) {
+        s.rel = 1.f; s.w = 0.5f;
+        if (side == 0) { s.r = {4, 0.f, -1.f}; s.f = {4, 0.f, 1.f}; } else { s.r = {4, 0.f, 1.f}; s.f = {4, 0.f, -1.f}; }
+    }
+    return s;
+}
+__device__ __forceinline__ float loss_val(const LossTerm& t, float x) {
+    switch (t.fn) {
+        case 1: return softplus(t.sign * x);
+        case 2: return t.sign * x;
+        case 3: return fmaxf(t.shift - x, 0.f);
+        case 4: return (x + t.shift) * (x + t.shift);
+        default: return 0.f;
+    }
+}
+__device__ __forceinline__ float loss_der(const LossTerm& t, float x) {
+    switch (t.fn) {
+        case 1: return t.sign / (1.f + expf(-t.sign * x));
+        case 2: return t.sign;
+        case 3: return (t.shift - x) > 0.f ? -1.f : 0.f;
+        case 4: return 2.f * (x + t.shift);
+        default: return 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void gan_loss_k(const float* r, const float* f, float* loss, int nr, int nf, LossSpec sp) {
+    __shared__ float red[4];
+    float mr = 0.f, mf = 0.f;
+    if (sp.rel != 0.f) {
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < nr; i += 256) a += r[i];
+        for (int i = threadIdx.x; i < nf; i += 256) b += f[i];
+        mr = block_sum(a, red) / (float)nr;
+        mf = block_sum(b, red) / (float)nf;
+    }
+    float a = 0.f, b = 0.f;
+    if (sp.r.fn) for (int i = threadIdx.x; i < nr; i += 256) a += loss_val(sp.r, r[i] - sp.rel * mf);
+    if (sp.f.fn) for (int i = threadIdx.x; i < nf; i += 256) b += loss_val(sp.f, f[i] - sp.rel * mr);
+    const float sa = block_sum(a, red), sb = block_sum(b, red);
+    if (threadIdx.x == 0) loss[0] = sp.w * ((sp.r.fn ? sa / (float)nr : 0.f) + (sp.f.fn ? sb / (float)nf : 0.f));
+}
+__global__ __launch_bounds__(256) void gan_loss_bwd_k(const float* r, const float* f, const float* gl, float* gr, float* gf,
+                                                      int nr, int nf, LossSpec sp) {
+    __shared__ float red[4];
+    const float g = gl[0] * sp.w;
+    float mr = 0.f, mf = 0.f, dr = 0.f, df = 0.f;        // means of the logits and of the terms' derivatives
+    if (sp.rel != 0.f) {
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < nr; i += 256) a += r[i];
+        for (int i = threadIdx.x; i < nf; i += 256) b += f[i];
+        mr = block_sum(a, red) / (float)nr;
+        mf = block_sum(b, red) / (float)nf;
+        a = 0.f; b = 0.f;
+        if (sp.r.fn) for (int i = threadIdx.x; i < nr; i += 256) a += loss_der(sp.r, r[i] - mf);
+        if (sp.f.fn) for (int i = threadIdx.x; i < nf; i += 256) b += loss_der(sp.f, f[i] - mr);
+        dr = block_sum(a, red) / (float)nr;
+        df = block_sum(b, red) / (float)nf;
+    }
+    // d/dr_i = p1'(u_i)/nr - rel * mean_j p2'(v_j) / nr ;   d/df_i symmetric
+    if (gr) for (int i = threadIdx.x; i < nr; i += 256)
+        gr[i] = g * ((sp.r.fn ? loss_der(sp.r, r[i] - sp.rel * mf) : 0.f) - sp.rel * df) / (float)nr;
+    if (gf) for (int i = threadIdx.x; i < nf; i += 256)
+        gf[i] = g * ((sp.f.fn ? loss_der(sp.f, f[i] - sp.rel * mr) : 0.f) - sp.rel * dr) / (float)nf;
+}
+static bool gan_loss_args_ok(const void* r, const void* f, int nr, int nf, int kind, int side) {
+    if (kind < 1 || kind > 5 || (side != 0 && side != 1) || nf < 1 || !f) return false;
+    const LossSpec sp = loss_spec(kind, side, 0.f);
+    if ((sp.r.fn || sp.rel != 0.f) && (!r || nr < 1)) return false;
+    return true;
+}
+extern "C" int t2v_gan_loss(const float* real, const float* fake, float* loss, int n_real, int n_fake, int kind, int side,
+                            float margin, void* st) {
+    if (!loss || !gan_loss_args_ok(real, fake, n_real, n_fake, kind, side)) return T2V_EINVAL;
+    T2V_LAUNCH(gan_loss_k, dim3(1), dim3(256), 0, S_(st), real, fake, loss, n_real, n_fake, loss_spec(kind, side, margin));
+    return launch_status();
+}
+extern "C" int t2v_gan_loss_bwd(const float* real, const float* fake, const float* gl, float* g_real, float* g_fake, int n_real,
+                                int n_fake, int kind, int side, float margin, void* st) {
+    if (!gl || !gan_loss_args_ok(real, fake, n_real, n_fake, kind, side)) return T2V_EINVAL;
+    T2V_LAUNCH(gan_loss_bwd_k, dim3(1), dim3(256), 0, S_(st), real, fake, gl, g_real, g_fake, n_real, n_fake,
+               loss_spec(kind, side, margin));
+    return launch_status();
+}
+
 __global__ void lerp_rows_k(const float* alpha, const float* xr, const float* xf, float* y, int rows, long S) {
     const long n = (long)rows * S;
     GRID_STRIDE(i, n) {

@@ -1074,6 +1074,39 @@ def rsgan(a, b):
     return RSGan.apply(a, b)
 
 
+LOSS_KINDS = {'vanilla': 1, 'hinge': 2, 'wasserstein': 3, 'rasgan': 4, 'ralsgan': 5}
+
+
+class GanLoss(Function):
+    """The rest of the loss zoo on D's logits (losses.py:19-68,87-133): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, real, fake, kind, side, margin):
+        fake = _c(fake)
+        real = _c(real) if real is not None else None
+        ctx.save_for_backward(real, fake)
+        ctx.cfg = (kind, side, float(margin))
+        out = torch.empty((), device=fake.device, dtype=torch.float32)
+        check(lib().t2v_gan_loss(_p(real), _p(fake), _p(out), real.numel() if real is not None else 0, fake.numel(), kind, side,
+                                 float(margin), _stream()), 't2v_gan_loss')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        real, fake = ctx.saved_tensors
+        kind, side, margin = ctx.cfg
+        gr = torch.empty_like(real) if (real is not None and ctx.needs_input_grad[0]) else None
+        gf = torch.empty_like(fake) if ctx.needs_input_grad[1] else None
+        check(lib().t2v_gan_loss_bwd(_p(real), _p(fake), _p(_c(g)), _p(gr), _p(gf), real.numel() if real is not None else 0,
+                                     fake.numel(), kind, side, margin, _stream()), 't2v_gan_loss_bwd')
+        return gr, gf, None, None, None
+
+
+def gan_loss(kind, side, real, fake, margin=0.0):
+    return GanLoss.apply(real, fake, LOSS_KINDS[kind], side, margin)
+
+
 def lerp_rows(alpha, xr, xf):
     """alpha[b]*xr[b] + (1-alpha[b])*xf[b]  (losses.py:146); no autograd (inputs are detached)."""
     xr, xf, alpha = _c(xr), _c(xf), _c(alpha)

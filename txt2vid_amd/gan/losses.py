@@ -1,8 +1,7 @@
 """GAN losses of the hot path — same classes / call signatures as txt2vid/gan/losses.py.
 
-RSGANLoss (losses.py:74-85) and the gradient penalty (losses.py:135-209) run on the HIP kernels.
-The remaining zoo (Vanilla/Hinge/Wasserstein/RaLS) is off the north-star path and is
-kept as small compositions of the same kernels where one exists, else as tiny tensor expressions.
+RSGANLoss (losses.py:74-85) and the gradient penalty (losses.py:135-209) are the north-star path; the rest of
+the zoo (Vanilla / Hinge / Wasserstein / RaSGAN / RaLSGAN) shares one HIP loss-head kernel.
 """
 import torch
 
@@ -40,24 +39,53 @@ class RSGANLoss(object):
         return TF.rsgan(fake, real)
 
 
-class WassersteinGanLoss(object):
-    """losses.py:55-68 (off the hot path; plain tensor means)."""
+class _ZooLoss(object):
+    """A loss of the zoo = one `t2v_gan_loss` launch per call (and one for its gradient)."""
+    kind, margin = None, 0.0
 
     def discrim_loss(self, fake=None, real=None):
-        return -(real.mean() - fake.mean())
+        return TF.gan_loss(self.kind, 0, real, fake, self.margin)
 
     def gen_loss(self, fake=None, real=None):
-        return -fake.mean()
+        return TF.gan_loss(self.kind, 1, real, fake, self.margin)
 
 
-class RaLSGANLoss(object):
-    """losses.py:113-133 (off the hot path)."""
+class VanillaGanLoss(_ZooLoss):
+    """losses.py:19-46. `LabelledGanLoss.__init__` stores the labels crossed (:27-28), so the reference's
+    D is trained towards fake -> 1, real -> 0 and G towards fake -> 0; consistent, and kept as is."""
+    kind = 'vanilla'
 
-    def discrim_loss(self, fake=None, real=None):
-        return (torch.mean((real - torch.mean(fake) - 1) ** 2) + torch.mean((fake - torch.mean(real) + 1) ** 2)) / 2
+    def __init__(self, bce_loss=True, reduction='mean'):
+        if not bce_loss or reduction != 'mean':
+            raise NotImplementedError('the reference scripts only use BCE-with-logits, mean reduction')
 
-    def gen_loss(self, fake=None, real=None):
-        return (torch.mean((real - torch.mean(fake) + 1) ** 2) + torch.mean((fake - torch.mean(real) - 1) ** 2)) / 2
+
+class HingeGanLoss(_ZooLoss):
+    """losses.py:48-52: nn.HingeEmbeddingLoss(margin) with labels fake -> 1, real -> -1 (crossed as above)."""
+    kind = 'hinge'
+
+    def __init__(self, margin=2.0):
+        self.margin = float(margin)
+
+
+class WassersteinGanLoss(_ZooLoss):
+    """losses.py:55-68."""
+    kind = 'wasserstein'
+
+
+class RaSGANLoss(_ZooLoss):
+    """losses.py:87-110 as intended: the reference reads `self.fake_labels` / `self.real_labels`, which do not
+    exist (it stores `fake_label` / `real_label`), so its RaSGAN raises on first use; labels 0 / 1."""
+    kind = 'rasgan'
+
+    def __init__(self, bce_loss=True):
+        if not bce_loss:
+            raise NotImplementedError('only the BCE form')
+
+
+class RaLSGANLoss(_ZooLoss):
+    """losses.py:113-133."""
+    kind = 'ralsgan'
 
 
 def _gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xbar=None, real_cond=None, fake_cond=None,
