@@ -258,6 +258,11 @@ def main():
     }
     if roof is not None:
         res['roofline'] = roof
+    if rank == 0 and world == 1 and prof:
+        # the north-star's own target line: D forward+backward on un-subsampled 16x64x64 clips
+        from txt2vid_amd.util.roofline import d_fwdbwd_roofline
+        log('D forward+backward roofline pass')
+        res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle on %d host threads' % host_threads())
         res['cpu_baseline'] = cpu_baseline(host_threads())

@@ -46,6 +46,7 @@ typedef struct {
 typedef struct {
     const float* x;      /* input  [N,Cin,D,H,W]                      (wgrad: the layer input)      */
     float* y;            /* output [N,Cout,D,H,W]                     (wgrad: dL/dy, read only)     */
+    const float* mask;   /* T2V_CONV_MASK_OUT: same shape as y; y = mask > 0 ? result : 0  (else NULL) */
     int32_t N, D, H, W;
     int32_t ntaps;
     int8_t dz[T2V_MAX_TAPS], dy[T2V_MAX_TAPS], dx[T2V_MAX_TAPS], widx[T2V_MAX_TAPS];
@@ -54,6 +55,8 @@ typedef struct {
 #define T2V_CONV_BIAS 1      /* add bias[Cout] in the epilogue                                   */
 #define T2V_CONV_RELU_IN 2   /* apply max(.,0) to the input while gathering (ReLU->conv fusion)  */
 #define T2V_CONV_ACCUM 4     /* y += result instead of y = result                                */
+#define T2V_CONV_MASK_OUT 8  /* zero the result where groups[i].mask <= 0: the ReLU adjoint fused into the data
+                                gradient of a ReLU->conv pair (layers.py:230-233). Not combined with ACCUM. */
 
 /* w[Cout][Cin][T] (PyTorch layout, T = kD*kH*kW) -> wp[ntaps][Cin][Cout] for the forward GEMM
  * (mode 0: wp[j][ci][co] = w[co][ci][taps[j]]) or wp[ntaps][Cout][Cin] for the data-gradient GEMM
@@ -210,6 +213,11 @@ int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
              float eps, float bc1, float bc2, float gscale, const float* step_dev, void* stream);
 /* step_dev != NULL: a device-resident {step, 1-b1^step, 1-b2^step} triple supplies the bias corrections
  * (HIP-graph replay cannot bake a host-side step number); t2v_adam_tick advances it by one step. */
+/* Multi-tensor form of t2v_adam: `jobs` is a HOST array (device pointers inside); tensors are processed 64 per launch
+   with their pointers in the kernel arguments. Same arithmetic, element for element, as t2v_adam. */
+typedef struct t2v_adam_job { void* p; const void* g; void* m; void* v; int64_t n; } t2v_adam_job;
+int t2v_adam_multi(const t2v_adam_job* jobs, int njobs, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                   float gscale, const float* step_dev, void* stream);
 int t2v_adam_tick(float* state, float b1, float b2, void* stream);
 
 /* ---- pyramid (trainer.py:131-165, layers.py:106-111) ------------------------------------------- */

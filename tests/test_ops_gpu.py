@@ -94,6 +94,35 @@ def test_conv_double_backward():
     close(w2d.grad, w2r.grad, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize('shapes', [[(2, 16, 4, 6, 6)], [(4, 64, 2, 16, 16), (2, 64, 4, 8, 8), (1, 64, 1, 5, 3)],
+                                    [(3, 8, 1, 1, 1), (2, 8, 2, 2, 2)]])
+def test_relu_conv_grouped_first_and_second_order(shapes):
+    """ReLU -> conv pairs (layers.py:230-233): fused gather forward, masked-epilogue data gradient (T2V_CONV_MASK_OUT),
+    grouped over several tensors that share the weight; gradients of a gradient-penalty-shaped loss vs torch."""
+    from txt2vid_amd import functional as TF
+    cin, cout = shapes[0][1], 24
+    w0, b0 = rnd(5, cout, cin, 3, 3, 3) * 0.2, rnd(6, cout) * 0.1
+    xs0 = [rnd(10 + i, *s) for i, s in enumerate(shapes)]
+
+    def run(conv_all, to):
+        w, b = to(w0).requires_grad_(True), to(b0).requires_grad_(True)
+        xs = [to(x).requires_grad_(True) for x in xs0]
+        ys = conv_all(xs, w, b)
+        out = sum((y * y).sum() for y in ys)
+        gxs = torch.autograd.grad(out, xs, create_graph=True)
+        loss = out * 0.01 + sum((g * g).sum() for g in gxs)
+        loss.backward()
+        return [y.detach() for y in ys], [g.detach() for g in gxs], w.grad, b.grad, [x.grad for x in xs]
+
+    ref = run(lambda xs, w, b: [F.conv3d(F.relu(x), w, b, padding=1) for x in xs], lambda t: t.double())
+    if len(shapes) == 1:
+        got = run(lambda xs, w, b: [TF.relu_conv(xs[0], w, b)], lambda t: t.to(dev()))
+    else:
+        got = run(lambda xs, w, b: TF.conv_group(xs, w, b, relu_in=True), lambda t: t.to(dev()))
+    for a, r in zip(got[0] + got[1] + [got[2], got[3]] + got[4], ref[0] + ref[1] + [ref[2], ref[3]] + ref[4]):
+        close(a, r.float(), rtol=2e-4, atol=2e-4)
+
+
 def test_avgpool():
     from txt2vid_amd import functional as TF
     for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),

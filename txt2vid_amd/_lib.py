@@ -23,9 +23,14 @@ class ConvGeom(C.Structure):
 
 class ConvGroup(C.Structure):
     """Mirror of `t2v_conv_group` (include/t2v_hip.h)."""
-    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('N', C.c_int32), ('D', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('mask', C.c_void_p), ('N', C.c_int32), ('D', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('ntaps', C.c_int32),
                 ('dz', C.c_int8 * MAX_TAPS), ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS), ('widx', C.c_int8 * MAX_TAPS)]
+
+
+class AdamJob(C.Structure):
+    """t2v_adam_job (include/t2v_hip.h)."""
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
 
 
 class PackJob(C.Structure):
@@ -99,6 +104,7 @@ SIGNATURES = {
     't2v_row_sqnorm': [_P, _P, _I, _L, _P],
     't2v_row_scale': [_P, _F, _P, _P, _I, _L, _P],
     't2v_adam': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P],
+    't2v_adam_multi': [_P, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P],
     't2v_adam_tick': [_P, _F, _F, _P],
     't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     't2v_copy2d': [_P, _L, _P, _L, _L, _L, _P],

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     const bool split = nsplit > 1;
     const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
     const bool accum = !split && (flags & T2V_CONV_ACCUM);
+    const bool mask_out = !split && (flags & T2V_CONV_MASK_OUT) && gd.mask != nullptr;
     float* out = split ? slab + (size_t)blockIdx.z * (size_t)tab.out_start[tab.n] + (size_t)tab.out_start[gi] : gd.y;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
@@ -459,7 +460,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
         if (m >= M) continue;
         const int n = m / DHW, sp = m - n * DHW;
         float* py = out + (size_t)n * Cout * DHW + sp;
-        if (!accum) {                      // (block-uniform) plain stores: no load, no wait in the store tail
+        if (mask_out) {                    // ReLU adjoint fused: y = mask > 0 ? result : 0
+            const float* pm = gd.mask + (size_t)n * Cout * DHW + sp;
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) {
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    mv[r] = pm[(size_t)(co < Cout ? co : Cout - 1) * DHW];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = acc[i][j][r] + (has_bias ? bias[co < Cout ? co : 0] : 0.f);
+                    if (co < Cout) py[(size_t)co * DHW] = mv[r] > 0.f ? v : 0.f;
+                }
+            }
+        } else if (!accum) {               // (block-uniform) plain stores: no load, no wait in the store tail
 #pragma unroll
             for (int i = 0; i < NCO; ++i) {
 #pragma unroll
@@ -500,6 +518,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GroupTable tab
             v += bias[(li / DHW) % Cout];
         }
         float* y = tab.g[gi].y;
+        if ((flags & T2V_CONV_MASK_OUT) && tab.g[gi].mask) v = tab.g[gi].mask[li] > 0.f ? v : 0.f;
         y[li] = accum ? y[li] + v : v;
     }
 }
@@ -567,11 +586,13 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GroupTable tab, co
     }
     const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
     const bool accum = flags & T2V_CONV_ACCUM;
+    const bool mask_out = (flags & T2V_CONV_MASK_OUT) && gd.mask != nullptr;
     float* py = gd.y + (size_t)n * Cout * DHW + sp;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < Cout) {
             float v = acc[c] + (has_bias ? bias[c] : 0.f);
+            if (mask_out) v = gd.mask[(size_t)n * Cout * DHW + sp + (size_t)c * DHW] > 0.f ? v : 0.f;
             py[(size_t)c * DHW] = accum ? py[(size_t)c * DHW] + v : v;
         }
     }
@@ -617,6 +638,7 @@ __global__ __launch_bounds__(256) void linear_thin_kernel(const GroupTable tab, 
             if (c < Cout) {
                 float v = acc[c] + (has_bias ? bias[c] : 0.f);
                 float* p = gd.y + (size_t)r * Cout + c;
+                if ((flags & T2V_CONV_MASK_OUT) && gd.mask) v = gd.mask[(size_t)r * Cout + c] > 0.f ? v : 0.f;
                 *p = accum ? *p + v : v;
             }
     }
@@ -728,6 +750,11 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     GroupTable tab;
     ConvPlan p;
     if (!wp || !build_table(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
+    if (flags & T2V_CONV_MASK_OUT) {
+        if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
+        for (int i = 0; i < ngroups; ++i)
+            if (!groups[i].mask) return T2V_EINVAL;
+    }
     hipStream_t s = (hipStream_t)stream;
 #ifdef T2V_ABLATION
     if (const char* e = getenv("T2V_DEBUG_FLAGS")) flags |= atoi(e);     // developer ablations (wrong results)
@@ -800,7 +827,7 @@ static bool geom_ok(const t2v_conv_geom* g) {
 }
 static t2v_conv_group group_of(const t2v_conv_geom* g, const float* x, float* y) {
     t2v_conv_group q;
-    q.x = x; q.y = y;
+    q.x = x; q.y = y; q.mask = nullptr;
     q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps;
     for (int t = 0; t < T2V_MAX_TAPS; ++t) {
         q.dz[t] = t < g->ntaps ? g->dz[t] : 0; q.dy[t] = t < g->ntaps ? g->dy[t] : 0; q.dx[t] = t < g->ntaps ? g->dx[t] : 0;

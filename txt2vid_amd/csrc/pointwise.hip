@@ -828,6 +828,76 @@ extern "C" int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n,
     T2V_LAUNCH(adam_k, dim3(nblocks(n)), dim3(256), 0, S_(st), p, g, m, v, (long)n, lr, b1, b2, eps, bc1, bc2, gscale, step_dev);
     return launch_status();
 }
+// Multi-tensor form: up to 64 parameter tensors per launch, their pointers passed BY VALUE in the kernel arguments (no
+// device-side table to keep in sync, and a captured HIP graph keeps the pointers in its kernel node). Block b works on
+// elements [4096 c, 4096 (c+1)) of tensor j, where begin[j] <= b < begin[j+1] and c = b - begin[j].
+#define ADAM_MT 64
+#define ADAM_CHUNK 4096
+struct AdamBatch {
+    float* p[ADAM_MT]; const float* g[ADAM_MT]; float* m[ADAM_MT]; float* v[ADAM_MT];
+    int n[ADAM_MT]; int begin[ADAM_MT + 1]; int njobs;
+};
+__global__ __launch_bounds__(256) void adam_multi_k(AdamBatch tb, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                     float gscale, const float* step_dev) {
+    if (step_dev) { bc1 = step_dev[1]; bc2 = step_dev[2]; }
+    const float step = lr / bc1;
+    const float isq = 1.f / sqrtf(bc2);
+    int lo = 0, hi = tb.njobs;                         // largest j with begin[j] <= blockIdx.x
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tb.begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const int j = lo;
+    const long base = (long)((int)blockIdx.x - tb.begin[j]) * ADAM_CHUNK;
+    const int len = (int)min((long)ADAM_CHUNK, (long)tb.n[j] - base);
+    float* __restrict__ p = tb.p[j] + base;
+    const float* __restrict__ g = tb.g[j] + base;
+    float* __restrict__ m = tb.m[j] + base;
+    float* __restrict__ v = tb.v[j] + base;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const int nv = vec ? (len >> 2) : 0;
+    for (int q = threadIdx.x; q < nv; q += 256) {
+        float4 P = ((float4*)p)[q], M = ((float4*)m)[q], V = ((float4*)v)[q];
+        const float4 G = ((const float4*)g)[q];
+        float* pp = (float*)&P; float* mm = (float*)&M; float* vv = (float*)&V; const float* gg = (const float*)&G;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gg[e] * gscale;
+            const float mi = b1 * mm[e] + (1.f - b1) * gi;
+            const float vi = b2 * vv[e] + (1.f - b2) * gi * gi;
+            mm[e] = mi; vv[e] = vi;
+            pp[e] = pp[e] - step * (mi / (sqrtf(vi) * isq + eps));
+        }
+        ((float4*)p)[q] = P; ((float4*)m)[q] = M; ((float4*)v)[q] = V;
+    }
+    for (int i = nv * 4 + threadIdx.x; i < len; i += 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step * (mi / (sqrtf(vi) * isq + eps));
+    }
+}
+extern "C" int t2v_adam_multi(const t2v_adam_job* jobs, int njobs, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                              float gscale, const float* step_dev, void* st) {
+    if (!jobs || njobs < 1) return T2V_EINVAL;
+    for (int i = 0; i < njobs; ++i)
+        if (!jobs[i].p || !jobs[i].g || !jobs[i].m || !jobs[i].v || jobs[i].n < 1 || jobs[i].n > 0x7fffffffL) return T2V_EINVAL;
+    for (int at = 0; at < njobs; at += ADAM_MT) {
+        AdamBatch tb;
+        const int cnt = njobs - at < ADAM_MT ? njobs - at : ADAM_MT;
+        long blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const t2v_adam_job& jb = jobs[at + i];
+            tb.p[i] = (float*)jb.p; tb.g[i] = (const float*)jb.g; tb.m[i] = (float*)jb.m; tb.v[i] = (float*)jb.v;
+            tb.n[i] = (int)jb.n; tb.begin[i] = (int)blocks;
+            blocks += (jb.n + ADAM_CHUNK - 1) / ADAM_CHUNK;
+        }
+        for (int i = cnt; i < ADAM_MT; ++i) { tb.p[i] = nullptr; tb.g[i] = nullptr; tb.m[i] = nullptr; tb.v[i] = nullptr; tb.n[i] = 0; tb.begin[i] = (int)blocks; }
+        tb.begin[ADAM_MT] = (int)blocks;
+        tb.njobs = cnt;
+        if (blocks > 0x7fffffffL) return T2V_EINVAL;
+        T2V_LAUNCH(adam_multi_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb, lr, b1, b2, eps, bc1, bc2, gscale, step_dev);
+    }
+    return launch_status();
+}
 // step state {step, bc1, bc2}: step += 1 and the bias corrections 1 - beta^step, evaluated in double and
 // rounded to float exactly like the host path does (python float -> c_float).
 __global__ void adam_tick_k(float* state, float b1, float b2) {

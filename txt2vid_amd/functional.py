@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, MAX_TAPS, MAX_GROUPS
 
-FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM = 1, 2, 4
+FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT = 1, 2, 4, 8
 
 # ------------------------------------------------------------------------------------------------
 # small helpers
@@ -61,9 +61,19 @@ def input_grads_only():
         _param_grads_enabled = old
 
 
-def bump_weight_epoch():
+def bump_weight_epoch(params=None):
+    """Tell the packed-weight caches that parameters were rewritten behind autograd's back (raw-pointer kernels do
+    not bump `_version`): the given ones, or — with no argument — every parameter."""
     global WEIGHT_EPOCH
-    WEIGHT_EPOCH += 1
+    if params is None:
+        WEIGHT_EPOCH += 1
+        return
+    for p in params:
+        p._t2v_epoch = getattr(p, '_t2v_epoch', 0) + 1
+
+
+def _wtag(base, ptr=None):
+    return (base._version, WEIGHT_EPOCH, getattr(base, '_t2v_epoch', 0), base.data_ptr() if ptr is None else ptr)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -124,7 +134,7 @@ def packed_weight(w5, geom, mode):
               't2v_pack_weight')
         return wp
     key = (tuple(w5.shape), geom.mask, mode)
-    tag = (base._version, WEIGHT_EPOCH, w5.data_ptr())
+    tag = _wtag(base, w5.data_ptr())
     ent = _pack_cache.setdefault(id(base), {})
     hit = ent.get(key)
     if hit is not None and hit[0]() is base:
@@ -191,10 +201,10 @@ def repack_params(params):
         _repack_tables[tkey] = tab
     check(lib().t2v_pack_multi(_p(tab[1]), tab[2], tab[3], _stream()), 't2v_pack_multi')
     for p, key, hit in jobs:
-        hit[1] = (p._version, WEIGHT_EPOCH, p.data_ptr())
+        hit[1] = _wtag(p)
     for fkey, fh in _fused_cache.items():
         if any(r() is p for r in fh[0] for p in params):
-            fh[1] = tuple((w()._version, WEIGHT_EPOCH, w().data_ptr()) for w in fh[0] if w() is not None)
+            fh[1] = tuple(_wtag(w()) for w in fh[0] if w() is not None)
 
 
 _fused_cache = {}
@@ -208,7 +218,7 @@ def packed_fused(ws, ts, mode):
     Cout, Cin = ws[0].shape[0], ws[0].shape[1]
     key = (tuple(id(w) for w in ws), ts.mask, mode)
     hit = _fused_cache.get(key)
-    tag = tuple((w._version, WEIGHT_EPOCH, w.data_ptr()) for w in ws)
+    tag = tuple(_wtag(w) for w in ws)
     if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
         if hit[1] != tag:
             for i, w in enumerate(ws):
@@ -226,13 +236,13 @@ def packed_fused(ws, ts, mode):
                                                  ro, co, _stream()), 't2v_pack_weight_into')
                 h = _fused_cache.get(key)
                 if h is not None:
-                    h[1] = tuple((x._version, WEIGHT_EPOCH, x.data_ptr()) for x in ws)
+                    h[1] = tuple(_wtag(x) for x in ws)
             return fn
         refresh.append(make(i))
         refresh[i](w)
         if isinstance(w, torch.nn.Parameter):
             ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
-            _pack_cache.setdefault(id(w), {})[('fused', key, i)] = [weakref.ref(w), (w._version, WEIGHT_EPOCH, w.data_ptr()), wp,
+            _pack_cache.setdefault(id(w), {})[('fused', key, i)] = [weakref.ref(w), _wtag(w), wp,
                                                                     refresh[i],
                                                                     (w, wp, Cout, Cin, ts.T, list(ts.taps), mode, rows, cols, ro, co)]
     if all(isinstance(w, torch.nn.Parameter) for w in ws):
@@ -406,7 +416,7 @@ class ReluConv(Function):
         x, w = ctx.saved_tensors
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ReluMask.apply(ConvDgrad.apply(gy, w), x)
+            gx = ConvDgradMaskG.apply(w, 1, gy, x)[0]          # dgrad(gy, w) * [x > 0] in one launch
         if _param_grads_enabled:
             if ctx.needs_input_grad[1]:
                 gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
@@ -1183,6 +1193,17 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0, step_dev=None):
           't2v_adam')
 
 
+def adam_step_multi(items, lr, b1, b2, eps, step, gscale=1.0, step_dev=None):
+    """`items`: [(p, g, exp_avg, exp_avg_sq)] that share `step` — one launch per 64 tensors (`t2v_adam_multi`)."""
+    from ._lib import AdamJob
+    arr = (AdamJob * len(items))()
+    for a, (p, g, m, v) in zip(arr, items):
+        a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    check(lib().t2v_adam_multi(arr, len(items), lr, b1, b2, eps, bc1, bc2, gscale, _p(step_dev), _stream()), 't2v_adam_multi')
+
+
 # ------------------------------------------------------------------------------------------------
 # layout glue (strided copies done by t2v_pyramid_gather / t2v_copy2d — no ATen kernels)
 # ------------------------------------------------------------------------------------------------
@@ -1628,11 +1649,12 @@ def _tapset(T, mask):
     return ts
 
 
-def _group_table(ins, outs, geoms, slot_of):
+def _group_table(ins, outs, geoms, slot_of, masks=None):
     arr = (ConvGroup * len(ins))()
     for i, (xi, yi, g) in enumerate(zip(ins, outs, geoms)):
         a = arr[i]
         a.x, a.y = xi.data_ptr(), (yi.data_ptr() if yi is not None else 0)
+        a.mask = masks[i].data_ptr() if masks is not None else None
         a.N, a.D, a.H, a.W, a.ntaps = g.cg.N, g.cg.D, g.cg.H, g.cg.W, g.cg.ntaps
         for j, t in enumerate(g.taps):
             a.dz[j], a.dy[j], a.dx[j] = g.cg.dz[j], g.cg.dy[j], g.cg.dx[j]
@@ -1640,8 +1662,9 @@ def _group_table(ins, outs, geoms, slot_of):
     return arr
 
 
-def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0):
-    """mode 0: ys[i] = conv(xs[i], w) (+bias); mode 1: data gradient (xs are dL/dy, channels swap roles)."""
+def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
+    """mode 0: ys[i] = conv(xs[i], w) (+bias); mode 1: data gradient (xs are dL/dy, channels swap roles).
+    masks: ys[i] is zeroed where masks[i] <= 0 (the ReLU adjoint, fused into the epilogue)."""
     if len(xs5) > MAX_GROUPS:
         raise ValueError('at most %d tensors per grouped convolution' % MAX_GROUPS)
     xs5 = [_c(t) for t in xs5]
@@ -1657,12 +1680,16 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0):
     wp = packed_weight(w5, ts, mode)
     slot_of = {t: j for j, t in enumerate(ts.taps)}
     ys = [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32) for t in xs5]
-    arr = _group_table(xs5, ys, geoms, slot_of)
+    if masks is not None:
+        masks = [_c(m) for m in masks]
+        if any(m.shape != y.shape for m, y in zip(masks, ys)):
+            raise ValueError('mask / output shape mismatch')
+    arr = _group_table(xs5, ys, geoms, slot_of, masks)
     n = int(lib().t2v_conv_fwd_grouped_ws_floats(arr, len(xs5), cin, cout))
     if n < 0:
         raise RuntimeError('bad grouped conv geometry')
     ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
-    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0)
+    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0)
     check(lib().t2v_conv_fwd_grouped(arr, len(xs5), cin, cout, _p(wp), _p(bias), _p(ws), flags, _stream()), 't2v_conv_fwd_grouped')
     return ys
 
@@ -1712,9 +1739,12 @@ class ConvG(Function):
             return (None, None, None) + tuple(gxs)
         need = [i for i in live if ctx.needs_input_grad[3 + i]]
         if need:
-            res = ConvDgradG.apply(w, *[gys[i] for i in need])
+            if ctx.relu_in:
+                res = ConvDgradMaskG.apply(w, len(need), *([gys[i] for i in need] + [xs[i] for i in need]))
+            else:
+                res = ConvDgradG.apply(w, *[gys[i] for i in need])
             for i, r in zip(need, res):
-                gxs[i] = ReluMask.apply(r, xs[i]) if ctx.relu_in else r
+                gxs[i] = r
         if _param_grads_enabled:
             if ctx.needs_input_grad[0]:
                 gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *([xs[i] for i in live] + [gys[i] for i in live]))
@@ -1753,8 +1783,41 @@ class ConvDgradG(Function):
         return (d_w,) + tuple(d_gys)
 
 
+class ConvDgradMaskG(Function):
+    """gxs[i] = dgrad(gys[i], w) * [xs[i] > 0]: the data gradient of a ReLU -> conv pair with the ReLU adjoint applied in
+    the epilogue (T2V_CONV_MASK_OUT) — one launch, no unmasked intermediate. Its own adjoints (the gradient penalty
+    differentiates through it) are composed from the unfused differentiable ops."""
+
+    @staticmethod
+    def forward(ctx, w, n, *gys_xs):
+        gys, xs = gys_xs[:n], gys_xs[n:]
+        ctx.save_for_backward(w, *gys_xs)
+        ctx.set_materialize_grads(False)
+        ctx.n = n
+        return tuple(conv_group_raw(gys, w, None, False, 1, masks=xs))
+
+    @staticmethod
+    def backward(ctx, *ggxs):
+        saved = ctx.saved_tensors
+        n = ctx.n
+        w, gys, xs = saved[0], saved[1:1 + n], saved[1 + n:]
+        live = [i for i, g in enumerate(ggxs) if g is not None]
+        d_w = None
+        d_gys = [None] * n
+        if live:
+            hs = {i: ReluMask.apply(ggxs[i], xs[i]) for i in live}
+            if ctx.needs_input_grad[0] and _param_grads_enabled:
+                d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *([hs[i] for i in live] + [gys[i] for i in live]))
+            need = [i for i in live if ctx.needs_input_grad[2 + i]]
+            if need:
+                res = ConvG.apply(w, None, False, *[hs[i] for i in need])
+                for i, r in zip(need, res):
+                    d_gys[i] = r
+        return (d_w, None) + tuple(d_gys) + (None,) * n
+
+
 class ConvWgradG(Function):
-    """gw = sum over the group of wgrad(relu?(x_i), gy_i)."""
+    """gw = sum over the group of wgrad(relu?(x_i), gy_i).""" 
 
     @staticmethod
     def forward(ctx, wshape, relu_in, n, *xs_gys):

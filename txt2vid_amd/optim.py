@@ -29,6 +29,7 @@ class Adam(torch.optim.Optimizer):
         touched = []
         for group in self.param_groups:
             b1, b2 = group['betas']
+            by_step = {}                      # tensors that have taken the same number of steps update in one launch
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -39,9 +40,10 @@ class Adam(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] = int(st['step']) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                TF.adam_step(p, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], b1, b2, group['eps'], st['step'],
-                             self.grad_scale, self.step_dev)
+                by_step.setdefault(st['step'], []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
                 touched.append(p)
-        TF.bump_weight_epoch()          # packed weights are stale ...
+            for step, items in by_step.items():
+                TF.adam_step_multi(items, group['lr'], b1, b2, group['eps'], step, self.grad_scale, self.step_dev)
+        TF.bump_weight_epoch(touched)   # their packed weights are stale ...
         TF.repack_params(touched)       # ... refresh them in place right away (same addresses for graph replay)
         return None
