@@ -221,16 +221,18 @@ def main():
         prof_dt = time.perf_counter() - t1
         log('instrumented eager pass done: %.1f ms/step' % (prof_dt / prof_steps * 1e3))
     if prof:
-        out = (C.c_double * 9)()
-        over = lib().t2v_prof_end(out, 3)
-        ms, fl, cnt = out[0], out[1], out[2]
+        out = (C.c_double * 15)()
+        over = lib().t2v_prof_end(out, 5)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce
+        ms, fl, cnt = out[0] + out[12], out[1], out[2]
         if cnt > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic()[0], 'traffic_note': pmc_traffic()[1],
                     'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2; '
                               'includes its split-K reduce pass)',
-                    'launches_per_step': cnt / prof_steps, 'avg_launch_us': ms * 1e3 / cnt,
+                    'launches_per_step': cnt / prof_steps, 'avg_launch_us': out[0] * 1e3 / cnt,
+                    'splitk_reduce': {'launches_per_step': out[14] / prof_steps, 'gpu_ms_per_step': out[12] / prof_steps},
+                    'timing': 'hipExtLaunchKernelGGL start/stop events = the dispatch\'s own begin/end (same clock as the rocprofv3 kernel trace)',
                     'flops_counted': 'executed MACs x2 (padding-only taps excluded), summed over all launches',
                     'measured_over': ('the timed region (eager launches)' if prof_in_region else
                                       '%d eager iterations right after the timed region (graph replay has no launch calls to '

@@ -180,6 +180,17 @@ int t2v_lstm_gates(const float* pre, const float* c_prev, float* h, float* c_new
                    int B, int64_t CS, void* stream);
 int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const float* act, const float* c_prev,
                        const float* c_new, float* gpre, float* gc_prev, int B, int64_t CS, void* stream);
+/* The same recurrence on 1x1 feature maps (the generator's ConvLSTM state is [B,1024,1,1]): a step is a 32-row GEMM.
+   t2v_skinny_gemm_slab: slab[s][m][n] = sum over the s-th K slice of x[m][k] * w[k][n] (x [M][K], w [K][N] row-major =
+   the packed 1-tap weight); S = t2v_skinny_gemm_splits(M,K,N) slices (K % 128 == 0, else < 0), slab holds S*M*N floats.
+   t2v_lstm_gates_slab / _bwd_slab: the gate kernels with  pre = bias + sum_s slab[s]  resp.  dL/dh = gh + sum_s slab[s]
+   (S = 0: no incoming term), so the split-K pass and the add are fused into them. */
+int t2v_skinny_gemm_splits(int M, int K, int N);
+int t2v_skinny_gemm_slab(const float* x, const float* w, float* slab, int M, int K, int N, void* stream);
+int t2v_lstm_gates_slab(const float* slab, int S, const float* bias, const float* c_prev, float* h, float* c_new,
+                        float* act, int B, int C, void* stream);
+int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S, const float* gc_in, const float* act,
+                            const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* stream);
 
 /* ---- non-local block (layers.py:23-36, 52-68) -------------------------------------------------- */
 /* C[b] = alpha * op(A[b]) x op(B[b]); row-major A[b]: (ta? K x M : M x K), B[b]: (tb? N x K : K x N). */

@@ -213,11 +213,13 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
-@pytest.mark.parametrize('hw', [1, 2])
-def test_conv_lstm(hw):
+@pytest.mark.parametrize('hw,C,B', [(1, 16, 3), (2, 16, 3), (1, 128, 5), (1, 256, 33)])
+def test_conv_lstm(hw, C, B):
+    """conv_lstm.py:75-97 vs the oracle; C % 128 == 0 on 1x1 maps takes the wave-per-strip GEMM + slab-summing gate
+    kernels (the generator's [B,1024,1,1] case), B = 33 a second, ragged MFMA row tile."""
     from txt2vid_amd import functional as TF
     from oracle import tganv2_oracle as O
-    C, B, steps = 16, 3, 5
+    steps = 5
     shapes = {}
     for gate in 'ifco':
         shapes['Wx%s.weight' % gate] = (C, C, 3, 3)
@@ -225,7 +227,7 @@ def test_conv_lstm(hw):
         shapes['Wh%s.weight' % gate] = (C, C, 3, 3)
     P = O.recipe_state(shapes)
     for v in P.values():
-        v.mul_(3.0).requires_grad_(True)
+        v.mul_(3.0 if C == 16 else 3.0 * (16.0 / C) ** 0.5).requires_grad_(True)
     x = rnd(1, B, C, hw, hw)
     xr = x.clone().requires_grad_(True)
     yr = torch.stack(O.conv_lstm(P, '', xr, steps))

@@ -92,6 +92,10 @@ SIGNATURES = {
     't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
     't2v_lstm_gates': [_P, _P, _P, _P, _P, _I, _L, _P],
     't2v_lstm_gates_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P],
+    't2v_skinny_gemm_splits': [_I, _I, _I],
+    't2v_skinny_gemm_slab': [_P, _P, _P, _I, _I, _I, _P],
+    't2v_lstm_gates_slab': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    't2v_lstm_gates_bwd_slab': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't2v_bmm': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     't2v_softmax': [_P, _P, _L, _I, _P],
     't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],

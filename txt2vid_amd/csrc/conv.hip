@@ -49,6 +49,7 @@ static inline int launch_status() {
 // optional launch instrumentation (bench.py roofline): hipEvent pairs recorded ON THE LAUNCH STREAM
 // around every conv-GEMM launch while enabled. Off by default; the product path never enables it.
 // ------------------------------------------------------------------------------------------------
+#include <hip/hip_ext.h>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -59,21 +60,30 @@ static struct {
     size_t used = 0;
 } g_prof;
 
+// A ProfScope arms ONE record; the next T2V_LAUNCH_PROF in the thread consumes it and launches through
+// hipExtLaunchKernelGGL, which stamps the two events with the dispatch's own begin / end times (the same clock the
+// rocprofv3 kernel trace reports), so neither the launch gap nor the event packets are counted.
+static thread_local ProfRec* g_prof_cur = nullptr;
 struct ProfScope {
-    ProfRec* r = nullptr;
-    hipStream_t s;
-    ProfScope(int kind, double flops, hipStream_t stream, long M = 0, int Cin = 0, int Cout = 0, int taps = 0, int groups = 0,
-              int S = 0) : s(stream) {
+    ProfScope(int kind, double flops, hipStream_t, long M = 0, int Cin = 0, int Cout = 0, int taps = 0, int groups = 0, int S = 0) {
+        g_prof_cur = nullptr;
         if (g_prof.on && g_prof.used < g_prof.recs.size()) {
-            r = &g_prof.recs[g_prof.used++];
+            ProfRec* r = &g_prof.recs[g_prof.used++];
             r->kind = kind;
             r->flops = flops;
             r->M = M; r->Cin = Cin; r->Cout = Cout; r->taps = taps; r->groups = groups; r->S = S;
-            (void)hipEventRecord(r->e0, s);
+            g_prof_cur = r;
         }
     }
-    ~ProfScope() { if (r) (void)hipEventRecord(r->e1, s); }
+    ~ProfScope() { g_prof_cur = nullptr; }
 };
+#define T2V_LAUNCH_PROF(kernel, grid, block, shm, stream, ...) do {                                                      \
+        (void)hipGetLastError();                                                                                          \
+        if (g_prof_cur) {                                                                                                 \
+            ProfRec* r_ = g_prof_cur; g_prof_cur = nullptr;                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, r_->e0, r_->e1, 0, __VA_ARGS__);                      \
+        } else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                         \
+    } while (0)
 
 extern "C" int t2v_prof_begin(int max_records) {
     if (max_records < 1 || max_records > (1 << 20)) return T2V_EINVAL;
@@ -724,10 +734,10 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
                           const ConvPlan& p, hipStream_t s) {
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
     if (p.fast) {
-        if (p.vecb) T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-        else T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        else T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
     } else {
-        T2V_LAUNCH((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
     }
 }
 
@@ -779,8 +789,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         for (int i = 0; i < ngroups; ++i) { tab.tile_start[i] = (int32_t)rows; rows += groups[i].N; }
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)rows;
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, 1, ngroups, 1);
-        if (Cout == 1) T2V_LAUNCH(linear_thin_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
-        else T2V_LAUNCH(linear_thin_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
+        if (Cout == 1) T2V_LAUNCH_PROF(linear_thin_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
+        else T2V_LAUNCH_PROF(linear_thin_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
         return launch_status();
     }
     if (thin) {
@@ -792,8 +802,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         }
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
-        if (Cout == 1) T2V_LAUNCH(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
-        else T2V_LAUNCH(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
+        if (Cout == 1) T2V_LAUNCH_PROF(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
+        else T2V_LAUNCH_PROF(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
         return launch_status();
     }
     ProfScope prof(0, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);      // executed (non-padding-tap) MACs x 2
@@ -813,7 +823,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     if (p.S > 1) {
         long blocks = (tab.out_start[ngroups] + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        T2V_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
+        ProfScope prof_r(4, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);     // the split-K pass, timed on its own
+        T2V_LAUNCH_PROF(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
     }
     return launch_status();
 }
@@ -1403,13 +1414,13 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
         if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
-            T2V_LAUNCH(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows);
+            T2V_LAUNCH_PROF(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows);
         } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
-            T2V_LAUNCH(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+            T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
         } else {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
-            T2V_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+            T2V_LAUNCH_PROF(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
         }
     }
     int st = launch_status();
@@ -1417,10 +1428,10 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     const long CoCi = (long)Cout * Cin;
     ProfScope prof2(2, 0.0, s, CoCi, Cin, Cout, T, live.n, p.S);
     if (CoCi <= 16384 && p.S >= 16)
-        T2V_LAUNCH(wgrad_reduce_small_kernel, dim3((unsigned)((CoCi + 63) / 64), (unsigned)T), dim3(256), 0, s, slab, dw, CoCi, T,
+        T2V_LAUNCH_PROF(wgrad_reduce_small_kernel, dim3((unsigned)((CoCi + 63) / 64), (unsigned)T), dim3(256), 0, s, slab, dw, CoCi, T,
                    live.n, p.S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
     else
-        T2V_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
+        T2V_LAUNCH_PROF(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
                    (flags & T2V_CONV_ACCUM) ? 1 : 0);
     return launch_status();
 }

@@ -550,6 +550,118 @@ extern "C" int t2v_lstm_gates_bwd(const float* gh, const float* gc_in, const flo
     return launch_status();
 }
 
+// ---- the recurrence on 1x1 feature maps (the TGANv2 frame-seed generator's ConvLSTM, conv_lstm.py:75-97, runs on
+// [B,1024,1,1]): each step is a [B x K] . [K x N] product with B = 32 rows — one MFMA row tile. A tiled GEMM spends its
+// time in prologue / epilogue / a separate split-K pass (25-37 us per step); here one WAVE owns a 32-column strip and a
+// K slice, streams its weights straight from memory into the MFMA B operand (no LDS, no barrier: nothing is shared between
+// waves) and writes its partial sums to a slab; the gate kernels below add the slab's slices in a fixed order.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// slab[s][m][n] = sum_{k in [s KW, (s+1) KW)} x[m][k] * w[k][n]      x: [M][K] row-major, w: [K][N] row-major
+template <int KW>
+__global__ __launch_bounds__(64) void skinny_gemm_slab_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ slab, const int M, const int K, const int N) {
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int n = blockIdx.x * 32 + l31, s = blockIdx.y, m = blockIdx.z * 32 + l31;
+    const int k0 = s * KW + 4 * hi;
+    const float* __restrict__ px = x + (size_t)(m < M ? m : M - 1) * K + k0;        // clamped row, masked below
+    const float* __restrict__ pw = w + (size_t)k0 * N + (n < N ? n : N - 1);
+    const float am = m < M ? 1.f : 0.f;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // MFMA 32x32x2: lane (l31, hi) supplies A[m = l31][k] and B[k][n = l31] for ONE k per issue; the lane's four k of an
+    // 8-wide group are k0 + kb + {0,1,2,3} (+4 for hi = 1) — any assignment works as long as A and B agree.
+#pragma unroll
+    for (int kb = 0; kb < KW; kb += 8) {
+        const float4 a = *(const float4*)(px + kb);
+        const float b0 = pw[(size_t)(kb + 0) * N], b1 = pw[(size_t)(kb + 1) * N], b2 = pw[(size_t)(kb + 2) * N],
+                    b3 = pw[(size_t)(kb + 3) * N];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x * am, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y * am, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z * am, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w * am, b3, acc, 0, 0, 0);
+    }
+    if (n < N) {
+        float* out = slab + (size_t)s * M * N + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (mr < M) out[(size_t)mr * N] = acc[r];
+        }
+    }
+}
+// K slice per wave: 128 keeps >= 1 wave per SIMD busy for the [32 x 1024 x 4096] steps; must divide K
+extern "C" int t2v_skinny_gemm_splits(int M, int K, int N) {
+    if (M < 1 || K < 1 || N < 1 || (K % 128) != 0) return T2V_EINVAL;
+    const long waves256 = (long)(K / 256) * ((N + 31) / 32) * ((M + 31) / 32);
+    return ((K % 256) == 0 && waves256 >= 1024) ? K / 256 : K / 128;
+}
+extern "C" int t2v_skinny_gemm_slab(const float* x, const float* w, float* slab, int M, int K, int N, void* st) {
+    const int S = t2v_skinny_gemm_splits(M, K, N);
+    if (!x || !w || !slab || S < 1 || S > 65535) return T2V_EINVAL;
+    dim3 grid((N + 31) / 32, S, (M + 31) / 32);
+    if (K / S == 256) T2V_LAUNCH(skinny_gemm_slab_k<256>, grid, dim3(64), 0, S_(st), x, w, slab, M, K, N);
+    else T2V_LAUNCH(skinny_gemm_slab_k<128>, grid, dim3(64), 0, S_(st), x, w, slab, M, K, N);
+    return launch_status();
+}
+
+// gate kernels that take their pre-activation / incoming dL/dh as  sum_s slab[s]  (+ bias, + a second addend)
+__global__ void lstm_gates_slab_k(const float* slab, int S, const float* bias, const float* c_prev, float* h, float* c_new,
+                                  float* act, int B, int Cc) {
+    const long n = (long)B * Cc, stride = n * 4;
+    GRID_STRIDE(i, n) {
+        const long b = i / Cc, r = i - b * Cc;
+        float p[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* ps = slab + b * 4 * Cc + (long)g * Cc + r;
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += ps[(long)s * stride];
+            p[g] = v + (bias ? bias[g * Cc + r] : 0.f);
+        }
+        const float gi = sigm(p[0]), gf = sigm(p[1]), gg = tanhf(p[2]), go = sigm(p[3]);
+        const float cc = gf * c_prev[i] + gi * gg;
+        c_new[i] = cc;
+        h[i] = go * tanhf(cc);
+        float* pa = act + b * 4 * Cc + r;
+        pa[0] = gi; pa[Cc] = gf; pa[2 * Cc] = gg; pa[3 * Cc] = go;
+    }
+}
+__global__ void lstm_gates_bwd_slab_k(const float* gh, const float* slab, int S, const float* gc_in, const float* act,
+                                      const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int Cc) {
+    const long n = (long)B * Cc;
+    GRID_STRIDE(i, n) {
+        const long b = i / Cc, r = i - b * Cc;
+        const float* pa = act + b * 4 * Cc + r;
+        const float gi = pa[0], gf = pa[Cc], gg = pa[2 * Cc], go = pa[3 * Cc];
+        const float tc = tanhf(c_new[i]);
+        float back = 0.f;                                  // dL/dh_t arriving from step t+1 = sum of the slab's slices
+        for (int s = 0; s < S; ++s) back += slab[(long)s * n + i];
+        const float dh = S > 0 ? gh[i] + back : gh[i];
+        const float dc = dh * go * (1.f - tc * tc) + (gc_in ? gc_in[i] : 0.f);
+        float* pg = gpre + b * 4 * Cc + r;
+        pg[0] = dc * gg * gi * (1.f - gi);
+        pg[Cc] = dc * c_prev[i] * gf * (1.f - gf);
+        pg[2 * Cc] = dc * gi * (1.f - gg * gg);
+        pg[3 * Cc] = dh * tc * go * (1.f - go);
+        gc_prev[i] = dc * gf;
+    }
+}
+extern "C" int t2v_lstm_gates_slab(const float* slab, int S, const float* bias, const float* c_prev, float* h, float* c_new,
+                                   float* act, int B, int C, void* st) {
+    if (!slab || S < 1 || !c_prev || !h || !c_new || !act || B < 1 || C < 1) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_gates_slab_k, dim3(nblocks((long)B * C)), dim3(256), 0, S_(st), slab, S, bias, c_prev, h, c_new, act, B, C);
+    return launch_status();
+}
+extern "C" int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S, const float* gc_in, const float* act,
+                                       const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* st) {
+    if (!gh || S < 0 || (S > 0 && !slab) || !act || !c_prev || !c_new || !gpre || !gc_prev || B < 1 || C < 1) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_gates_bwd_slab_k, dim3(nblocks((long)B * C)), dim3(256), 0, S_(st), gh, slab, S, gc_in, act, c_prev, c_new,
+               gpre, gc_prev, B, C);
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- non-local block
 // Batched thin GEMM: head dims are 4..64, so no MFMA tile fits; 16x16 output tile per workgroup,
 // K staged through LDS in 16-wide slabs.

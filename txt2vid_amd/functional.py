@@ -953,6 +953,18 @@ def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5
     return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu)
 
 
+def _skinny_ok(M, K, N):
+    return M <= 64 and int(lib().t2v_skinny_gemm_splits(M, K, N)) > 0
+
+
+def _skinny(x, wp, M, K, N):
+    """slab[S][M][N] of partial products x[M][K] . wp[K][N] (`t2v_skinny_gemm_slab`); the consumer sums the S slices."""
+    S = int(lib().t2v_skinny_gemm_splits(M, K, N))
+    slab = torch.empty((S, M, N), device=x.device, dtype=torch.float32)
+    check(lib().t2v_skinny_gemm_slab(_p(x), _p(wp), _p(slab), M, K, N, _stream()), 't2v_skinny_gemm_slab')
+    return slab, S
+
+
 class ConvLSTMFn(Function):
     """16-step single-cell ConvLSTM (conv_lstm.py:75-97). x is the input at step 0 and zero afterwards,
     so the Wx convolutions run once; from step 1 on their contribution is the bias. The four gate weights
@@ -985,6 +997,15 @@ class ConvLSTMFn(Function):
         acts = torch.empty((steps, B, 4 * Cc, h, w), device=dev, dtype=torch.float32)
         pre = torch.empty((B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         check(lib().t2v_fill(_p(cs[0]), 0.0, B * CS, _stream()), 't2v_fill')
+        if h == 1 and w == 1 and _skinny_ok(B, Cc, 4 * Cc):
+            # 1x1 maps (the TGANv2 generator): a step = one 32-row GEMM; wave-per-strip kernel + slab-summing gate kernel
+            for t in range(steps):
+                slab, S = _skinny(x5 if t == 0 else hs[t - 1], wpx if t == 0 else wph, B, Cc, 4 * Cc)
+                check(lib().t2v_lstm_gates_slab(_p(slab), S, _p(bias4), _p(cs[t]), _p(hs[t]), _p(cs[t + 1]), _p(acts[t]), B, Cc,
+                                                _stream()), 't2v_lstm_gates_slab')
+            ctx.save_for_backward(x, hs, cs, acts, *params)
+            ctx.steps = steps
+            return hs.squeeze(3)
         for t in range(steps):
             if t == 0:
                 conv_packed_raw(x5, wpx, Cc, 4 * Cc, k, bias4, out=pre)           # h0 = 0: the Wh term vanishes
@@ -1018,7 +1039,16 @@ class ConvLSTMFn(Function):
         gpre = torch.empty((steps, B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         gh_next = None           # dL/dh_t arriving from step t+1
         gc = None
-        for t in range(steps - 1, -1, -1):
+        skinny = h == 1 and w == 1 and _skinny_ok(B, 4 * Cc, Cc)
+        slab, S = None, 0
+        for t in range(steps - 1, -1, -1) if skinny else ():
+            gcp = torch.empty((B, Cc, h, w), device=dev, dtype=torch.float32)
+            check(lib().t2v_lstm_gates_bwd_slab(_p(ghs[t]), _p(slab), S, _p(gc), _p(acts[t]), _p(cs[t]), _p(cs[t + 1]), _p(gpre[t]),
+                                                _p(gcp), B, Cc, _stream()), 't2v_lstm_gates_bwd_slab')
+            gc = gcp
+            if t > 0:
+                slab, S = _skinny(gpre[t], wph1, B, 4 * Cc, Cc)
+        for t in range(steps - 1, -1, -1) if not skinny else ():
             if gh_next is None:
                 gh = ghs[t]
             else:
