@@ -260,6 +260,63 @@ struct GroupTable {
     int32_t n;
 };
 
+// ---- epilogue shared by the implicit-GEMM kernels: rows (registers) = co, columns (lanes) = m
+template <int NCO, int NM, int WCO, int WM>
+__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[NCO][NM], const GroupTable& tab, const int gi, const t2v_conv_group& gd,
+                                               const float* __restrict__ bias, float* __restrict__ slab, const int Cout,
+                                               const int flags, const int nsplit, const int m0, const int co0, const int M,
+                                               const int DHW, const int wm, const int wco, const int l31, const int hi) {
+    const bool split = nsplit > 1;
+    const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const bool accum = !split && (flags & T2V_CONV_ACCUM);
+    const bool mask_out = !split && (flags & T2V_CONV_MASK_OUT) && gd.mask != nullptr;
+    float* out = split ? slab + (size_t)blockIdx.z * (size_t)tab.out_start[tab.n] + (size_t)tab.out_start[gi] : gd.y;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int m = m0 + wm * WM + j * 32 + l31;
+        if (m >= M) continue;
+        const int n = m / DHW, sp = m - n * DHW;
+        float* py = out + (size_t)n * Cout * DHW + sp;
+        if (mask_out) {                    // ReLU adjoint fused: y = mask > 0 ? result : 0
+            const float* pm = gd.mask + (size_t)n * Cout * DHW + sp;
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) {
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    mv[r] = pm[(size_t)(co < Cout ? co : Cout - 1) * DHW];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = acc[i][j][r] + (has_bias ? bias[co < Cout ? co : 0] : 0.f);
+                    if (co < Cout) py[(size_t)co * DHW] = mv[r] > 0.f ? v : 0.f;
+                }
+            }
+        } else if (!accum) {               // (block-uniform) plain stores: no load, no wait in the store tail
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < Cout) py[(size_t)co * DHW] = acc[i][j][r] + (has_bias ? bias[co] : 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < Cout) py[(size_t)co * DHW] += acc[i][j][r] + (has_bias ? bias[co] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+
 template <int BM, int BN, int WAVES_CO, int BKT, bool FAST, bool VECB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                          const float* __restrict__ bias, float* __restrict__ slab,
@@ -458,55 +515,230 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
         cur ^= 1;
     }
 
-    // ---- epilogue: rows (registers) = co, columns (lanes) = m
-    const bool split = nsplit > 1;
-    const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
-    const bool accum = !split && (flags & T2V_CONV_ACCUM);
-    const bool mask_out = !split && (flags & T2V_CONV_MASK_OUT) && gd.mask != nullptr;
-    float* out = split ? slab + (size_t)blockIdx.z * (size_t)tab.out_start[tab.n] + (size_t)tab.out_start[gi] : gd.y;
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// STRIP variant of the implicit GEMM for kernels that are 3 taps wide along W (all the 3x3x3 / 3x3 layers on maps
+// wider than one voxel). The three dx taps of one (dz,dy) row read the same input row shifted by one voxel, so the
+// A tile is gathered and staged ONCE per (row, channel block) as a strip of BM + 2 voxels and the three chunks read
+// it at offsets -1 / 0 / +1 (row ends masked at read time, one v_cndmask per operand): a third of the scattered
+// global gathers and LDS writes per MFMA. Chunk order: (row tap, channel block, dx) with dx fastest; weights are
+// staged per chunk as before. Requires taps in product order with dx fastest (what conv_geom emits) and Cin % BKT == 0.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_CO, int BKT, bool VECB>
+__global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ slab,
+                                                               const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr int WAVES_M = 4 / WAVES_CO;
+    constexpr int WCO = BN / WAVES_CO;
+    constexpr int WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int AP = BM + 4;              // [left halo][BM voxels][right halo][pad]
+    constexpr int LA = BKT * BM / 256;
+    constexpr int KSA = 256 / BM;
+    constexpr int LB = BKT * BN / 256;
+    constexpr int KSB = 256 / BN;
+    constexpr int NV = BKT * BN / 4;
+    constexpr int LBV = NV >= 256 ? NV / 256 : 1;
+    constexpr int KSBV = 1024 / BN;
+    static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LB >= 1 && 2 * BKT <= 256, "tile");
+
+    __shared__ __attribute__((aligned(16))) float As[2 * BKT * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BKT * BN];
+    __shared__ int s_roff[T2V_MAX_TAPS];
+    __shared__ int s_widx[T2V_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
 #pragma unroll
-    for (int j = 0; j < NM; ++j) {
-        const int m = m0 + wm * WM + j * 32 + l31;
-        if (m >= M) continue;
-        const int n = m / DHW, sp = m - n * DHW;
-        float* py = out + (size_t)n * Cout * DHW + sp;
-        if (mask_out) {                    // ReLU adjoint fused: y = mask > 0 ? result : 0
-            const float* pm = gd.mask + (size_t)n * Cout * DHW + sp;
-#pragma unroll
-            for (int i = 0; i < NCO; ++i) {
-                float mv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    mv[r] = pm[(size_t)(co < Cout ? co : Cout - 1) * DHW];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = acc[i][j][r] + (has_bias ? bias[co < Cout ? co : 0] : 0.f);
-                    if (co < Cout) py[(size_t)co * DHW] = mv[r] > 0.f ? v : 0.f;
-                }
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const float* __restrict__ x = gd.x;
+    const int D = gd.D, H = gd.H, W = gd.W;
+    const int HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    const int ndx = gd.dx[0] < 0 ? 3 : 1;           // taps r*ndx + {0,1,2} = dx -1, 0, +1 of row tap r
+    const int nrow = ntaps / ndx;
+
+    if (tid < nrow) s_roff[tid] = gd.dz[tid * ndx] * HW + gd.dy[tid * ndx] * W;
+    if (tid < ntaps) s_widx[tid] = gd.widx[tid];
+
+    // ---- staging coordinates: this thread's voxel of the strip body, and (threads < 2 BKT) one halo element
+    const int ma_l = tid % BM, ka_l = tid / BM;
+    const int he = tid / BKT, hk = tid % BKT;        // halo: he = 0 left (voxel m0 - 1), 1 right (voxel m0 + BM)
+    const bool halo_thread = tid < 2 * BKT;
+    uint32_t rowmask = 0, rowmask_h = 0;
+    size_t xbase = 0, xbase_h = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {
+            const int n = m_a / DHW, sp = m_a - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase = (size_t)n * Cin * DHW + sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
             }
-        } else if (!accum) {               // (block-uniform) plain stores: no load, no wait in the store tail
-#pragma unroll
-            for (int i = 0; i < NCO; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < Cout) py[(size_t)co * DHW] = acc[i][j][r] + (has_bias ? bias[co] : 0.f);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NCO; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < Cout) py[(size_t)co * DHW] += acc[i][j][r] + (has_bias ? bias[co] : 0.f);
-                }
+        }
+        const int m_h = he ? m0 + BM : m0 - 1;
+        if (halo_thread && m_h >= 0 && m_h < M) {
+            const int n = m_h / DHW, sp = m_h - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase_h = (size_t)n * Cin * DHW + sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
             }
         }
     }
+    // ---- reader coordinates: may this lane's voxel look one step left / right inside its row?
+    bool can_l[NM], can_r[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int m = m0 + wm * WM + j * 32 + l31;
+        const int w_ = m % W;
+        can_l[j] = w_ > 0;
+        can_r[j] = w_ < W - 1;
+    }
+    const int cob_l = tid % BN, kb_l = tid / BN;
+    const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4);
+    const bool vact = (NV >= 256) || (tid < NV);
+    const bool co_ok = VECB ? (vact && (co0 + cv_l) < Cout) : (co0 + cob_l) < Cout;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+
+    f32x16 acc[NCO][NM];
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[LA], rah = 0.f;
+    float rb[VECB ? 1 : LB];
+    float4 rbv[VECB ? LBV : 1];
+    const int ncb = Cin / BKT;
+    const int nchunks = ntaps * ncb;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * cps;
+    int q1 = q0 + cps;
+    if (q1 > nchunks) q1 = nchunks;
+    __syncthreads();   // s_roff / s_widx visible
+
+    // chunk q = (r * ncb + cb) * ndx + d
+    int r_cur = q0 / (ncb * ndx);
+    int cb_cur = (q0 - r_cur * ncb * ndx) / ndx;
+    int d_cur = q0 - (r_cur * ncb + cb_cur) * ndx;
+    auto advance = [&]() {
+        if (++d_cur == ndx) { d_cur = 0; if (++cb_cur == ncb) { cb_cur = 0; ++r_cur; } }
+    };
+    bool pend_has_a = false, pend_av = false, pend_hv = false;
+    int pend_dx = 0;
+    // loads are unconditional from clamped addresses; masking happens when the registers go to LDS (see conv_igemm_kernel)
+    auto load_chunk = [&](bool force_a) {
+        const int c0 = cb_cur * BKT;
+        pend_has_a = force_a || d_cur == 0;
+        pend_dx = ndx == 3 ? d_cur - 1 : 0;
+        if (pend_has_a) {
+            pend_av = (rowmask >> r_cur) & 1u;
+            const float* px = x + xbase + (pend_av ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + ka_l) * DHW;
+#pragma unroll
+            for (int j = 0; j < LA; ++j) ra[j] = px[(size_t)j * KSA * DHW];
+            if (halo_thread) {
+                pend_hv = (rowmask_h >> r_cur) & 1u;
+                rah = x[xbase_h + (pend_hv ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + hk) * DHW];
+            }
+        }
+        const int t = r_cur * ndx + d_cur;
+        if (VECB) {
+            const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kv_l) * Cout + co0 + cv_l : wp;
+#pragma unroll
+            for (int j = 0; j < LBV; ++j) rbv[j] = *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout);
+        } else {
+            const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kb_l) * Cout + co0 + cob_l : wp;
+#pragma unroll
+            for (int j = 0; j < LB; ++j) rb[j] = pw[(size_t)j * KSB * Cout];
+        }
+    };
+    auto stage = [&](int ab, int bb) {
+        if (pend_has_a) {
+            float* as = As + ab * (BKT * AP);
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const float val = pend_av ? ra[j] : 0.f;
+                as[(ka_l + j * KSA) * AP + 1 + ma_l] = relu_in ? fmaxf(val, 0.f) : val;
+            }
+            if (halo_thread) {
+                const float val = pend_hv ? rah : 0.f;
+                as[hk * AP + (he ? BM + 1 : 0)] = relu_in ? fmaxf(val, 0.f) : val;
+            }
+        }
+        float* bs = Bs + bb * (BKT * BN);
+        if (VECB) {
+#pragma unroll
+            for (int j = 0; j < LBV; ++j)
+                if (vact) *reinterpret_cast<float4*>(&bs[(kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rbv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < LB; ++j) bs[(kb_l + j * KSB) * BN + cob_l] = co_ok ? rb[j] : 0.f;
+        }
+    };
+
+    int acur = 0, bcur = 0, dx_now = 0;
+    if (q0 < q1) {
+        load_chunk(true);
+        stage(0, 0);
+        dx_now = pend_dx;
+        __syncthreads();
+        if (q0 + 1 < q1) { advance(); load_chunk(false); }
+    }
+    for (int q = q0; q < q1; ++q) {
+        const float* as = As + acur * (BKT * AP) + 1 + dx_now + wm * WM + l31;
+        const float* bs = Bs + bcur * (BKT * BN) + wco * WCO + l31;
+        bool keep[NM];
+#pragma unroll
+        for (int j = 0; j < NM; ++j) keep[j] = dx_now < 0 ? can_l[j] : (dx_now > 0 ? can_r[j] : true);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < BKT / 2; ++k2) {
+            float a[NCO], b[NM];
+            const int krow = k2 * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < NCO; ++i) a[i] = bs[krow * BN + i * 32];
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const float v = as[krow * AP + j * 32];
+                b[j] = keep[j] ? v : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NCO; ++i)
+#pragma unroll
+                for (int j = 0; j < NM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const bool more = q + 1 < q1;
+        const bool next_a = more && pend_has_a;
+        int dx_next = dx_now;
+        if (more) { stage(acur ^ 1, bcur ^ 1); dx_next = pend_dx; }
+        __syncthreads();
+        if (q + 2 < q1) { advance(); load_chunk(false); }
+        bcur ^= 1;
+        if (next_a) acur ^= 1;
+        dx_now = dx_next;
+    }
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
 
 // y_g = (accum ? y_g : 0) + bias[co] + sum_s slab[s]   (fixed summation order), for every group
@@ -729,10 +961,35 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     return true;
 }
 
+// strip variant: every member's taps come in product order with dx fastest, and members that are wider than one voxel
+// carry all three dx taps per row
+static bool strip_ok(const GroupTable& tab) {
+    bool any3 = false;
+    for (int i = 0; i < tab.n; ++i) {
+        const t2v_conv_group& g = tab.g[i];
+        const int ndx = g.dx[0] < 0 ? 3 : 1;
+        if (g.ntaps % ndx) return false;
+        for (int r = 0; r < g.ntaps / ndx; ++r)
+            for (int d = 0; d < ndx; ++d) {
+                const int t = r * ndx + d;
+                if (g.dx[t] != (ndx == 3 ? d - 1 : 0) || g.dz[t] != g.dz[r * ndx] || g.dy[t] != g.dy[r * ndx]) return false;
+            }
+        if (ndx == 3 && g.W < 2) return false;
+        any3 = any3 || ndx == 3;
+    }
+    return any3;
+}
+static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
+
 template <int BM, int BN, int WAVES_CO, int BKT>
 static void launch_conv_t(const GroupTable& tab, const float* wp, const float* bias, float* slab, int Cin, int Cout, int flags,
                           const ConvPlan& p, hipStream_t s) {
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
+    if (p.fast && BKT == 32 && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
+        if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        return;
+    }
     if (p.fast) {
         if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
         else T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, BKT, true, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
