@@ -141,6 +141,17 @@ int t2v_avgpool3d(const float* x, const float* x2, float* y, int NC, int D, int 
                   const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
 int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, int Do, int Ho, int Wo,
                       const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
+/* Multi-tensor forms: `jobs` is a HOST array; 8 jobs per launch, descriptors passed in the kernel arguments (the pyramid
+   levels of one DownBlock are pooled together). fwd: y = pool(x [+ x2]) [+ add]. bwd: x = dL/dy [NC,Do,Ho,Wo], y = dL/dx
+   [NC,D,H,W]; only un-padded windows with kernel <= stride (what DownSample produces, layers.py:197-217). */
+typedef struct t2v_pool_job {
+    const float* x; const float* x2; float* y;
+    const float* add;    /* fwd only, optional: y = pool(x [+ x2]) + add  (add has y's shape: the stem's skip, resnet3d.py:16-19) */
+    int32_t NC, D, H, W, Do, Ho, Wo;
+    int32_t k[3], s[3], p[3];
+} t2v_pool_job;
+int t2v_avgpool3d_multi(const t2v_pool_job* jobs, int njobs, void* stream);
+int t2v_avgpool3d_bwd_multi(const t2v_pool_job* jobs, int njobs, void* stream);
 
 /* max_pool [1,2,2] / [2,2] (layers.py:26-27,57-58): y + flat argmax index inside the (H,W) plane.
  * `_scatter`: gx = 0 except gx[idx] = g;  `_gather`: y = x[idx]. */

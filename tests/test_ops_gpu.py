@@ -140,6 +140,38 @@ def test_avgpool():
         close(xd.grad, xr.grad)
 
 
+def test_avgpool_group_matches_torch_first_and_second_order():
+    """Multi-tensor pooling (`t2v_avgpool3d_multi` / `_bwd_multi`): pool(x + x2) + add over four differently shaped
+    members, incl. the stem's kernel (1,2,2) / stride 2 and an identity member; gradients of a GP-shaped loss."""
+    from txt2vid_amd import functional as TF
+    shapes = [(2, 3, 4, 8, 8), (1, 3, 2, 6, 4), (3, 3, 1, 4, 4), (2, 3, 1, 1, 1)]
+    cfgs = [((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((1, 2, 2), (2, 2, 2), (0, 0, 0)), ((1, 2, 2), (1, 2, 2), (0, 0, 0)),
+            ((1, 1, 1), (1, 1, 1), (0, 0, 0))]
+    xs0 = [rnd(30 + i, *s) for i, s in enumerate(shapes)]
+    x2s0 = [rnd(40 + i, *s) for i, s in enumerate(shapes)]
+
+    def run(pool, to):
+        xs = [to(x).requires_grad_(True) for x in xs0]
+        x2s = [to(x).requires_grad_(True) for x in x2s0]
+        ys0 = pool(xs, x2s, None)
+        adds = [to(rnd(50 + i, *y.shape)).requires_grad_(True) for i, y in enumerate(ys0)]
+        ys = pool(xs, x2s, adds)
+        out = sum((y ** 3).sum() for y in ys)
+        g1 = torch.autograd.grad(out, xs + adds, create_graph=True)
+        loss = out + sum((g * g).sum() for g in g1)
+        loss.backward()
+        return [y.detach() for y in ys] + [t.grad for t in xs + x2s + adds]
+
+    def torch_pool(xs, x2s, adds):
+        ys = [F.avg_pool3d(x + x2, k, s, p) for x, x2, (k, s, p) in zip(xs, x2s, cfgs)]
+        return ys if adds is None else [y + a for y, a in zip(ys, adds)]
+
+    ref = run(torch_pool, lambda t: t.double())
+    got = run(lambda xs, x2s, adds: TF.avg_pool3d_group(xs, cfgs, x2s=x2s, adds=adds), lambda t: t.to(dev()))
+    for a, r in zip(got, ref):
+        close(a, r.float(), rtol=1e-4, atol=1e-4)
+
+
 def test_maxpool_softmax_bmm_double_backward():
     from txt2vid_amd import functional as TF
     th, ph, gg = rnd(1, 2, 4, 16), rnd(2, 2, 4, 2, 4, 4), rnd(3, 2, 8, 2, 4, 4)

@@ -33,6 +33,13 @@ class AdamJob(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
 
 
+class PoolJob(C.Structure):
+    """t2v_pool_job (include/t2v_hip.h)."""
+    _fields_ = [('x', C.c_void_p), ('x2', C.c_void_p), ('y', C.c_void_p), ('add', C.c_void_p), ('NC', C.c_int32), ('D', C.c_int32), ('H', C.c_int32),
+                ('W', C.c_int32), ('Do', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32), ('k', C.c_int32 * 3), ('s', C.c_int32 * 3),
+                ('p', C.c_int32 * 3)]
+
+
 class PackJob(C.Structure):
     """Mirror of `t2v_pack_job` (include/t2v_hip.h)."""
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('Cout', C.c_int32), ('Cin', C.c_int32), ('T', C.c_int32),
@@ -78,6 +85,8 @@ SIGNATURES = {
     't2v_tanh_bwd': [_P, _P, _P, _L, _P],
     't2v_avgpool3d': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
     't2v_avgpool3d_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I3, _I3, _I3, _P],
+    't2v_avgpool3d_multi': [_P, _I, _P],
+    't2v_avgpool3d_bwd_multi': [_P, _I, _P],
     't2v_maxpool2x2': [_P, _P, _P, _L, _I, _I, _P],
     't2v_maxpool2x2_scatter': [_P, _P, _P, _L, _I, _I, _P],
     't2v_maxpool2x2_gather': [_P, _P, _P, _L, _I, _I, _P],

@@ -199,6 +199,98 @@ __global__ void avgpool3d_bwd_simple_k(const float* gy, float* gx, int NC, int D
         gx[i] = in ? gy[((nc * Do + d_o) * Ho + ho) * (long)Wo + wo] * inv : 0.f;
     }
 }
+// Multi-tensor forms (the pyramid levels of one DownBlock pooled by ONE launch): up to 8 jobs by value in the kernel
+// arguments; a workgroup handles 1024 consecutive output elements of one job.
+#define POOL_MT 8
+#define POOL_CHUNK 1024
+struct PoolBatch { t2v_pool_job j[POOL_MT]; int begin[POOL_MT + 1]; int n; };
+__global__ __launch_bounds__(256) void avgpool3d_multi_k(const PoolBatch tb) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < POOL_MT; ++k)
+        if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
+    const t2v_pool_job& q = tb.j[ji];
+    const int D = q.D, H = q.H, W = q.W, Do = q.Do, Ho = q.Ho, Wo = q.Wo;
+    const long n = (long)q.NC * Do * Ho * Wo;
+    const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const float* __restrict__ x = q.x;
+    const float* __restrict__ x2 = q.x2;
+    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; r /= Ho;
+        int d_o = r % Do; long nc = r / Do;
+        const long off = nc * (long)D * H * W;
+        float acc = 0.f;
+        for (int a = 0; a < q.k[0]; ++a) {
+            int d = d_o * q.s[0] - q.p[0] + a;
+            if ((unsigned)d >= (unsigned)D) continue;
+            for (int b = 0; b < q.k[1]; ++b) {
+                int h = ho * q.s[1] - q.p[1] + b;
+                if ((unsigned)h >= (unsigned)H) continue;
+                for (int c = 0; c < q.k[2]; ++c) {
+                    int w = wo * q.s[2] - q.p[2] + c;
+                    if ((unsigned)w >= (unsigned)W) continue;
+                    const long o = off + ((long)d * H + h) * W + w;
+                    acc += x2 ? x[o] + x2[o] : x[o];
+                }
+            }
+        }
+        q.y[i] = acc * inv + (q.add ? q.add[i] : 0.f);
+    }
+}
+// adjoint for non-overlapping unpadded windows (what DownSample produces): job.x = dL/dy [NC,Do,Ho,Wo], job.y = dL/dx
+__global__ __launch_bounds__(256) void avgpool3d_bwd_multi_k(const PoolBatch tb) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < POOL_MT; ++k)
+        if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
+    const t2v_pool_job& q = tb.j[ji];
+    const int D = q.D, H = q.H, W = q.W, Do = q.Do, Ho = q.Ho, Wo = q.Wo;
+    const long n = (long)q.NC * D * H * W;
+    const float inv = 1.f / (float)(q.k[0] * q.k[1] * q.k[2]);
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const float* __restrict__ gy = q.x;
+    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
+        int w = i % W; long r = i / W;
+        int h = r % H; r /= H;
+        int d = r % D; long nc = r / D;
+        const int d_o = d / q.s[0], ho = h / q.s[1], wo = w / q.s[2];
+        const bool in = (d - d_o * q.s[0] < q.k[0]) && (h - ho * q.s[1] < q.k[1]) && (w - wo * q.s[2] < q.k[2]) &&
+                        d_o < Do && ho < Ho && wo < Wo;
+        q.y[i] = in ? gy[((nc * Do + d_o) * Ho + ho) * (long)Wo + wo] * inv : 0.f;
+    }
+}
+static int pool_multi(const t2v_pool_job* jobs, int njobs, bool bwd, void* st) {
+    if (!jobs || njobs < 1) return T2V_EINVAL;
+    for (int at = 0; at < njobs; at += POOL_MT) {
+        PoolBatch tb;
+        const int cnt = njobs - at < POOL_MT ? njobs - at : POOL_MT;
+        long blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const t2v_pool_job& q = jobs[at + i];
+            if (!q.x || !q.y || q.NC < 1 || q.D < 1 || q.H < 1 || q.W < 1 || q.Do < 1 || q.Ho < 1 || q.Wo < 1) return T2V_EINVAL;
+            for (int a = 0; a < 3; ++a) {
+                if (q.k[a] < 1 || q.k[a] > 4 || q.s[a] < 1 || q.p[a] < 0) return T2V_EINVAL;
+                if (bwd && (q.p[a] != 0 || q.k[a] > q.s[a])) return T2V_EINVAL;      // the simple adjoint only
+            }
+            tb.j[i] = q;
+            tb.begin[i] = (int)blocks;
+            const long n = bwd ? (long)q.NC * q.D * q.H * q.W : (long)q.NC * q.Do * q.Ho * q.Wo;
+            blocks += (n + POOL_CHUNK - 1) / POOL_CHUNK;
+        }
+        for (int i = cnt; i <= POOL_MT; ++i) tb.begin[i] = (int)blocks;
+        for (int i = cnt; i < POOL_MT; ++i) tb.j[i] = tb.j[0];
+        tb.n = cnt;
+        if (blocks > 0x7fffffffL) return T2V_EINVAL;
+        if (bwd) T2V_LAUNCH(avgpool3d_bwd_multi_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb);
+        else T2V_LAUNCH(avgpool3d_multi_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb);
+    }
+    return launch_status();
+}
+extern "C" int t2v_avgpool3d_multi(const t2v_pool_job* jobs, int njobs, void* st) { return pool_multi(jobs, njobs, false, st); }
+extern "C" int t2v_avgpool3d_bwd_multi(const t2v_pool_job* jobs, int njobs, void* st) { return pool_multi(jobs, njobs, true, st); }
+
 static bool pool_ok(const int32_t* k, const int32_t* s, const int32_t* p) {
     for (int i = 0; i < 3; ++i)
         if (k[i] < 1 || k[i] > 4 || s[i] < 1 || p[i] < 0) return false;

@@ -614,6 +614,97 @@ class AvgPool3dBwd(Function):
         return AvgPool3d.apply(gg, k, s, p), None, None, None, None
 
 
+def _pool_jobs(ins, in2s, outs, cfgs, in_sps, adds=None):
+    """t2v_pool_job array: cfgs[i] = (k, s, p); in_sps[i] = (D, H, W) of the un-pooled tensor; NC from outs[i]."""
+    from ._lib import PoolJob
+    arr = (PoolJob * len(ins))()
+    for i, a in enumerate(arr):
+        k, s_, p = cfgs[i]
+        D, H, W = in_sps[i]
+        a.x, a.y = ins[i].data_ptr(), outs[i].data_ptr()
+        a.x2 = in2s[i].data_ptr() if in2s is not None else None
+        a.add = adds[i].data_ptr() if adds is not None else None
+        a.NC = outs[i].shape[0] * outs[i].shape[1]
+        a.D, a.H, a.W = D, H, W
+        a.Do, a.Ho, a.Wo = _pool_out(D, k[0], s_[0], p[0]), _pool_out(H, k[1], s_[1], p[1]), _pool_out(W, k[2], s_[2], p[2])
+        for j in range(3):
+            a.k[j], a.s[j], a.p[j] = k[j], s_[j], p[j]
+    return arr
+
+
+class AvgPool3dG(Function):
+    """ys[i] = pool_i(xs[i] (+ x2s[i])) (+ adds[i]) for several tensors (the pyramid levels of a DownBlock) in ONE launch.
+    args: cfgs (tuple of (k, s, p)), has_second, has_add, then the xs, the x2s, the adds. Members whose output receives
+    no gradient cost nothing in the backward."""
+
+    @staticmethod
+    def forward(ctx, cfgs, has2, has_add, *ts):
+        n = len(cfgs)
+        xs = [_c(t) for t in ts[:n]]
+        x2s = [_c(t) for t in ts[n:2 * n]] if has2 else None
+        adds = [_c(t) for t in ts[(2 * n if has2 else n):]] if has_add else None
+        in_sps = [tuple(x.shape[2:]) for x in xs]
+        ys = []
+        for x, (k, s_, p) in zip(xs, cfgs):
+            ys.append(torch.empty((x.shape[0], x.shape[1], _pool_out(x.shape[2], k[0], s_[0], p[0]),
+                                   _pool_out(x.shape[3], k[1], s_[1], p[1]), _pool_out(x.shape[4], k[2], s_[2], p[2])),
+                                  device=x.device, dtype=torch.float32))
+        if adds is not None and any(a.shape != y.shape for a, y in zip(adds, ys)):
+            raise ValueError('addend / pooled shape mismatch')
+        check(lib().t2v_avgpool3d_multi(_pool_jobs(xs, x2s, ys, cfgs, in_sps, adds), n, _stream()), 't2v_avgpool3d_multi')
+        ctx.cfg = (cfgs, has2, has_add, in_sps)
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cfgs, has2, has_add, in_sps = ctx.cfg
+        n = len(cfgs)
+        live = [i for i, g in enumerate(gs) if g is not None]
+        gxs = [None] * n
+        if live:
+            res = AvgPool3dBwdG.apply(tuple(cfgs[i] for i in live), tuple(in_sps[i] for i in live), *[gs[i] for i in live])
+            for i, r in zip(live, res):
+                gxs[i] = r
+        return (None, None, None) + tuple(gxs) + (tuple(gxs) if has2 else ()) + (tuple(gs) if has_add else ())
+
+
+class AvgPool3dBwdG(Function):
+    @staticmethod
+    def forward(ctx, cfgs, in_sps, *gs):
+        gs = [_c(g) for g in gs]
+        gxs = [torch.empty((g.shape[0], g.shape[1]) + tuple(sp), device=g.device, dtype=torch.float32) for g, sp in zip(gs, in_sps)]
+        check(lib().t2v_avgpool3d_bwd_multi(_pool_jobs(gs, None, gxs, cfgs, in_sps), len(gs), _stream()), 't2v_avgpool3d_bwd_multi')
+        ctx.cfg = cfgs
+        ctx.set_materialize_grads(False)
+        return tuple(gxs)
+
+    @staticmethod
+    def backward(ctx, *ggs):
+        cfgs = ctx.cfg
+        live = [i for i, g in enumerate(ggs) if g is not None]
+        out = [None] * len(cfgs)
+        if live:
+            res = AvgPool3dG.apply(tuple(cfgs[i] for i in live), False, False, *[ggs[i] for i in live])
+            for i, r in zip(live, res):
+                out[i] = r
+        return (None, None) + tuple(out)
+
+
+def avg_pool3d_group(xs, cfgs, x2s=None, adds=None):
+    """cfgs[i] = (k, s, p) per tensor; x2s: pool(xs[i] + x2s[i]); adds: ... + adds[i] (pooled shape). Falls back to
+    per-tensor launches for padded / overlapping windows (their adjoint is the general gather kernel)."""
+    cfgs = tuple((tuple(k), tuple(s_), tuple(p)) for k, s_, p in cfgs)
+    if any(any(p) or any(kk > ss for kk, ss in zip(k, s_)) for k, s_, p in cfgs) or len(xs) > 8:
+        if x2s is None:
+            ys = [avg_pool3d(x, *c) for x, c in zip(xs, cfgs)]
+        else:
+            ys = [add_avg_pool3d(x, x2, *c) for x, x2, c in zip(xs, x2s, cfgs)]
+        return ys if adds is None else [add(y, a) for y, a in zip(ys, adds)]
+    ts = list(xs) + (list(x2s) if x2s is not None else []) + (list(adds) if adds is not None else [])
+    return list(AvgPool3dG.apply(cfgs, x2s is not None, adds is not None, *ts))
+
+
 def avg_pool3d(x, k, s, p=(0, 0, 0)):
     return AvgPool3d.apply(x, tuple(k), tuple(s), tuple(p))
 

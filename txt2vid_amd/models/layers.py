@@ -299,7 +299,7 @@ def down_block_levels(block, xs):
     hs = TF.conv_group(hs, m[3].weight, m[3].bias, relu_in=True)
     ss = TF.conv_group(xs, idm[0].weight, idm[0].bias)
     if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
-        return [downsample_sum(s_, h) for s_, h in zip(ss, hs)]
+        return TF.avg_pool3d_group(ss, [downsample_cfg(s_) for s_ in ss], x2s=hs)     # one launch for all levels
     return [TF.add(idm[1](s_), m[4](h)) for s_, h in zip(ss, hs)]
 
 
