@@ -59,6 +59,8 @@ class GradArena(object):
         for v, p in zip(self.views(), self.params):
             if p.grad is None:
                 v.zero_()
+            elif p.grad.data_ptr() == v.data_ptr():
+                continue                      # the producing kernel already wrote it here (functional.GradSink)
             elif self.copy_fn is not None and p.grad.is_cuda:
                 self.copy_fn(p.grad, v)
             else:

@@ -61,6 +61,60 @@ def input_grads_only():
         _param_grads_enabled = old
 
 
+class GradSink(object):
+    """Weight / bias gradients written straight into a flat per-model arena (`dist.GradArena`) by the kernels that
+    produce them: the first producer of a step stores, later producers of the same parameter accumulate in place
+    (T2V_CONV_ACCUM) and hand autograd nothing — no per-parameter sum kernels, and the data-parallel exchange finds
+    the gradients already in its buffer. Only used while autograd is not recording (the final `loss.backward()`);
+    `reset()` belongs wherever the model's gradients are cleared."""
+
+    def __init__(self, arenas):
+        self.slots, self.count = {}, {}
+        for arena in arenas:
+            for off, p in zip(arena.offsets, arena.params):
+                self.slots[id(p)] = (arena, off, p.numel())
+
+    def reset(self):
+        self.count.clear()
+
+    def take(self, param):
+        slot = self.slots.get(id(param))
+        if slot is None:
+            return None
+        arena, off, n = slot
+        c = self.count.get(id(param), 0)
+        self.count[id(param)] = c + 1
+        return arena.flat[off:off + n], c > 0
+
+
+_grad_sink = None
+
+
+def set_grad_sink(sink):
+    global _grad_sink
+    old, _grad_sink = _grad_sink, sink
+    return old
+
+
+def grad_sink_reset():
+    if _grad_sink is not None:
+        _grad_sink.reset()
+
+
+def _to_sink(param_like, compute):
+    """If `param_like` (a parameter or a view of one) has a sink slot: run compute(out, accum) into it and return
+    (True, grad for autograd — a fresh view the first time, None when accumulated). Else (False, None)."""
+    if _grad_sink is None or param_like is None or torch.is_grad_enabled():
+        return False, None
+    base = param_like._base if param_like._base is not None else param_like
+    slot = _grad_sink.take(base)
+    if slot is None:
+        return False, None
+    flat, accum = slot
+    compute(flat.view(param_like.shape), accum)
+    return True, (None if accum else flat.view(param_like.shape))
+
+
 def bump_weight_epoch(params=None):
     """Tell the packed-weight caches that parameters were rewritten behind autograd's back (raw-pointer kernels do
     not bump `_version`): the given ones, or — with no argument — every parameter."""
@@ -314,27 +368,28 @@ def conv_dgrad_raw(gy5, w5, out=None, accum=False):
     return gx
 
 
-def conv_wgrad_raw(x5, gy5, wshape, relu_in=False):
+def conv_wgrad_raw(x5, gy5, wshape, relu_in=False, out=None, accum=False):
     x5, gy5 = _c(x5), _c(gy5)
     g = conv_geom(x5.shape[0], wshape[1], x5.shape[2], x5.shape[3], x5.shape[4], wshape[0], wshape[2], wshape[3], wshape[4])
     n = lib().t2v_conv_wgrad_slab_floats(C.byref(g.cg), g.T)
     if n <= 0:
         raise RuntimeError('bad wgrad geometry')
     slab = torch.empty((n,), device=x5.device, dtype=torch.float32)
-    dw = torch.empty(tuple(wshape), device=x5.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(tuple(wshape), device=x5.device, dtype=torch.float32)
     check(lib().t2v_conv_wgrad(_p(x5), _p(gy5), _p(dw), _p(slab), C.byref(g.cg), g.taps_c, g.T,
-                               FLAG_RELU_IN if relu_in else 0, _stream()), 't2v_conv_wgrad')
+                               (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0), _stream()), 't2v_conv_wgrad')
     return dw
 
 
-def channel_sum_raw(t5):
+def channel_sum_raw(t5, out=None, accum=False):
     t5 = _c(t5)
     N, Cc = t5.shape[0], t5.shape[1]
     S = t5.numel() // (N * Cc)
-    out = torch.empty((Cc,), device=t5.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((Cc,), device=t5.device, dtype=torch.float32)
     nws = int(lib().t2v_channel_sum_ws_floats(N, Cc, S))
     ws = torch.empty((nws,), device=t5.device, dtype=torch.float32) if nws > 0 else None
-    check(lib().t2v_channel_sum(_p(t5), _p(out), _p(ws), N, Cc, S, 0, _stream()), 't2v_channel_sum')
+    check(lib().t2v_channel_sum(_p(t5), _p(out), _p(ws), N, Cc, S, 1 if accum else 0, _stream()), 't2v_channel_sum')
     return out
 
 
@@ -344,7 +399,7 @@ class Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+        ctx.has_bias, ctx.bias = b is not None, b
         return conv_fwd_raw(x, w, b)
 
     @staticmethod
@@ -355,9 +410,13 @@ class Conv(Function):
             gx = ConvDgrad.apply(gy, w)
         if _param_grads_enabled:
             if ctx.needs_input_grad[1]:
-                gw = ConvWgrad.apply(x, gy, tuple(w.shape))
+                done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), out=out, accum=acc))
+                if not done:
+                    gw = ConvWgrad.apply(x, gy, tuple(w.shape))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ChannelSum.apply(gy)
+                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
+                if not done:
+                    gb = ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -376,7 +435,9 @@ class ConvDgrad(Function):
         if ctx.needs_input_grad[0]:
             d_gy = Conv.apply(ggx, w, None)
         if ctx.needs_input_grad[1] and _param_grads_enabled:
-            d_w = ConvWgrad.apply(ggx, gy, tuple(w.shape))
+            done, d_w = _to_sink(w, lambda out, acc: conv_wgrad_raw(ggx, gy, tuple(w.shape), out=out, accum=acc))
+            if not done:
+                d_w = ConvWgrad.apply(ggx, gy, tuple(w.shape))
         return d_gy, d_w
 
 
@@ -408,7 +469,7 @@ class ReluConv(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+        ctx.has_bias, ctx.bias = b is not None, b
         return conv_fwd_raw(x, w, b, relu_in=True)
 
     @staticmethod
@@ -419,9 +480,13 @@ class ReluConv(Function):
             gx = ConvDgradMaskG.apply(w, 1, gy, x)[0]          # dgrad(gy, w) * [x > 0] in one launch
         if _param_grads_enabled:
             if ctx.needs_input_grad[1]:
-                gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
+                done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), relu_in=True, out=out, accum=acc))
+                if not done:
+                    gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = ChannelSum.apply(gy)
+                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
+                if not done:
+                    gb = ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -1815,7 +1880,7 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
     return ys
 
 
-def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False):
+def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False):
     xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
     Cout, Cin = wshape[0], wshape[1]
     k = tuple(wshape[2:])
@@ -1825,9 +1890,10 @@ def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False):
     if n <= 0:
         raise RuntimeError('bad grouped wgrad geometry')
     slab = torch.empty((n,), device=xs5[0].device, dtype=torch.float32)
-    dw = torch.empty(tuple(wshape), device=xs5[0].device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(tuple(wshape), device=xs5[0].device, dtype=torch.float32)
     check(lib().t2v_conv_wgrad_grouped(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(slab),
-                                       FLAG_RELU_IN if relu_in else 0, _stream()), 't2v_conv_wgrad_grouped')
+                                       (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0), _stream()),
+          't2v_conv_wgrad_grouped')
     return dw
 
 
@@ -1846,7 +1912,7 @@ class ConvG(Function):
     def forward(ctx, w, b, relu_in, *xs):
         ctx.save_for_backward(w, *xs)
         ctx.set_materialize_grads(False)          # members nobody differentiates arrive as None, not as zeros
-        ctx.has_bias, ctx.relu_in = b is not None, relu_in
+        ctx.has_bias, ctx.relu_in, ctx.bias = b is not None, relu_in, b
         return tuple(conv_group_raw(xs, w, b, relu_in, 0))
 
     @staticmethod
@@ -1867,10 +1933,15 @@ class ConvG(Function):
             for i, r in zip(need, res):
                 gxs[i] = r
         if _param_grads_enabled:
+            lx, lg = [xs[i] for i in live], [gys[i] for i in live]
             if ctx.needs_input_grad[0]:
-                gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *([xs[i] for i in live] + [gys[i] for i in live]))
+                done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), ctx.relu_in, out=out, accum=acc))
+                if not done:
+                    gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *(lx + lg))
             if ctx.has_bias and ctx.needs_input_grad[1]:
-                gb = ChannelSumG.apply(*[gys[i] for i in live])
+                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_group_raw(lg, out=out, accum=acc))
+                if not done:
+                    gb = ChannelSumG.apply(*lg)
         return (gw, gb, None) + tuple(gxs)
 
 
@@ -1895,7 +1966,10 @@ class ConvDgradG(Function):
         if not live:
             return (None,) + tuple(d_gys)
         if ctx.needs_input_grad[0] and _param_grads_enabled:
-            d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *([ggxs[i] for i in live] + [gys[i] for i in live]))
+            lx, lg = [ggxs[i] for i in live], [gys[i] for i in live]
+            done, d_w = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), False, out=out, accum=acc))
+            if not done:
+                d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *(lx + lg))
         need = [i for i in live if ctx.needs_input_grad[1 + i]]
         if need:
             res = ConvG.apply(w, None, False, *[ggxs[i] for i in need])
@@ -1928,7 +2002,10 @@ class ConvDgradMaskG(Function):
         if live:
             hs = {i: ReluMask.apply(ggxs[i], xs[i]) for i in live}
             if ctx.needs_input_grad[0] and _param_grads_enabled:
-                d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *([hs[i] for i in live] + [gys[i] for i in live]))
+                lx, lg = [hs[i] for i in live], [gys[i] for i in live]
+                done, d_w = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), False, out=out, accum=acc))
+                if not done:
+                    d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *(lx + lg))
             need = [i for i in live if ctx.needs_input_grad[2 + i]]
             if need:
                 res = ConvG.apply(w, None, False, *[hs[i] for i in need])
@@ -1967,22 +2044,27 @@ class ConvWgradG(Function):
         return (None, None, None) + tuple(d_xs) + tuple(d_gys)
 
 
+def channel_sum_group_raw(gys, out=None, accum=False):
+    gys = [_c(g) for g in gys]
+    Cc = gys[0].shape[1]
+    arr = (ConvGroup * len(gys))()
+    for a, g in zip(arr, gys):
+        a.x, a.N = g.data_ptr(), g.shape[0]
+        a.D, a.H, a.W = g.shape[2], g.shape[3], g.shape[4]
+    if out is None:
+        out = torch.empty((Cc,), device=gys[0].device, dtype=torch.float32)
+    nws = int(lib().t2v_channel_sum_grouped_ws_floats(arr, len(gys), Cc))
+    ws = torch.empty((nws,), device=out.device, dtype=torch.float32) if nws > 0 else None
+    check(lib().t2v_channel_sum_grouped(arr, len(gys), Cc, _p(out), _p(ws), 1 if accum else 0, _stream()), 't2v_channel_sum_grouped')
+    return out
+
+
 class ChannelSumG(Function):
     """bias gradient of a grouped convolution: sum over every member, one launch."""
 
     @staticmethod
     def forward(ctx, *gys):
-        gys = [_c(g) for g in gys]
-        Cc = gys[0].shape[1]
-        arr = (ConvGroup * len(gys))()
-        for a, g in zip(arr, gys):
-            a.x, a.N = g.data_ptr(), g.shape[0]
-            a.D, a.H, a.W = g.shape[2], g.shape[3], g.shape[4]
-        out = torch.empty((Cc,), device=gys[0].device, dtype=torch.float32)
-        nws = int(lib().t2v_channel_sum_grouped_ws_floats(arr, len(gys), Cc))
-        ws = torch.empty((nws,), device=out.device, dtype=torch.float32) if nws > 0 else None
-        check(lib().t2v_channel_sum_grouped(arr, len(gys), Cc, _p(out), _p(ws), 0, _stream()), 't2v_channel_sum_grouped')
-        return out
+        return channel_sum_group_raw(gys)
 
     @staticmethod
     @once_differentiable

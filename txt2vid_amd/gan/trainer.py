@@ -88,9 +88,27 @@ class TrainStep(object):
         self.gan, self.optD, self.optG, self.losses, self.params = gan, optD, optG, losses, params
         self.device, self.end2end, self.grad_sync = device, end2end, grad_sync
         self.lD = self.lG = self.fake = self.xs = self.conds = None
+        # weight / bias gradients land directly in flat per-model arenas (the ones the data-parallel exchange
+        # all-reduces, when there is one): no per-parameter sums, no gather copies
+        self.grad_sink = None
+        if not end2end and torch.device(device).type == 'cuda':
+            cached = gan.__dict__.get('_t2v_grad_sink')
+            if cached is None or cached[0] is not grad_sync:
+                from ..dist import GradArena
+                arenas = list(grad_sync.arenas.values()) if grad_sync is not None else [
+                    GradArena([q for d in gan.discrims for q in d.parameters()], TF.copy_into),
+                    GradArena(gan.gen.parameters(), TF.copy_into)]
+                cached = (grad_sync, TF.GradSink(arenas))
+                gan.__dict__['_t2v_grad_sink'] = cached          # one pair of arenas per model, reused by every step
+            self.grad_sink = cached[1]
+
+    def _arm_sink(self):
+        TF.set_grad_sink(self.grad_sink)
+        TF.grad_sink_reset()              # the step about to run clears this model's gradients first
 
     def part_d(self, x, cond):
         p = self.params
+        self._arm_sink()
         self.xs, self.conds = multiscale_data(x, cond, p.frame_sizes, p.subsample_input)
         z = TF.draws.z(x.size(0), self.gan.gen.latent_size, self.device)       # CPU generator, then copy (parity)
         self.fake = self.gan(z, cond=self.conds[0] if self.conds is not None else None)
@@ -101,6 +119,7 @@ class TrainStep(object):
 
     def part_g(self):
         self.optD.step()
+        self._arm_sink()
         # D after its update, on the real batch (trainer.py:247). Its graph is only needed when the text
         # encoder trains end-to-end; otherwise nothing upstream of these predictions receives a gradient
         # that is ever used, so none is recorded (identical results, SURVEY §7 "wasted work").
