@@ -133,6 +133,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_roofline', action='store_true')
+    ap.add_argument('--no_d_roofline', action='store_true', help='skip the D forward+backward roofline pass')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay (eager launches)')
     args = ap.parse_args()
 
@@ -260,7 +261,7 @@ def main():
     }
     if roof is not None:
         res['roofline'] = roof
-    if rank == 0 and world == 1 and prof:
+    if rank == 0 and world == 1 and prof and not args.no_d_roofline:
         # the north-star's own target line: D forward+backward on un-subsampled 16x64x64 clips
         from txt2vid_amd.util.roofline import d_fwdbwd_roofline
         log('D forward+backward roofline pass')

@@ -37,6 +37,8 @@ CONV_CASES = [
     # (x shape, Cout, kernel)
     ((2, 16, 4, 6, 6), 32, (3, 3, 3)),
     ((3, 1, 4, 8, 8), 64, (3, 3, 3)),        # Cin=1: generic-K path
+    ((2, 1, 9, 32, 32), 64, (3, 3, 3)),      # Cin=1, M=18432: its data gradient takes the two-pass thin path
+    ((5, 1, 1, 64, 64), 32, (3, 3, 3)),      # same with D=1 (9 live taps)
     ((2, 3, 2, 5, 7), 8, (3, 3, 3)),         # Cin=3, odd sizes
     ((2, 32, 1, 8, 8), 16, (3, 3, 3)),       # D=1: centre plane of taps only
     ((5, 64, 1, 1, 1), 48, (3, 3, 3)),       # 1x1x1 map: centre tap only

@@ -886,6 +886,98 @@ __global__ __launch_bounds__(256) void linear_thin_kernel(const GroupTable tab, 
     }
 }
 
+// Thin convolution with ONE output channel and many taps (the data gradient of the 1 -> 64 stem convolution,
+// 64 channels x 27 taps -> 1), in two passes that read the input once instead of 27 times:
+//   taps pass:   P[slot][m] = sum_ci x[m][ci] * w[slot][ci]      for every voxel m and packed tap slot
+//   shift pass:  y[m]       = sum_taps valid(m, tap) * P[slot(tap)][m + offset(tap)]
+// P (nslots x M floats per member, members back to back) lives in the caller's workspace.
+__global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
+                                                        const int Cin, const int nslots, const int flags) {
+    __shared__ float sw[THIN_MAX_W];                     // w[slot][ci]
+    const int tid = threadIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int DHW = gd.D * gd.H * gd.W, M = gd.N * DHW;
+    for (int i = tid; i < nslots * Cin; i += 256) sw[i] = wp[i];          // Cout == 1: wp[slot][ci][0]
+    __syncthreads();
+    const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + tid;
+    if (m >= M) return;
+    const int n = m / DHW, sp = m - n * DHW;
+    const float* __restrict__ px = gd.x + (size_t)n * Cin * DHW + sp;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    float acc[T2V_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) acc[t] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += 16) {               // 16 channel loads in flight per lane (latency, not bytes, bounds this)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int ci = c0 + u < Cin ? c0 + u : Cin - 1;
+            v[u] = px[(size_t)ci * DHW];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (relu_in) v[u] = fmaxf(v[u], 0.f);
+            if (c0 + u >= Cin) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < T2V_MAX_TAPS; ++t) {
+            if (t < nslots) {
+                const float* wt = sw + t * Cin + c0;     // rows past Cin multiply zeros; THIN_MAX_W leaves the slack
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[t] += v[u] * wt[c0 + u < Cin ? u : 0];
+            }
+        }
+    }
+    // P of this member starts at nslots * (voxels of the members before it) = nslots * out_start (Cout == 1)
+    float* pp = P + (size_t)nslots * (size_t)tab.out_start[gi] + m;
+#pragma unroll
+    for (int t = 0; t < T2V_MAX_TAPS; ++t)
+        if (t < nslots) pp[(size_t)t * M] = acc[t];
+}
+__global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable tab, const float* __restrict__ P,
+                                                             const float* __restrict__ bias, const int nslots, const int flags) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+    const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + (int)threadIdx.x;
+    if (m >= M) return;
+    const int n = m / DHW, sp = m - n * DHW;
+    const int d = sp / HW, r = sp - d * HW;
+    const int h = r / W, w_ = r - h * W;
+    const float* __restrict__ pp = P + (size_t)nslots * (size_t)tab.out_start[gi] + m;
+    float acc = 0.f;
+    const int ntaps = gd.ntaps;
+    float pv[T2V_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) {             // all (unconditional, clamped) loads first ...
+        const int tt = t < ntaps ? t : 0;
+        const int dd = d + gd.dz[tt], hh = h + gd.dy[tt], ww = w_ + gd.dx[tt];
+        const bool ok = t < ntaps && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int off = ok ? gd.dz[tt] * HW + gd.dy[tt] * W + gd.dx[tt] : 0;
+        const float v = pp[(size_t)gd.widx[tt] * M + off];
+        pv[t] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) acc += pv[t];   // ... then the sum in tap order
+    float v = acc + (((flags & T2V_CONV_BIAS) && bias) ? bias[0] : 0.f);
+    if ((flags & T2V_CONV_MASK_OUT) && gd.mask) v = gd.mask[m] > 0.f ? v : 0.f;
+    gd.y[m] = (flags & T2V_CONV_ACCUM) ? gd.y[m] + v : v;
+}
+// worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
+static bool thin_two_pass(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int nslots) {
+    if (Cout != 1 || nslots < 9 || Cin < 16 || nslots * Cin > THIN_MAX_W) return false;
+    long M = 0;
+    for (int i = 0; i < ngroups; ++i) M += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+    return M >= 16384;
+}
+
 static bool thin_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int& nslots) {
     if (Cout > 4) return false;
     nslots = 0;
@@ -1003,7 +1095,8 @@ extern "C" int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, 
     ConvPlan p;
     if (!build_table(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
     int nslots;
-    if (thin_ok(groups, ngroups, Cin, Cout, nslots)) return 0;
+    if (thin_ok(groups, ngroups, Cin, Cout, nslots))
+        return thin_two_pass(groups, ngroups, Cin, Cout, nslots) ? (int64_t)nslots * tab.out_start[ngroups] : 0;
     if (Cout <= 4) {
         bool pl = true;
         for (int i = 0; i < ngroups; ++i) pl = pl && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1 && groups[i].ntaps == 1;
@@ -1058,6 +1151,15 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
             mt += ((long)groups[i].N * groups[i].D * groups[i].H * groups[i].W + 255) / 256;
         }
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
+        if (ws && thin_two_pass(groups, ngroups, Cin, Cout, nslots)) {
+            {
+                ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
+                T2V_LAUNCH_PROF(thin_taps_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, Cin, nslots, flags);
+            }
+            ProfScope prof2(3, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, 2);
+            T2V_LAUNCH_PROF(thin_shift_sum_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, ws, bias, nslots, flags);
+            return launch_status();
+        }
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
         if (Cout == 1) T2V_LAUNCH_PROF(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
         else T2V_LAUNCH_PROF(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);

@@ -709,7 +709,8 @@ __global__ void lstm_gates_slab_k(const float* slab, int S, const float* bias, c
         for (int g = 0; g < 4; ++g) {
             const float* ps = slab + b * 4 * Cc + (long)g * Cc + r;
             float v = 0.f;
-            for (int s = 0; s < S; ++s) v += ps[(long)s * stride];
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) v += ps[(long)s * stride];      // unrolled: 8 loads in flight, summed in order
             p[g] = v + (bias ? bias[g * Cc + r] : 0.f);
         }
         const float gi = sigm(p[0]), gf = sigm(p[1]), gg = tanhf(p[2]), go = sigm(p[3]);
@@ -729,6 +730,7 @@ __global__ void lstm_gates_bwd_slab_k(const float* gh, const float* slab, int S,
         const float gi = pa[0], gf = pa[Cc], gg = pa[2 * Cc], go = pa[3 * Cc];
         const float tc = tanhf(c_new[i]);
         float back = 0.f;                                  // dL/dh_t arriving from step t+1 = sum of the slab's slices
+#pragma unroll 8
         for (int s = 0; s < S; ++s) back += slab[(long)s * n + i];
         const float dh = S > 0 ? gh[i] + back : gh[i];
         const float dc = dh * go * (1.f - tc * tc) + (gc_in ? gc_in[i] : 0.f);
@@ -743,13 +745,13 @@ __global__ void lstm_gates_bwd_slab_k(const float* gh, const float* slab, int S,
 extern "C" int t2v_lstm_gates_slab(const float* slab, int S, const float* bias, const float* c_prev, float* h, float* c_new,
                                    float* act, int B, int C, void* st) {
     if (!slab || S < 1 || !c_prev || !h || !c_new || !act || B < 1 || C < 1) return T2V_EINVAL;
-    T2V_LAUNCH(lstm_gates_slab_k, dim3(nblocks((long)B * C)), dim3(256), 0, S_(st), slab, S, bias, c_prev, h, c_new, act, B, C);
+    T2V_LAUNCH(lstm_gates_slab_k, dim3((unsigned)(((long)B * C + 63) / 64)), dim3(64), 0, S_(st), slab, S, bias, c_prev, h, c_new, act, B, C);
     return launch_status();
 }
 extern "C" int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S, const float* gc_in, const float* act,
                                        const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* st) {
     if (!gh || S < 0 || (S > 0 && !slab) || !act || !c_prev || !c_new || !gpre || !gc_prev || B < 1 || C < 1) return T2V_EINVAL;
-    T2V_LAUNCH(lstm_gates_bwd_slab_k, dim3(nblocks((long)B * C)), dim3(256), 0, S_(st), gh, slab, S, gc_in, act, c_prev, c_new,
+    T2V_LAUNCH(lstm_gates_bwd_slab_k, dim3((unsigned)(((long)B * C + 63) / 64)), dim3(64), 0, S_(st), gh, slab, S, gc_in, act, c_prev, c_new,
                gpre, gc_prev, B, C);
     return launch_status();
 }
