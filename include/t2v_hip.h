@@ -55,6 +55,7 @@ typedef struct {
 #define T2V_CONV_BIAS 1      /* add bias[Cout] in the epilogue                                   */
 #define T2V_CONV_RELU_IN 2   /* apply max(.,0) to the input while gathering (ReLU->conv fusion)  */
 #define T2V_CONV_ACCUM 4     /* y += result instead of y = result                                */
+#define T2V_CONV_ACCUM_BIAS 16 /* t2v_conv_wgrad_grouped_bias: dbias += result (T2V_CONV_ACCUM covers dw only)      */
 #define T2V_CONV_MASK_OUT 8  /* zero the result where groups[i].mask <= 0: the ReLU adjoint fused into the data
                                 gradient of a ReLU->conv pair (layers.py:230-233). Not combined with ACCUM. */
 
@@ -115,6 +116,14 @@ int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* groups, int ngr
                                            int kH, int kW);
 int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                            float* dw, float* slab, int flags, void* stream);
+/* Same, plus the bias gradient dbias[Cout] = sum over all members and voxels of dL/dy (what t2v_channel_sum_grouped
+ * computes, layers.py / resnet3d.py conv biases): on the 3-tap-row path the weight-gradient kernel adds up the dL/dy
+ * tiles it stages anyway, elsewhere the stand-alone channel sum runs. The slab must hold
+ * t2v_conv_wgrad_grouped_bias_slab_floats() floats. */
+int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
+                                                int kH, int kW);
+int t2v_conv_wgrad_grouped_bias(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                                float* dw, float* dbias, float* slab, int flags, void* stream);
 
 /* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
 int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S);   /* floats of `ws` needed (0: none) */

@@ -125,6 +125,32 @@ def test_relu_conv_grouped_first_and_second_order(shapes):
         close(a, r.float(), rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize('cin,cout,k,shapes', [
+    (64, 96, (3, 3, 3), [(2, 64, 4, 8, 8), (1, 64, 2, 16, 16), (3, 64, 1, 4, 4)]),     # 3-tap-row kernel: bias summed on the side
+    (64, 64, (1, 3, 3), [(4, 64, 1, 16, 16)]),                                          # 2-D, one member
+    (32, 48, (3, 3, 3), [(2, 32, 4, 8, 8), (2, 32, 2, 4, 4)]),                          # Cin < 64: stand-alone channel sum
+    (128, 40, (1, 1, 1), [(2, 128, 4, 8, 8), (5, 128, 1, 1, 1)]),                       # 1x1x1 kernel
+])
+def test_wgrad_with_bias_gradient(cin, cout, k, shapes):
+    """`t2v_conv_wgrad_grouped_bias`: dW and db of a grouped convolution in one call, stored or accumulated."""
+    from txt2vid_amd import functional as TF
+    xs = [rnd(60 + i, *s) for i, s in enumerate(shapes)]
+    gys = [rnd(70 + i, s[0], cout, *s[2:]) for i, s in enumerate(shapes)]
+    w = torch.zeros(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    pad = tuple(kk // 2 for kk in k)
+    sum((F.conv3d(x.double(), w, b, padding=pad) * g.double()).sum() for x, g in zip(xs, gys)).backward()
+    xd, gd = [x.to(dev()) for x in xs], [g.to(dev()) for g in gys]
+    dw = torch.full((cout, cin) + k, 7.0, device=dev())
+    db = torch.full((cout,), -3.0, device=dev())
+    TF.conv_group_wgrad_raw(xd, gd, (cout, cin) + k, False, out=dw, accum=False, dbias=db, accum_bias=False)
+    close(dw, w.grad.float(), rtol=2e-4, atol=2e-4)
+    close(db, b.grad.float(), rtol=2e-4, atol=2e-4)
+    TF.conv_group_wgrad_raw(xd, gd, (cout, cin) + k, False, out=dw, accum=True, dbias=db, accum_bias=True)
+    close(dw, 2 * w.grad.float(), rtol=2e-4, atol=2e-4)
+    close(db, 2 * b.grad.float(), rtol=2e-4, atol=2e-4)
+
+
 def test_avgpool():
     from txt2vid_amd import functional as TF
     for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),

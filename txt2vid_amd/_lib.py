@@ -69,6 +69,8 @@ SIGNATURES = {
     't2v_conv_fwd_grouped': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_conv_wgrad_grouped_slab_floats': [_P, _I, _I, _I, _I, _I, _I],
     't2v_conv_wgrad_grouped': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    't2v_conv_wgrad_grouped_bias_slab_floats': [_P, _I, _I, _I, _I, _I, _I],
+    't2v_conv_wgrad_grouped_bias': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_conv_wgrad': [_P, _P, _P, _P, _G, _I3, _I, _I, _P],
     't2v_channel_sum_ws_floats': [_I, _I, _L],
     't2v_channel_sum': [_P, _P, _P, _I, _I, _L, _I, _P],
@@ -131,7 +133,7 @@ SIGNATURES = {
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
-_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
+_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_grouped_bias_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
             't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_channel_sum_grouped_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None

@@ -1465,7 +1465,8 @@ struct LiveRows { int8_t r[9]; int32_t n; };    // slab row slot -> original ker
 
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                           const int Cout, const int kD, const int kH, const int flags,
-                                                          const int chunks_per_split, const LiveRows live) {
+                                                          const int chunks_per_split, const LiveRows live,
+                                                          float* __restrict__ bias_slab) {
     __shared__ float As[64 * W3_AP];   // gy^T tile [co][m]
     __shared__ float Bs[3 * 64 * W3_AP];   // three shifted + masked copies of the x tile: [dx][ci][m]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1493,6 +1494,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
     float ra[8], rb[8], rh = 0.f;
     uint32_t pm0 = 0, pm1 = 0, pm2 = 0;       // pending chunk: validity of (voxel, dx) as 32-bit masks
     int pend_DHW = 1;
+    // bias gradient on the side: the workgroups of the first channel tile and first kernel row also add up the dL/dy
+    // values they stage anyway (bias_slab[split][co], summed over the splits by bias_slab_reduce_kernel)
+    const bool do_bias = bias_slab != nullptr && ci0 == 0 && rslot == 0;
+    bool pend_mv = false;
+    float bsum[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
 #ifdef T2V_ABLATION
     const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
 #endif
@@ -1529,6 +1537,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
         pm1 = (uint32_t)__ballot(vc);
         pm2 = (uint32_t)__ballot(vc && w_ + 1 < W);
         pend_DHW = DHW;
+        pend_mv = mv;
         const float* __restrict__ gy = gd.y;
         const float* __restrict__ x = gd.x;
 #pragma unroll
@@ -1561,6 +1570,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
             const bool v0 = ml + 1 < WG_BK && ((pm0 >> (ml + 1)) & 1u);   // my voxel is the LEFT neighbour of voxel ml+1
             const bool v1 = (pm1 >> ml) & 1u;
             const bool v2 = ml >= 1 && ((pm2 >> (ml - 1)) & 1u);          // ... the RIGHT neighbour of voxel ml-1
+            if (do_bias) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
+            }
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int row = rl + p * 8;
@@ -1595,6 +1608,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
         }
         __syncthreads();
     }
+    if (do_bias) {                            // lanes ml = 0..31 of a half-wave hold the same 8 output channels
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = bsum[p];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int co = co0 + rl + p * 8;
+            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
+        }
+    }
     // slab[((split*nslots + rslot*3 + dx+1)*Cout + co)*Cin + ci]
     const int ci = ci0 + wci * 32 + l31;
     if (ci < Cin) {
@@ -1610,6 +1633,22 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
             }
         }
     }
+}
+
+// dbias[co] = (accum ? dbias[co] : 0) + sum_s bias_slab[s][co]   (fixed order)
+__global__ __launch_bounds__(256) void bias_slab_reduce_kernel(const float* __restrict__ bias_slab, float* __restrict__ dbias,
+                                                               int S, int Cout, int accum) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Cout) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        v0 += bias_slab[(size_t)s * Cout + co]; v1 += bias_slab[(size_t)(s + 1) * Cout + co];
+        v2 += bias_slab[(size_t)(s + 2) * Cout + co]; v3 += bias_slab[(size_t)(s + 3) * Cout + co];
+    }
+    for (; s < S; ++s) v0 += bias_slab[(size_t)s * Cout + co];
+    const float v = (v0 + v1) + (v2 + v3);
+    dbias[co] = accum ? dbias[co] + v : v;
 }
 
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
@@ -1728,12 +1767,52 @@ extern "C" int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* grou
     return (int64_t)p.S * p.nlive * Cout * Cin;
 }
 
+extern "C" int64_t t2v_channel_sum_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int C);
+extern "C" int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups, int C, float* out, float* ws, int accum, void* stream);
+
+// floats the bias part needs behind the weight-gradient slab: S x Cout partial sums when the 3-tap kernel produces them
+// on the side, else the workspace of the stand-alone channel sum
+static int64_t wgrad_bias_extra(const t2v_conv_group* groups, int ngroups, int Cout, const WgradPlan& p) {
+    if (p.rows3) return (int64_t)p.S * Cout;
+    t2v_conv_group tmp[T2V_MAX_GROUPS];
+    for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
+    const int64_t n = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
+    return n < 0 ? 0 : n;
+}
+extern "C" int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
+                                                           int kH, int kW) {
+    WGroupTable tab;
+    WgradPlan p;
+    if (!build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
+    return (int64_t)p.S * p.nlive * Cout * Cin + wgrad_bias_extra(groups, ngroups, Cout, p);
+}
+
+static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, float* dw,
+                      float* dbias, float* slab, int flags, void* stream);
 extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                                       float* dw, float* slab, int flags, void* stream) {
+    return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, dw, nullptr, slab, flags, stream);
+}
+extern "C" int t2v_conv_wgrad_grouped_bias(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                                           float* dw, float* dbias, float* slab, int flags, void* stream) {
+    if (!dbias) return T2V_EINVAL;
+    return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, dw, dbias, slab, flags, stream);
+}
+static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, float* dw,
+                      float* dbias, float* slab, int flags, void* stream) {
     WGroupTable tab;
     WgradPlan p;
     if (!dw || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;         // behind the weight-gradient slab
+    if (dbias && !p.rows3) {                                              // no fused path: the stand-alone channel sum
+        t2v_conv_group tmp[T2V_MAX_GROUPS];
+        for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
+        const int64_t nws = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
+        const int rc = t2v_channel_sum_grouped(tmp, ngroups, Cout, dbias, nws > 0 ? bias_part : nullptr,
+                                               (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0, stream);
+        if (rc) return rc;
+    }
 #ifdef T2V_ABLATION
     if (const char* e = getenv("T2V_DEBUG_FLAGS")) flags |= atoi(e);     // developer ablations (wrong results)
 #endif
@@ -1773,7 +1852,8 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
         if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
-            T2V_LAUNCH_PROF(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows);
+            T2V_LAUNCH_PROF(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
+                            dbias ? bias_part : (float*)nullptr);
         } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
             T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
@@ -1784,6 +1864,9 @@ extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups,
     }
     int st = launch_status();
     if (st) return st;
+    if (dbias && p.rows3)
+        T2V_LAUNCH(bias_slab_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, bias_part, dbias, p.S, Cout,
+                   (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0);
     const long CoCi = (long)Cout * Cin;
     ProfScope prof2(2, 0.0, s, CoCi, Cin, Cout, T, live.n, p.S);
     if (CoCi <= 16384 && p.S >= 16)

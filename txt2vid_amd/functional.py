@@ -19,7 +19,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, MAX_TAPS, MAX_GROUPS
 
-FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT = 1, 2, 4, 8
+FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT, FLAG_ACCUM_BIAS = 1, 2, 4, 8, 16
 
 # ------------------------------------------------------------------------------------------------
 # small helpers
@@ -99,6 +99,21 @@ def set_grad_sink(sink):
 def grad_sink_reset():
     if _grad_sink is not None:
         _grad_sink.reset()
+
+
+def _to_sink_wb(w, b, xs, gys, relu_in):
+    """Weight AND bias gradient of one (grouped) convolution into their sink slots with ONE weight-gradient launch
+    (`t2v_conv_wgrad_grouped_bias`: the 3-tap-row kernel sums the dL/dy tiles it stages anyway). Returns
+    (handled, gw, gb) like `_to_sink`."""
+    if _grad_sink is None or w is None or b is None or torch.is_grad_enabled():
+        return False, None, None
+    wbase = w._base if w._base is not None else w
+    if id(wbase) not in _grad_sink.slots or id(b) not in _grad_sink.slots:
+        return False, None, None
+    wflat, wacc = _grad_sink.take(wbase)
+    bflat, bacc = _grad_sink.take(b)
+    conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
+    return True, (None if wacc else wflat.view(w.shape)), (None if bacc else bflat.view(b.shape))
 
 
 def _to_sink(param_like, compute):
@@ -409,14 +424,18 @@ class Conv(Function):
         if ctx.needs_input_grad[0]:
             gx = ConvDgrad.apply(gy, w)
         if _param_grads_enabled:
-            if ctx.needs_input_grad[1]:
-                done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), out=out, accum=acc))
-                if not done:
-                    gw = ConvWgrad.apply(x, gy, tuple(w.shape))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
-                if not done:
-                    gb = ChannelSum.apply(gy)
+            both = False
+            if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+                both, gw, gb = _to_sink_wb(w, ctx.bias, [x], [gy], False)
+            if not both:
+                if ctx.needs_input_grad[1]:
+                    done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), out=out, accum=acc))
+                    if not done:
+                        gw = ConvWgrad.apply(x, gy, tuple(w.shape))
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
+                    if not done:
+                        gb = ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -479,14 +498,18 @@ class ReluConv(Function):
         if ctx.needs_input_grad[0]:
             gx = ConvDgradMaskG.apply(w, 1, gy, x)[0]          # dgrad(gy, w) * [x > 0] in one launch
         if _param_grads_enabled:
-            if ctx.needs_input_grad[1]:
-                done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), relu_in=True, out=out, accum=acc))
-                if not done:
-                    gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
-                if not done:
-                    gb = ChannelSum.apply(gy)
+            both = False
+            if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+                both, gw, gb = _to_sink_wb(w, ctx.bias, [x], [gy], True)
+            if not both:
+                if ctx.needs_input_grad[1]:
+                    done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), relu_in=True, out=out, accum=acc))
+                    if not done:
+                        gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_raw(gy, out=out, accum=acc))
+                    if not done:
+                        gb = ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -1880,20 +1903,26 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
     return ys
 
 
-def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False):
+def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False, dbias=None, accum_bias=False):
     xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
     Cout, Cin = wshape[0], wshape[1]
     k = tuple(wshape[2:])
     geoms = [conv_geom(t.shape[0], Cin, t.shape[2], t.shape[3], t.shape[4], Cout, k[0], k[1], k[2]) for t in xs5]
     arr = _group_table(xs5, gys5, geoms, None)
-    n = int(lib().t2v_conv_wgrad_grouped_slab_floats(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
+    query = lib().t2v_conv_wgrad_grouped_bias_slab_floats if dbias is not None else lib().t2v_conv_wgrad_grouped_slab_floats
+    n = int(query(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
     if n <= 0:
         raise RuntimeError('bad grouped wgrad geometry')
     slab = torch.empty((n,), device=xs5[0].device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(tuple(wshape), device=xs5[0].device, dtype=torch.float32)
-    check(lib().t2v_conv_wgrad_grouped(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(slab),
-                                       (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0), _stream()),
-          't2v_conv_wgrad_grouped')
+    flags = (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0)
+    if dbias is not None:
+        check(lib().t2v_conv_wgrad_grouped_bias(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(dbias), _p(slab),
+                                                flags | (FLAG_ACCUM_BIAS if accum_bias else 0), _stream()),
+              't2v_conv_wgrad_grouped_bias')
+    else:
+        check(lib().t2v_conv_wgrad_grouped(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(slab), flags, _stream()),
+              't2v_conv_wgrad_grouped')
     return dw
 
 
@@ -1934,14 +1963,18 @@ class ConvG(Function):
                 gxs[i] = r
         if _param_grads_enabled:
             lx, lg = [xs[i] for i in live], [gys[i] for i in live]
-            if ctx.needs_input_grad[0]:
-                done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), ctx.relu_in, out=out, accum=acc))
-                if not done:
-                    gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *(lx + lg))
-            if ctx.has_bias and ctx.needs_input_grad[1]:
-                done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_group_raw(lg, out=out, accum=acc))
-                if not done:
-                    gb = ChannelSumG.apply(*lg)
+            both = False
+            if ctx.needs_input_grad[0] and ctx.has_bias and ctx.needs_input_grad[1]:
+                both, gw, gb = _to_sink_wb(w, ctx.bias, lx, lg, ctx.relu_in)
+            if not both:
+                if ctx.needs_input_grad[0]:
+                    done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), ctx.relu_in, out=out, accum=acc))
+                    if not done:
+                        gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *(lx + lg))
+                if ctx.has_bias and ctx.needs_input_grad[1]:
+                    done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_group_raw(lg, out=out, accum=acc))
+                    if not done:
+                        gb = ChannelSumG.apply(*lg)
         return (gw, gb, None) + tuple(gxs)
 
 
