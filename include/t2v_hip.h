@@ -221,6 +221,26 @@ int t2v_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, in
 /* adjoint of softmax_bwd w.r.t. y: gyv = gg*(gy - s) - gy*sum(gg*y), s = sum(gy*y) */
 int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, float* out, int64_t rows, int n, void* stream);
 
+/* ---- multi-job launches: the non-local block's small ops over all pyramid levels at once -------------------------
+ * Up to 8 differently shaped jobs per call (HOST array; the descriptors travel in the kernel arguments). Field roles:
+ *   T2V_MJ_SCALE            out = scalar[0] * a                         n = elements
+ *   T2V_MJ_SCALE_ADD        out = scalar[0] * a + b                     (layers.py:36,68: gamma * o + x)
+ *   T2V_MJ_DOT              jobs[0].out[0] (+= if jobs[0].f0) sum over ALL jobs of <a, b>; ws: t2v_multi_ws_floats floats
+ *   T2V_MJ_MAXPOOL          out = maxpool2x2(a), out2 = int32 argmax    n = planes, d0 = H, d1 = W  (layers.py:26-27,57-58)
+ *   T2V_MJ_MAXSCATTER       out[planes,H,W] = scatter(a = g, b = idx)   T2V_MJ_MAXGATHER: out = a[b = idx]
+ *   T2V_MJ_SOFTMAX          out = softmax over rows of a                n = rows, d0 = row length
+ *   T2V_MJ_SOFTMAX_BWD      out = a*(b - sum(a*b))  (a = y, b = gy);  _BWD_BWD_Y: a = y, b = gy, c = gg (see t2v_softmax_bwd_bwd_y)
+ *   T2V_MJ_BMM              out[b] = op(a[b]) @ op(b[b])                n = batch, d0 = M, d1 = N, d2 = K, f0 = ta, f1 = tb */
+enum { T2V_MJ_SCALE = 1, T2V_MJ_SCALE_ADD, T2V_MJ_DOT, T2V_MJ_MAXPOOL, T2V_MJ_MAXSCATTER, T2V_MJ_MAXGATHER, T2V_MJ_SOFTMAX,
+       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM };
+typedef struct t2v_multi_job {
+    const void* a; const void* b; const void* c; void* out; void* out2;
+    int64_t n;
+    int32_t d0, d1, d2, f0, f1, reserved;
+} t2v_multi_job;
+int64_t t2v_multi_ws_floats(int op, const t2v_multi_job* jobs, int njobs);
+int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const float* scalar_dev, float* ws, void* stream);
+
 /* ---- losses (txt2vid/gan/losses.py) ------------------------------------------------------------ */
 /* RSGAN (losses.py:79-85): loss = mean softplus(-(a-b)) ; ga = -sigmoid(-(a-b))/n * gscale, gb = -ga. */
 int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* stream);

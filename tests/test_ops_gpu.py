@@ -226,6 +226,38 @@ def test_maxpool_softmax_bmm_double_backward():
         close(td.grad, tr.grad, rtol=1e-3, atol=1e-3)
 
 
+def test_nonlocal_block_grouped_matches_per_level_first_and_second_order():
+    """`layers.nonlocal_levels` (every op one multi-job launch over the levels, `t2v_multi`) against the per-tensor
+    non-local block on three differently shaped members, one of which takes no part in the backward; gradients of a
+    gradient-penalty-shaped loss (double backward through max-pool, both batched GEMMs, softmax and gamma*o + x)."""
+    from txt2vid_amd.models.layers import Attention3d, nonlocal_levels
+    torch.manual_seed(3)
+    att = Attention3d(32).to(dev())
+    with torch.no_grad():
+        att.gamma.fill_(0.7)
+        for p_ in att.parameters():
+            if p_.dim() > 1:
+                p_.mul_(3.0)
+    shapes = [(2, 32, 4, 4, 4), (1, 32, 2, 8, 8), (3, 32, 1, 2, 2)]
+    xs0 = [rnd(80 + i, *sh) for i, sh in enumerate(shapes)]
+
+    def run(fwd):
+        for p_ in att.parameters():
+            p_.grad = None
+        xs = [x.to(dev()).requires_grad_(i != 2) for i, x in enumerate(xs0)]
+        ys = fwd(xs)
+        out = sum((y ** 2).sum() for y in ys[:2]) + ys[2].sum() * 0.0
+        g1 = torch.autograd.grad(out, xs[:2], create_graph=True)
+        loss = out * 0.1 + sum((g * g).sum() for g in g1)
+        loss.backward()
+        return [y.detach() for y in ys] + [g.detach() for g in g1] + [xs[0].grad, xs[1].grad] + [p_.grad.clone() for p_ in att.parameters()]
+
+    ref = run(lambda xs: [att(x) for x in xs])
+    got = run(lambda xs: nonlocal_levels(att, xs))
+    for a, r in zip(got, ref):
+        close(a, r, rtol=2e-4, atol=2e-5)
+
+
 def test_scale_add_rowsum_double_backward():
     from txt2vid_amd import functional as TF
     gam, o, x = torch.tensor(0.7), rnd(1, 2, 3, 2, 2, 2), rnd(2, 2, 3, 2, 2, 2)

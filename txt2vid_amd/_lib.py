@@ -40,6 +40,12 @@ class PoolJob(C.Structure):
                 ('p', C.c_int32 * 3)]
 
 
+class MultiJob(C.Structure):
+    """t2v_multi_job (include/t2v_hip.h)."""
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('out', C.c_void_p), ('out2', C.c_void_p), ('n', C.c_int64),
+                ('d0', C.c_int32), ('d1', C.c_int32), ('d2', C.c_int32), ('f0', C.c_int32), ('f1', C.c_int32), ('reserved', C.c_int32)]
+
+
 class PackJob(C.Structure):
     """Mirror of `t2v_pack_job` (include/t2v_hip.h)."""
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('Cout', C.c_int32), ('Cin', C.c_int32), ('T', C.c_int32),
@@ -111,6 +117,8 @@ SIGNATURES = {
     't2v_softmax': [_P, _P, _L, _I, _P],
     't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],
     't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
+    't2v_multi_ws_floats': [_I, _P, _I],
+    't2v_multi': [_I, _P, _I, _P, _P, _P],
     't2v_rsgan': [_P, _P, _P, _I, _P],
     't2v_rsgan_bwd': [_P, _P, _P, _P, _P, _I, _P],
     't2v_gan_loss': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -133,7 +141,7 @@ SIGNATURES = {
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
-_RESTYPE = {'t2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_grouped_bias_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
+_RESTYPE = {'t2v_multi_ws_floats': C.c_int64, 't2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_grouped_bias_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
             't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_channel_sum_grouped_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None

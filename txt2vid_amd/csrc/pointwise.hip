@@ -844,6 +844,240 @@ extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const floa
     return launch_status();
 }
 
+// ---------------------------------------------------------------- multi-job launches (non-local block over pyramid levels)
+// The non-local block runs the same tiny op on every pyramid level (and on the real||fake and x-hat members of a level):
+// up to 8 differently shaped jobs share ONE launch; the job descriptors travel in the kernel arguments and a workgroup
+// finds its job in a prefix table of per-job workgroup counts.
+#define MJ_MAX 8
+struct MultiBatch { t2v_multi_job j[MJ_MAX]; int begin[MJ_MAX + 1]; int n; };
+__device__ __forceinline__ int mj_find(const MultiBatch& tb) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < MJ_MAX; ++k)
+        if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
+    return ji;
+}
+#define MJ_CHUNK 1024      // elements per workgroup of the element-wise ops
+
+// out = s * a (+ b)          a, b, out: n floats; s = scalar[0]
+__global__ __launch_bounds__(256) void mj_scale_k(const MultiBatch tb, const float* __restrict__ scalar) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float f = scalar[0];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b; float* o = (float*)q.out;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) o[i] = b ? f * a[i] + b[i] : f * a[i];
+}
+// partial[block] = sum over this workgroup's elements of a*b; mj_dot_final sums the partials in block order
+__global__ __launch_bounds__(256) void mj_dot_partial_k(const MultiBatch tb, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * (MJ_CHUNK * 4);
+    float acc = 0.f;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK * 4 && i < q.n; i += 256) acc += a[i] * b[i];
+    const float v = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void mj_dot_final_k(const float* __restrict__ partial, float* __restrict__ out, int nb, int accum) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+    const float v = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = accum ? out[0] + v : v;
+}
+// 2x2 max-pool over the trailing (d0 = H, d1 = W) plane: a = x, out = y, out2 = idx (int32); n = planes
+__global__ __launch_bounds__(256) void mj_maxpool_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const int H = q.d0, W = q.d1, Ho = H / 2, Wo = W / 2;
+    const long n = q.n * Ho * Wo;
+    const float* x = (const float*)q.a; float* y = (float*)q.out; int32_t* idx = (int32_t*)q.out2;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < n; i += 256) {
+        int wo = i % Wo; long r = i / Wo;
+        int ho = r % Ho; long pl = r / Ho;
+        const float* px = x + pl * (long)H * W;
+        int best = (2 * ho) * W + 2 * wo;
+        float bv = px[best];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                int id = (2 * ho + a) * W + 2 * wo + b;
+                float v = px[id];
+                if (v > bv || (v != v && bv == bv)) { bv = v; best = id; }
+            }
+        y[i] = bv;
+        idx[i] = best;
+    }
+}
+// scatter: a = g [planes,Ho,Wo], b = idx, out = gx [planes,H,W]
+__global__ __launch_bounds__(256) void mj_maxscatter_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const int H = q.d0, W = q.d1, Ho = H / 2, Wo = W / 2;
+    const long n = q.n * H * W;
+    const float* g = (const float*)q.a; const int32_t* idx = (const int32_t*)q.b; float* gx = (float*)q.out;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < n; i += 256) {
+        int w = i % W; long r = i / W;
+        int h = r % H; long pl = r / H;
+        int ho = h >> 1, wo = w >> 1;
+        float v = 0.f;
+        if (ho < Ho && wo < Wo) {
+            long o = (pl * Ho + ho) * Wo + wo;
+            if (idx[o] == h * W + w) v = g[o];
+        }
+        gx[i] = v;
+    }
+}
+// gather: a = x [planes,H,W], b = idx, out = y [planes,Ho,Wo]
+__global__ __launch_bounds__(256) void mj_maxgather_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const int H = q.d0, W = q.d1, Ho = H / 2, Wo = W / 2;
+    const long n = q.n * Ho * Wo;
+    const float* x = (const float*)q.a; const int32_t* idx = (const int32_t*)q.b; float* y = (float*)q.out;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < n; i += 256) {
+        long pl = i / ((long)Ho * Wo);
+        y[i] = x[pl * (long)H * W + idx[i]];
+    }
+}
+// row softmax family (one wave per row, d0 = row length, n = rows). mode 0: out = softmax(a); 1: out = y*(gy - sum gy*y)
+// with a = y, b = gy; 2: out = gg*(gy - s) - gy*sum(gg*y) with a = y, b = gy, c = gg
+__global__ __launch_bounds__(256) void mj_softmax_k(const MultiBatch tb, const int mode) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const long row = (long)((int)blockIdx.x - tb.begin[ji]) * 4 + (threadIdx.x >> 6);
+    if (row >= q.n) return;
+    const int n = q.d0, lane = threadIdx.x & 63;
+    const float* pa = (const float*)q.a + row * n;
+    float* po = (float*)q.out + row * n;
+    if (mode == 0) {
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += 64) mx = fmaxf(mx, pa[i]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += expf(pa[i] - mx);
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+        for (int i = lane; i < n; i += 64) po[i] = expf(pa[i] - mx) * inv;
+    } else if (mode == 1) {
+        const float* pg = (const float*)q.b + row * n;
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += pg[i] * pa[i];
+        s = wave_sum(s);
+        for (int i = lane; i < n; i += 64) po[i] = pa[i] * (pg[i] - s);
+    } else {
+        const float* pg = (const float*)q.b + row * n;
+        const float* pq = (const float*)q.c + row * n;
+        float s = 0.f, u = 0.f;
+        for (int i = lane; i < n; i += 64) { s += pg[i] * pa[i]; u += pq[i] * pa[i]; }
+        s = wave_sum(s);
+        u = wave_sum(u);
+        for (int i = lane; i < n; i += 64) po[i] = pq[i] * (pg[i] - s) - pg[i] * u;
+    }
+}
+// batched thin GEMM (see bmm_k): n = batch, d0 = M, d1 = N, d2 = K, f0 = ta, f1 = tb; a = A, b = B, out = C
+__global__ __launch_bounds__(256) void mj_bmm_k(const MultiBatch tb) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const int M = q.d0, N = q.d1, K = q.d2, ta = q.f0, tb_ = q.f1;
+    const int tn = (N + 15) / 16, tm = (M + 15) / 16;
+    int lb = (int)blockIdx.x - tb.begin[ji];
+    const int bx = lb % tn; lb /= tn;
+    const int by = lb % tm;
+    const int b = lb / tm;
+    const float* a = (const float*)q.a + (long)b * M * K;
+    const float* bb = (const float*)q.b + (long)b * K * N;
+    float* c = (float*)q.out + (long)b * M * N;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row = by * 16 + ty, col = bx * 16 + tx;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        {
+            int r = by * 16 + ty, k = k0 + tx;
+            As[ty][tx] = (r < M && k < K) ? (ta ? a[(long)k * M + r] : a[(long)r * K + k]) : 0.f;
+            int kk = k0 + ty, cc = bx * 16 + tx;
+            Bs[ty][tx] = (kk < K && cc < N) ? (tb_ ? bb[(long)cc * K + kk] : bb[(long)kk * N + cc]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    if (row < M && col < N) c[(long)row * N + col] = acc;
+}
+extern "C" int64_t t2v_multi_ws_floats(int op, const t2v_multi_job* jobs, int njobs) {
+    if (!jobs || njobs < 1 || njobs > MJ_MAX) return T2V_EINVAL;
+    if (op != T2V_MJ_DOT) return 0;
+    long blocks = 0;
+    for (int i = 0; i < njobs; ++i) blocks += (jobs[i].n + MJ_CHUNK * 4 - 1) / (MJ_CHUNK * 4);
+    return blocks;
+}
+extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const float* scalar, float* ws, void* st) {
+    if (!jobs || njobs < 1 || njobs > MJ_MAX) return T2V_EINVAL;
+    MultiBatch tb;
+    long blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const t2v_multi_job& q = jobs[i];
+        if (q.n < 1 || !q.a) return T2V_EINVAL;
+        long nb = 0;
+        switch (op) {
+            case T2V_MJ_SCALE: case T2V_MJ_SCALE_ADD:
+                if (!q.out || !scalar || (op == T2V_MJ_SCALE_ADD && !q.b)) return T2V_EINVAL;
+                nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_DOT:
+                if (!q.b || !q.out || !ws) return T2V_EINVAL;
+                nb = (q.n + MJ_CHUNK * 4 - 1) / (MJ_CHUNK * 4); break;
+            case T2V_MJ_MAXPOOL:
+                if (!q.out || !q.out2 || q.d0 < 2 || q.d1 < 2) return T2V_EINVAL;
+                nb = (q.n * (q.d0 / 2) * (q.d1 / 2) + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_MAXSCATTER:
+                if (!q.b || !q.out || q.d0 < 2 || q.d1 < 2) return T2V_EINVAL;
+                nb = (q.n * q.d0 * q.d1 + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_MAXGATHER:
+                if (!q.b || !q.out || q.d0 < 2 || q.d1 < 2) return T2V_EINVAL;
+                nb = (q.n * (q.d0 / 2) * (q.d1 / 2) + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_SOFTMAX: case T2V_MJ_SOFTMAX_BWD: case T2V_MJ_SOFTMAX_BWD_BWD_Y:
+                if (!q.out || q.d0 < 1 || (op != T2V_MJ_SOFTMAX && !q.b) || (op == T2V_MJ_SOFTMAX_BWD_BWD_Y && !q.c)) return T2V_EINVAL;
+                nb = (q.n + 3) / 4; break;
+            case T2V_MJ_BMM:
+                if (!q.b || !q.out || q.d0 < 1 || q.d1 < 1 || q.d2 < 1) return T2V_EINVAL;
+                nb = (long)((q.d1 + 15) / 16) * ((q.d0 + 15) / 16) * q.n; break;
+            default: return T2V_EINVAL;
+        }
+        tb.j[i] = q;
+        tb.begin[i] = (int)blocks;
+        blocks += nb;
+        if (blocks > 0x7fffffffL) return T2V_EINVAL;
+    }
+    for (int i = njobs; i <= MJ_MAX; ++i) tb.begin[i] = (int)blocks;
+    for (int i = njobs; i < MJ_MAX; ++i) tb.j[i] = tb.j[0];
+    tb.n = njobs;
+    const dim3 grid((unsigned)blocks), blk(256);
+    switch (op) {
+        case T2V_MJ_SCALE: case T2V_MJ_SCALE_ADD:
+            if (op == T2V_MJ_SCALE) for (int i = 0; i < MJ_MAX; ++i) tb.j[i].b = nullptr;
+            T2V_LAUNCH(mj_scale_k, grid, blk, 0, S_(st), tb, scalar); break;
+        case T2V_MJ_DOT:
+            T2V_LAUNCH(mj_dot_partial_k, grid, blk, 0, S_(st), tb, ws);
+            T2V_LAUNCH(mj_dot_final_k, dim3(1), blk, 0, S_(st), ws, (float*)jobs[0].out, (int)blocks, jobs[0].f0); break;
+        case T2V_MJ_MAXPOOL: T2V_LAUNCH(mj_maxpool_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_MAXSCATTER: T2V_LAUNCH(mj_maxscatter_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_MAXGATHER: T2V_LAUNCH(mj_maxgather_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_SOFTMAX: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 0); break;
+        case T2V_MJ_SOFTMAX_BWD: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 1); break;
+        case T2V_MJ_SOFTMAX_BWD_BWD_Y: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 2); break;
+        case T2V_MJ_BMM: T2V_LAUNCH(mj_bmm_k, grid, blk, 0, S_(st), tb); break;
+    }
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- losses
 __device__ __forceinline__ float softplus(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
 

@@ -108,23 +108,23 @@ def _nonlocal(self, x, pooled_planes):
 
 
 def nonlocal_levels(att, xs):
-    """Attention3d over a list of pyramid levels: the four 1x1x1 convolutions are grouped launches over the
-    levels; the (tiny, per-sample) max-pool / bmm / softmax stay per level."""
+    """Attention3d over a list of pyramid levels: the four 1x1x1 convolutions are grouped launches over the levels, and
+    so is every small op in between (max-pool, the two batched GEMMs, the softmax, gamma * o + x): 9 launches for all
+    levels together (layers.py:52-68)."""
+    if len(xs) > 8:
+        raise ValueError('at most 8 tensors per grouped non-local block')
     thetas = TF.conv_group(xs, att.theta.weight, None)
-    phis = TF.conv_group(xs, att.phi.weight, None)
-    gs = TF.conv_group(xs, att.g.weight, None)
-    os_ = []
-    for x, theta, phi, g in zip(xs, thetas, phis, gs):
-        b = x.size(0)
-        phi = TF.max_pool2x2(phi)
-        g = TF.max_pool2x2(g)
-        theta = theta.reshape(b, att.ch // 8, -1)
-        phi = phi.reshape(b, att.ch // 8, -1)
-        g = g.reshape(b, att.ch // 2, -1)
-        beta = TF.softmax_lastdim(TF.bmm(theta, phi, True, False))
-        os_.append(TF.bmm(g, beta, False, True).reshape((b, att.ch // 2) + tuple(x.shape[2:])))
+    phis = TF.max_pool2x2_group(TF.conv_group(xs, att.phi.weight, None))
+    gs = TF.max_pool2x2_group(TF.conv_group(xs, att.g.weight, None))
+    bs = [x.size(0) for x in xs]
+    thetas = [t.reshape(b, att.ch // 8, -1) for t, b in zip(thetas, bs)]
+    phis = [t.reshape(b, att.ch // 8, -1) for t, b in zip(phis, bs)]
+    gs = [t.reshape(b, att.ch // 2, -1) for t, b in zip(gs, bs)]
+    betas = TF.softmax_lastdim_group(TF.bmm_group(thetas, phis, True, False))
+    os_ = TF.bmm_group(gs, betas, False, True)
+    os_ = [o.reshape((b, att.ch // 2) + tuple(x.shape[2:])) for o, b, x in zip(os_, bs, xs)]
     os_ = TF.conv_group(os_, att.o.weight, None)
-    return [TF.scale_add(att.gamma, o, x) for o, x in zip(os_, xs)]
+    return TF.scale_add_group(att.gamma, os_, xs)
 
 
 class Attention(nn.Module):
