@@ -129,7 +129,8 @@ def test_relu_conv_grouped_first_and_second_order(shapes):
     (64, 96, (3, 3, 3), [(2, 64, 4, 8, 8), (1, 64, 2, 16, 16), (3, 64, 1, 4, 4)]),     # 3-tap-row kernel: bias summed on the side
     (64, 64, (1, 3, 3), [(4, 64, 1, 16, 16)]),                                          # 2-D, one member
     (32, 48, (3, 3, 3), [(2, 32, 4, 8, 8), (2, 32, 2, 4, 4)]),                          # Cin < 64: stand-alone channel sum
-    (128, 40, (1, 1, 1), [(2, 128, 4, 8, 8), (5, 128, 1, 1, 1)]),                       # 1x1x1 kernel
+    (128, 40, (1, 1, 1), [(2, 128, 4, 8, 8), (5, 128, 1, 1, 1)]),                       # 1x1x1 kernel (per-tap kernel, bias on the side)
+    (64, 32, (3, 3, 3), [(3, 64, 2, 1, 1), (2, 64, 1, 1, 1)]),                          # 3^3 kernel on W = 1 maps: centre-tap workgroups sum the bias
 ])
 def test_wgrad_with_bias_gradient(cin, cout, k, shapes):
     """`t2v_conv_wgrad_grouped_bias`: dW and db of a grouped convolution in one call, stored or accumulated."""

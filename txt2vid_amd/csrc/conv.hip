@@ -1235,7 +1235,8 @@ struct LiveTaps { int8_t t[T2V_MAX_TAPS]; int32_t n; };   // slab slot j -> orig
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                          const int Cout, const int T, const int kH, const int kW,
-                                                         const int flags, const int chunks_per_split, const LiveTaps live) {
+                                                         const int flags, const int chunks_per_split, const LiveTaps live,
+                                                         float* __restrict__ bias_slab) {
     __shared__ __attribute__((aligned(16))) float As[64 * WG_PITCH];   // gy^T tile  [co][m]
     __shared__ __attribute__((aligned(16))) float Bs[64 * WG_PITCH];   // x   tile   [ci][m]
 
@@ -1267,6 +1268,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 
     float ra[8], rb[8];
     bool pend_v = false;
+    // bias gradient on the side (see conv_wgrad3_kernel): the centre tap's workgroups of the first channel tile see every
+    // voxel of every member exactly once
+    const bool do_bias = bias_slab != nullptr && ci0 == 0 && t == T / 2;
+    bool pend_mv = false;
+    float bsum[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
     const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
     auto load_chunk = [&](int q) {
         if (dbg_noload && q != q0) return;
@@ -1305,10 +1313,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
             rb[p] = x[xb + (size_t)(ci < Cin ? ci : Cin - 1) * DHW];
         }
         pend_v = xv;
+        pend_mv = mv;
     };
 
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
+        }
         if (!(dbg_nostage && q != q0))
 #pragma unroll
         for (int p = 0; p < 8; ++p) {          // masking + fused ReLU at the LDS write, one chunk after the loads
@@ -1327,6 +1340,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = bsum[p];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int co = co0 + rl + p * 8;
+            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
+        }
     }
     // slab[((split*nlive + slot)*Cout + co)*Cin + ci]; rows = co (registers), cols = ci (lanes)
     const int ci = ci0 + wci * 32 + l31;
@@ -1772,8 +1795,8 @@ extern "C" int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups
 
 // floats the bias part needs behind the weight-gradient slab: S x Cout partial sums when the 3-tap kernel produces them
 // on the side, else the workspace of the stand-alone channel sum
-static int64_t wgrad_bias_extra(const t2v_conv_group* groups, int ngroups, int Cout, const WgradPlan& p) {
-    if (p.rows3) return (int64_t)p.S * Cout;
+static int64_t wgrad_bias_extra(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const WgradPlan& p) {
+    if (p.rows3 || Cin >= 64) return (int64_t)p.S * Cout;
     t2v_conv_group tmp[T2V_MAX_GROUPS];
     for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
     const int64_t n = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
@@ -1784,7 +1807,7 @@ extern "C" int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group*
     WGroupTable tab;
     WgradPlan p;
     if (!build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
-    return (int64_t)p.S * p.nlive * Cout * Cin + wgrad_bias_extra(groups, ngroups, Cout, p);
+    return (int64_t)p.S * p.nlive * Cout * Cin + wgrad_bias_extra(groups, ngroups, Cin, Cout, p);
 }
 
 static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, float* dw,
@@ -1805,7 +1828,8 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     if (!dw || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;         // behind the weight-gradient slab
-    if (dbias && !p.rows3) {                                              // no fused path: the stand-alone channel sum
+    const bool bias_fused = p.rows3 || Cin >= 64;                         // both MFMA weight-gradient kernels sum dL/dy on the side
+    if (dbias && !bias_fused) {                                           // Cin < 64: the stand-alone channel sum
         t2v_conv_group tmp[T2V_MAX_GROUPS];
         for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
         const int64_t nws = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
@@ -1859,12 +1883,13 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
             T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
         } else {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
-            T2V_LAUNCH_PROF(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+            T2V_LAUNCH_PROF(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
+                            dbias ? bias_part : (float*)nullptr);
         }
     }
     int st = launch_status();
     if (st) return st;
-    if (dbias && p.rows3)
+    if (dbias && bias_fused)
         T2V_LAUNCH(bias_slab_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, bias_part, dbias, p.S, Cout,
                    (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0);
     const long CoCi = (long)Cout * Cin;
