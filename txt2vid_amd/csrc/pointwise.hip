@@ -887,6 +887,34 @@ __global__ __launch_bounds__(256) void mj_dot_final_k(const float* __restrict__ 
     const float v = block_sum(acc, red);
     if (threadIdx.x == 0) out[0] = accum ? out[0] + v : v;
 }
+// out = (b > 0) ? a : 0      (ReLU adjoint; a = g, b = x)
+__global__ __launch_bounds__(256) void mj_relu_mask_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* g = (const float*)q.a; const float* x = (const float*)q.b; float* o = (float*)q.out;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) o[i] = x[i] > 0.f ? g[i] : 0.f;
+}
+// row sums (one wave per row): out[row] = sum_s a[row][s], n = rows, d0 = S;  mode 1: broadcast out[row][s] = a[row]
+__global__ __launch_bounds__(256) void mj_rowsum_k(const MultiBatch tb, const int bcast) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const long S = q.d0;
+    if (!bcast) {
+        const long row = (long)((int)blockIdx.x - tb.begin[ji]) * 4 + (threadIdx.x >> 6);
+        if (row >= q.n) return;
+        const float* p = (const float*)q.a + row * S;
+        float acc = 0.f;
+        for (long i = threadIdx.x & 63; i < S; i += 64) acc += p[i];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) ((float*)q.out)[row] = acc;
+    } else {
+        const long n = q.n * S;
+        const float* g = (const float*)q.a; float* o = (float*)q.out;
+        const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+        for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < n; i += 256) o[i] = g[i / S];
+    }
+}
 // 2x2 max-pool over the trailing (d0 = H, d1 = W) plane: a = x, out = y, out2 = idx (int32); n = planes
 __global__ __launch_bounds__(256) void mj_maxpool_k(const MultiBatch tb) {
     const int ji = mj_find(tb);
@@ -1046,6 +1074,15 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
             case T2V_MJ_SOFTMAX: case T2V_MJ_SOFTMAX_BWD: case T2V_MJ_SOFTMAX_BWD_BWD_Y:
                 if (!q.out || q.d0 < 1 || (op != T2V_MJ_SOFTMAX && !q.b) || (op == T2V_MJ_SOFTMAX_BWD_BWD_Y && !q.c)) return T2V_EINVAL;
                 nb = (q.n + 3) / 4; break;
+            case T2V_MJ_RELU_MASK:
+                if (!q.b || !q.out) return T2V_EINVAL;
+                nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_ROWSUM:
+                if (!q.out || q.d0 < 1) return T2V_EINVAL;
+                nb = (q.n + 3) / 4; break;
+            case T2V_MJ_ROWBCAST:
+                if (!q.out || q.d0 < 1) return T2V_EINVAL;
+                nb = (q.n * q.d0 + MJ_CHUNK - 1) / MJ_CHUNK; break;
             case T2V_MJ_BMM:
                 if (!q.b || !q.out || q.d0 < 1 || q.d1 < 1 || q.d2 < 1) return T2V_EINVAL;
                 nb = (long)((q.d1 + 15) / 16) * ((q.d0 + 15) / 16) * q.n; break;
@@ -1074,6 +1111,9 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
         case T2V_MJ_SOFTMAX_BWD: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 1); break;
         case T2V_MJ_SOFTMAX_BWD_BWD_Y: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 2); break;
         case T2V_MJ_BMM: T2V_LAUNCH(mj_bmm_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_RELU_MASK: T2V_LAUNCH(mj_relu_mask_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_ROWSUM: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 0); break;
+        case T2V_MJ_ROWBCAST: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 1); break;
     }
     return launch_status();
 }

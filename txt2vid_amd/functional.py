@@ -1043,7 +1043,8 @@ def scale_add(gamma, o, x):
 # levels / members instead of one per level. Same closure under differentiation as the single-tensor Functions;
 # members that receive no gradient (None) are left out of the backward launches.
 # ------------------------------------------------------------------------------------------------
-MJ_SCALE, MJ_SCALE_ADD, MJ_DOT, MJ_MAXPOOL, MJ_MAXSCATTER, MJ_MAXGATHER, MJ_SOFTMAX, MJ_SOFTMAX_BWD, MJ_SOFTMAX_BWD_BWD_Y, MJ_BMM = range(1, 11)
+(MJ_SCALE, MJ_SCALE_ADD, MJ_DOT, MJ_MAXPOOL, MJ_MAXSCATTER, MJ_MAXGATHER, MJ_SOFTMAX, MJ_SOFTMAX_BWD, MJ_SOFTMAX_BWD_BWD_Y, MJ_BMM,
+ MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST) = range(1, 14)
 
 
 def _mj(op, jobs, scalar=None, dot_out=None):
@@ -1327,6 +1328,74 @@ class ScaleAddG(Function):
                 for i, r in zip(lo, ScaleG.apply(s, *[gs[i] for i in lo])):
                     d_os[i] = r
         return (d_s, None) + tuple(d_os) + tuple(gs)
+
+
+class ReluMaskG(Function):
+    """outs[i] = gs[i] * [xs[i] > 0] for several tensors in one launch (linear in g; its adjoint is itself)."""
+
+    @staticmethod
+    def forward(ctx, n, *gs_xs):
+        gs, xs = [_c(t) for t in gs_xs[:n]], [_c(t) for t in gs_xs[n:]]
+        outs = [torch.empty_like(g) for g in gs]
+        _mj(MJ_RELU_MASK, [dict(a=g, b=x, out=o, n=g.numel()) for g, x, o in zip(gs, xs, outs)])
+        ctx.save_for_backward(*xs)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *ggs):
+        xs = ctx.saved_tensors
+        live = _live(ggs)
+        out = [None] * len(xs)
+        if live:
+            for i, r in zip(live, ReluMaskG.apply(len(live), *([ggs[i] for i in live] + [xs[i] for i in live]))):
+                out[i] = r
+        return (None,) + tuple(out) + (None,) * len(xs)
+
+
+class RowSumG(Function):
+    """ys[i] = xs[i] summed over everything behind the first two dims ([b,C,...] -> [b,C]) for several tensors."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_c(x) for x in xs]
+        ys = [torch.empty(tuple(x.shape[:2]), device=x.device, dtype=torch.float32) for x in xs]
+        _mj(MJ_ROWSUM, [dict(a=x, out=y, n=y.numel(), d0=x.numel() // y.numel()) for x, y in zip(xs, ys)])
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = _live(gs)
+        out = [None] * len(gs)
+        if live:
+            for i, r in zip(live, RowBcastG.apply(tuple(ctx.shapes[i] for i in live), *[gs[i] for i in live])):
+                out[i] = r
+        return tuple(out)
+
+
+class RowBcastG(Function):
+    @staticmethod
+    def forward(ctx, shapes, *gs):
+        gs = [_c(g) for g in gs]
+        outs = [torch.empty(sh, device=g.device, dtype=torch.float32) for sh, g in zip(shapes, gs)]
+        _mj(MJ_ROWBCAST, [dict(a=g, out=o, n=g.numel(), d0=o.numel() // g.numel()) for g, o in zip(gs, outs)])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *ggs):
+        live = _live(ggs)
+        out = [None] * len(ggs)
+        if live:
+            for i, r in zip(live, RowSumG.apply(*[ggs[i] for i in live])):
+                out[i] = r
+        return (None,) + tuple(out)
+
+
+def sum_spatial_group(xs):
+    return list(RowSumG.apply(*xs))
 
 
 def max_pool2x2_group(xs):
@@ -2340,7 +2409,10 @@ class ConvDgradMaskG(Function):
         d_w = None
         d_gys = [None] * n
         if live:
-            hs = {i: ReluMask.apply(ggxs[i], xs[i]) for i in live}
+            if len(live) > 1:
+                hs = dict(zip(live, ReluMaskG.apply(len(live), *([ggxs[i] for i in live] + [xs[i] for i in live]))))
+            else:
+                hs = {i: ReluMask.apply(ggxs[i], xs[i]) for i in live}
             if ctx.needs_input_grad[0] and _param_grads_enabled:
                 lx, lg = [hs[i] for i in live], [gys[i] for i in live]
                 done, d_w = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), False, out=out, accum=acc))

@@ -64,14 +64,15 @@ class Resnet3D(nn.Module):
                 hs = down_block_levels(d, hs)
             else:
                 hs = nonlocal_levels(d, hs)
+        feats = TF.sum_spatial_group(hs)                                      # torch.sum(x, [2,3,4]) of every level: one launch
+        w5 = self.fc_uncond.weight.view(self.fc_uncond.weight.shape + (1, 1, 1))
+        us = TF.conv_group([f.view(f.shape + (1, 1, 1)) for f in feats], w5, self.fc_uncond.bias)   # all heads: one launch
         out = []
-        for i, h in enumerate(hs):
-            feat = TF.sum_spatial(h)
-            u = self.fc_uncond(feat)
+        for i, (feat, u) in enumerate(zip(feats, us)):
             c = None
             if conds is not None:
                 c = self.fc(TF.cat_features(feat, conds[i]))
-            out.append((u, c, feat))
+            out.append((u.view(u.shape[0], u.shape[1]), c, feat))
         return out
 
     def forward(self, x=None, cond=None, xbar=None, computed_features=None):
