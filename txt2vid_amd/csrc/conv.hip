@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
     uint32_t pm0 = 0, pm1 = 0, pm2 = 0;       // pending chunk: validity of (voxel, dx) as 32-bit masks
     int pend_DHW = 1;
     // bias gradient on the side: the workgroups of the first channel tile and first kernel row also add up the dL/dy
-    // values they stage anyway (bias_slab[split][co], summed over the splits by bias_slab_reduce_kernel)
+    // values they stage anyway (bias_slab[split][co], summed over the splits by one workgroup of the reduce kernel)
     const bool do_bias = bias_slab != nullptr && ci0 == 0 && rslot == 0;
     bool pend_mv = false;
     float bsum[8];
@@ -1697,29 +1697,32 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
     }
 }
 
-// dbias[co] = (accum ? dbias[co] : 0) + sum_s bias_slab[s][co]   (fixed order)
-__global__ __launch_bounds__(256) void bias_slab_reduce_kernel(const float* __restrict__ bias_slab, float* __restrict__ dbias,
-                                                               int S, int Cout, int accum) {
-    const int co = blockIdx.x * 256 + threadIdx.x;
-    if (co >= Cout) return;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        v0 += bias_slab[(size_t)s * Cout + co]; v1 += bias_slab[(size_t)(s + 1) * Cout + co];
-        v2 += bias_slab[(size_t)(s + 2) * Cout + co]; v3 += bias_slab[(size_t)(s + 3) * Cout + co];
+// one workgroup's share of  dbias[co] = (accum ? dbias[co] : 0) + sum_s bias_slab[s][co]  (fixed order); called by ONE
+// workgroup of the weight-gradient reduce kernels so that the bias needs no launch of its own
+__device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bias_slab, float* __restrict__ dbias, int S, int Cout,
+                                                 int accum) {
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {
+            v0 += bias_slab[(size_t)s * Cout + co]; v1 += bias_slab[(size_t)(s + 1) * Cout + co];
+            v2 += bias_slab[(size_t)(s + 2) * Cout + co]; v3 += bias_slab[(size_t)(s + 3) * Cout + co];
+        }
+        for (; s < S; ++s) v0 += bias_slab[(size_t)s * Cout + co];
+        const float v = (v0 + v1) + (v2 + v3);
+        dbias[co] = accum ? dbias[co] + v : v;
     }
-    for (; s < S; ++s) v0 += bias_slab[(size_t)s * Cout + co];
-    const float v = (v0 + v1) + (v2 + v3);
-    dbias[co] = accum ? dbias[co] + v : v;
 }
-
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
 
 // dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
 // lane-contiguous along (co,ci); the [i][t] transposition goes through LDS so that the PyTorch-layout
 // gradient is written as one contiguous run per workgroup.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                           long CoCi, int T, int ntaps, int S, TapMap map, int accum) {
+                                                           long CoCi, int T, int ntaps, int S, TapMap map, int accum,
+                                                           const float* __restrict__ bias_slab, float* __restrict__ dbias,
+                                                           int Cout, int accum_bias) {
+    if (bias_slab && blockIdx.x == 0) bias_slab_reduce(bias_slab, dbias, S, Cout, accum_bias);
     // workgroup = 64 (co,ci) pairs x T taps; the 4 waves take taps t = wave, wave+4, ...
     __shared__ float tile[64 * T2V_MAX_TAPS];
     const long i0 = (long)blockIdx.x * 64;
@@ -1750,7 +1753,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Small weights with many k-splits (the 64x64 and 64x1 stem convs: 171-256 partial slabs): one workgroup per
 // (64 pairs, tap); the 4 waves each sum a quarter of the splits and combine through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                 long CoCi, int T, int ntaps, int S, TapMap map, int accum) {
+                                                                 long CoCi, int T, int ntaps, int S, TapMap map, int accum,
+                                                                 const float* __restrict__ bias_slab, float* __restrict__ dbias,
+                                                                 int Cout, int accum_bias) {
+    if (bias_slab && blockIdx.x == 0 && blockIdx.y == 0) bias_slab_reduce(bias_slab, dbias, S, Cout, accum_bias);
     __shared__ float part[4][64];
     const int t = blockIdx.y;
     const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -1928,17 +1934,16 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     }
     int st = launch_status();
     if (st) return st;
-    if (dbias && bias_fused)
-        T2V_LAUNCH(bias_slab_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, s, bias_part, dbias, p.S, Cout,
-                   (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0);
+    const float* bias_in = (dbias && bias_fused) ? bias_part : (const float*)nullptr;   // summed by one workgroup of the reduce below
+    const int accum_bias = (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0;
     const long CoCi = (long)Cout * Cin;
     ProfScope prof2(2, 0.0, s, CoCi, Cin, Cout, T, live.n, p.S);
     if (CoCi <= 16384 && p.S >= 16)
         T2V_LAUNCH_PROF(wgrad_reduce_small_kernel, dim3((unsigned)((CoCi + 63) / 64), (unsigned)T), dim3(256), 0, s, slab, dw, CoCi, T,
-                   live.n, p.S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0);
+                   live.n, p.S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
     else
         T2V_LAUNCH_PROF(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
-                   (flags & T2V_CONV_ACCUM) ? 1 : 0);
+                   (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
     return launch_status();
 }
 

@@ -549,6 +549,79 @@ __global__ void bn_bwd_apply_k(const float* gy, const float* x, const float* y, 
         gx[i] = gamma[c] * istd * (g - ws[c] * invcnt - xh * ws[C + c] * invcnt);
     }
 }
+// Fused second passes: every workgroup (channel c, slice y) first merges the channel's partial statistics itself — a
+// short serial Chan merge / sum, identical in every workgroup of the channel — and then normalises its slice; the
+// y == 0 workgroup also publishes the merged values (stats, running stats / dgamma, dbeta). No `final` launch.
+__global__ __launch_bounds__(256) void bn_apply_merge_k(const float* x, const float* part, int split, const float* gamma,
+                                                        const float* beta, float* y, float* stats, float* rmean, float* rvar,
+                                                        int N, int C, long S, float momentum, float eps, int relu) {
+    const int c = blockIdx.x;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < split; ++k) {
+        const float* p = part + ((size_t)c * split + k) * 3;
+        const float nb = p[0];
+        if (nb <= 0.f) continue;
+        const float delta = p[1] - mean, nt = n + nb;
+        mean += delta * (nb / nt);
+        m2 += p[2] + delta * delta * (n * nb / nt);
+        n = nt;
+    }
+    const float var = m2 / n;
+    const float istd = 1.f / sqrtf(var + eps);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        stats[c] = mean;
+        stats[C + c] = istd;
+        if (rmean) {
+            const float unb = n > 1.f ? m2 / (n - 1.f) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
+    }
+    const float sc = istd * gamma[c], sh = beta[c];
+    const long total = (long)N * S;
+    const long per = (total + gridDim.y - 1) / gridDim.y;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const long nn = e / S, sp = e - nn * S;
+        const size_t idx = ((size_t)nn * C + c) * S + sp;
+        const float v = (x[idx] - mean) * sc + sh;
+        y[idx] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_merge_k(const float* gy, const float* x, const float* y, const float* stats,
+                                                            const float* gamma, const float* part, int split, float* gx,
+                                                            float* ggamma, float* gbeta, int N, int C, long S, int relu) {
+    const int c = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < split; ++k) { s1 += part[((size_t)c * split + k) * 2]; s2 += part[((size_t)c * split + k) * 2 + 1]; }
+    if (blockIdx.y == 0 && threadIdx.x == 0) { gbeta[c] = s1; ggamma[c] = s2; }
+    const float mean = stats[c], istd = stats[C + c];
+    const float invcnt = 1.f / (float)((long)N * S);
+    const float k0 = gamma[c] * istd, a1 = s1 * invcnt, a2 = s2 * invcnt;
+    const long total = (long)N * S;
+    const long per = (total + gridDim.y - 1) / gridDim.y;
+    const long e0 = (long)blockIdx.y * per;
+    long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const long nn = e / S, sp = e - nn * S;
+        const size_t idx = ((size_t)nn * C + c) * S + sp;
+        float g = gy[idx];
+        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        const float xh = (x[idx] - mean) * istd;
+        gx[idx] = k0 * (g - a1 - xh * a2);
+    }
+}
+static int bn_slices(int N, int C, long S) {           // workgroups per channel of the fused second passes
+    const long total = (long)N * S;
+    long sl = (2048 + C - 1) / C;
+    if (sl > (total + 1023) / 1024) sl = (total + 1023) / 1024;
+    if (sl < 1) sl = 1;
+    if (sl > 1024) sl = 1024;
+    return (int)sl;
+}
 __global__ void bn_eval_k(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,
                           int N, int C, long S, float eps, int relu) {
     const long n = (long)N * C * S;
@@ -585,6 +658,25 @@ extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const
     T2V_LAUNCH(bn_bwd_part_k, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, part, N, C, (long)S, relu, sp);
     T2V_LAUNCH(bn_bwd_final_k, dim3((C + 255) / 256), dim3(256), 0, S_(st), part, ws, ggamma, gbeta, C, sp);
     T2V_LAUNCH(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
+    return launch_status();
+}
+extern "C" int t2v_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* rm, float* rv,
+                                float* ws, int N, int C, int64_t S, float momentum, float eps, int relu, void* st) {
+    if (!x || !gamma || !beta || !y || !stats || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    const int sp = bn_split(N, C, (long)S);
+    T2V_LAUNCH(bn_stats_part_k, dim3(C, sp), dim3(256), 0, S_(st), x, ws, N, C, (long)S, sp);
+    T2V_LAUNCH(bn_apply_merge_k, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), x, ws, sp, gamma, beta, y, stats, rm, rv, N,
+               C, (long)S, momentum, eps, relu);
+    return launch_status();
+}
+extern "C" int t2v_bn_train_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
+                                float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* st) {
+    if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
+    if (relu && !y) return T2V_EINVAL;
+    const int sp = bn_split(N, C, (long)S);
+    T2V_LAUNCH(bn_bwd_part_k, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, (long)S, relu, sp);
+    T2V_LAUNCH(bn_bwd_apply_merge_k, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
+               ggamma, gbeta, N, C, (long)S, relu);
     return launch_status();
 }
 extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,

@@ -1475,9 +1475,8 @@ class BatchNormAct(Function):
         if training:
             stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
             ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
-            check(lib().t2v_bn_stats(_p(x), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S, momentum, eps, _stream()),
-                  't2v_bn_stats')
-            check(lib().t2v_bn_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, Cc, S, int(relu), _stream()), 't2v_bn_apply')
+            check(lib().t2v_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S, momentum,
+                                         eps, int(relu), _stream()), 't2v_bn_train_fwd')
             ctx.save_for_backward(x, y, stats, gamma)
             ctx.relu = relu
         else:
@@ -1499,8 +1498,8 @@ class BatchNormAct(Function):
         gg = torch.empty_like(gamma)
         gb = torch.empty_like(gamma)
         ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
-        check(lib().t2v_bn_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
-                               int(ctx.relu), _stream()), 't2v_bn_bwd')
+        check(lib().t2v_bn_train_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
+                                     int(ctx.relu), _stream()), 't2v_bn_train_bwd')
         return gx, gg, gb, None, None, None, None, None, None
 
 
