@@ -152,6 +152,37 @@ def test_wgrad_with_bias_gradient(cin, cout, k, shapes):
     close(db, 2 * b.grad.float(), rtol=2e-4, atol=2e-4)
 
 
+def test_conv_multi_group_accumulates_data_gradients_in_kernel():
+    """`ConvMultiG`: a 3^3 ReLU-conv and a 1^3 conv of the same tensors (a DownBlock's main / skip pair). First-order backward
+    without a recorded graph takes the in-kernel accumulation path (T2V_CONV_ACCUM into one buffer per member); the
+    create_graph sweep takes the composed path; both against torch, one member without gradient."""
+    from txt2vid_amd import functional as TF
+    shapes = [(2, 16, 4, 6, 6), (1, 16, 2, 8, 8), (3, 16, 1, 4, 4)]
+    w1, b1 = rnd(1, 24, 16, 3, 3, 3) * 0.2, rnd(2, 24) * 0.1
+    w2, b2 = rnd(3, 24, 16, 1, 1, 1) * 0.3, rnd(4, 24) * 0.1
+    xs0 = [rnd(90 + i, *s_) for i, s_ in enumerate(shapes)]
+
+    def run(fwd, to, second_order):
+        ps = [to(t).requires_grad_(True) for t in (w1, b1, w2, b2)]
+        xs = [to(x).requires_grad_(i != 2) for i, x in enumerate(xs0)]
+        hs, ss = fwd(xs, *ps)
+        out = sum(((h + s_) ** 2).sum() for h, s_ in zip(hs, ss))
+        if second_order:
+            g1 = torch.autograd.grad(out, xs[:2], create_graph=True)
+            out = out * 0.01 + sum((g * g).sum() for g in g1)
+        out.backward()
+        return [h.detach() for h in hs] + [s_.detach() for s_ in ss] + [xs[0].grad, xs[1].grad] + [p_.grad for p_ in ps]
+
+    def ref_fwd(xs, a, b, c, d):
+        return [F.conv3d(F.relu(x), a, b, padding=1) for x in xs], [F.conv3d(x, c, d) for x in xs]
+
+    for second in (False, True):
+        ref = run(ref_fwd, lambda t: t.double(), second)
+        got = run(lambda xs, a, b, c, d: TF.conv_multi_group(xs, [(a, b, True), (c, d, False)]), lambda t: t.to(dev()), second)
+        for a_, r_ in zip(got, ref):
+            close(a_, r_.float(), rtol=2e-4, atol=2e-4)
+
+
 def test_avgpool():
     from txt2vid_amd import functional as TF
     for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),

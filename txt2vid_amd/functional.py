@@ -2246,7 +2246,7 @@ def _group_table(ins, outs, geoms, slot_of, masks=None):
     return arr
 
 
-def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
+def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=None, accum=False):
     """mode 0: ys[i] = conv(xs[i], w) (+bias); mode 1: data gradient (xs are dL/dy, channels swap roles).
     masks: ys[i] is zeroed where masks[i] <= 0 (the ReLU adjoint, fused into the epilogue)."""
     if len(xs5) > MAX_GROUPS:
@@ -2263,7 +2263,8 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
     ts = _tapset(geoms[0].T, mask)
     wp = packed_weight(w5, ts, mode)
     slot_of = {t: j for j, t in enumerate(ts.taps)}
-    ys = [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32) for t in xs5]
+    ys = outs if outs is not None else [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32)
+                                        for t in xs5]
     if masks is not None:
         masks = [_c(m) for m in masks]
         if any(m.shape != y.shape for m, y in zip(masks, ys)):
@@ -2273,7 +2274,8 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None):
     if n < 0:
         raise RuntimeError('bad grouped conv geometry')
     ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
-    flags = (FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0)
+    flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0) |
+             (FLAG_ACCUM if accum else 0))
     check(lib().t2v_conv_fwd_grouped(arr, len(xs5), cin, cout, _p(wp), _p(bias), _p(ws), flags, _stream()), 't2v_conv_fwd_grouped')
     return ys
 
@@ -2337,20 +2339,104 @@ class ConvG(Function):
             for i, r in zip(need, res):
                 gxs[i] = r
         if _param_grads_enabled:
-            lx, lg = [xs[i] for i in live], [gys[i] for i in live]
-            both = False
-            if ctx.needs_input_grad[0] and ctx.has_bias and ctx.needs_input_grad[1]:
-                both, gw, gb = _to_sink_wb(w, ctx.bias, lx, lg, ctx.relu_in)
-            if not both:
-                if ctx.needs_input_grad[0]:
-                    done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), ctx.relu_in, out=out, accum=acc))
-                    if not done:
-                        gw = ConvWgradG.apply(tuple(w.shape), ctx.relu_in, len(live), *(lx + lg))
-                if ctx.has_bias and ctx.needs_input_grad[1]:
-                    done, gb = _to_sink(ctx.bias, lambda out, acc: channel_sum_group_raw(lg, out=out, accum=acc))
-                    if not done:
-                        gb = ChannelSumG.apply(*lg)
+            gw, gb = _group_param_grads(w, ctx.bias if ctx.has_bias else None, ctx.relu_in, [xs[i] for i in live],
+                                        [gys[i] for i in live], ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1])
         return (gw, gb, None) + tuple(gxs)
+
+
+def _group_param_grads(w, b, relu_in, lx, lg, need_w, need_b):
+    """(gw, gb) of a grouped convolution over its live members: into the gradient sink when one is armed (one launch for
+    both when possible), else as differentiable Functions."""
+    gw = gb = None
+    both = False
+    if need_w and need_b:
+        both, gw, gb = _to_sink_wb(w, b, lx, lg, relu_in)
+    if not both:
+        if need_w:
+            done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), relu_in, out=out, accum=acc))
+            if not done:
+                gw = ConvWgradG.apply(tuple(w.shape), relu_in, len(lx), *(lx + lg))
+        if need_b:
+            done, gb = _to_sink(b, lambda out, acc: channel_sum_group_raw(lg, out=out, accum=acc))
+            if not done:
+                gb = ChannelSumG.apply(*lg)
+    return gw, gb
+
+
+class ConvMultiG(Function):
+    """Several convolutions of the SAME tensors (a block's main and skip convolution; the non-local block's theta / phi / g):
+    outputs of spec k are ys[k*n:(k+1)*n]. Forward = one grouped launch per spec, as separate ConvG calls would be; the
+    point is the backward: the data gradients of all specs are accumulated by the kernels into ONE buffer per member
+    (T2V_CONV_ACCUM), so autograd never has to add the contributions of the consumers of a tensor. While autograd is
+    recording (the gradient penalty's sweep) the backward is composed from the differentiable Functions instead.
+    args: relus (tuple of bool per spec), nspec, then w_0, b_0, ..., w_{k-1}, b_{k-1}, then the n tensors."""
+
+    @staticmethod
+    def forward(ctx, relus, nspec, *rest):
+        wb, xs = rest[:2 * nspec], rest[2 * nspec:]
+        ws, bs = wb[0::2], wb[1::2]
+        ctx.save_for_backward(*ws, *xs)
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (relus, nspec, len(xs))
+        ctx.biases = bs
+        out = []
+        for w, b, r in zip(ws, bs, relus):
+            out += conv_group_raw(xs, w, b, r, 0)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        relus, nspec, n = ctx.cfg
+        saved = ctx.saved_tensors
+        ws, xs = saved[:nspec], saved[nspec:]
+        bs = ctx.biases
+        g_of = [gys[k * n:(k + 1) * n] for k in range(nspec)]
+        need_x = [ctx.needs_input_grad[2 + 2 * nspec + i] for i in range(n)]
+        gxs = [None] * n
+        order = sorted(range(nspec), key=lambda k: 0 if relus[k] else 1)           # masked data gradients write first
+        fused = not torch.is_grad_enabled()
+        for k in order:
+            mem = [i for i in range(n) if g_of[k][i] is not None and need_x[i]]
+            if not mem:
+                continue
+            fresh = [i for i in mem if gxs[i] is None]
+            again = [i for i in mem if gxs[i] is not None]
+            if fresh:
+                if relus[k]:
+                    res = ConvDgradMaskG.apply(ws[k], len(fresh), *([g_of[k][i] for i in fresh] + [xs[i] for i in fresh]))
+                else:
+                    res = ConvDgradG.apply(ws[k], *[g_of[k][i] for i in fresh])
+                for i, r in zip(fresh, res):
+                    gxs[i] = r
+            if again:
+                if fused and not relus[k]:
+                    conv_group_raw([g_of[k][i] for i in again], ws[k], None, False, 1, outs=[gxs[i] for i in again], accum=True)
+                else:
+                    if relus[k]:
+                        res = ConvDgradMaskG.apply(ws[k], len(again), *([g_of[k][i] for i in again] + [xs[i] for i in again]))
+                    else:
+                        res = ConvDgradG.apply(ws[k], *[g_of[k][i] for i in again])
+                    for i, r in zip(again, res):
+                        gxs[i] = Add.apply(gxs[i], r)
+        grads = []
+        for k in range(nspec):
+            gw = gb = None
+            live = [i for i in range(n) if g_of[k][i] is not None]
+            if live and _param_grads_enabled:
+                gw, gb = _group_param_grads(ws[k], bs[k], relus[k], [xs[i] for i in live], [g_of[k][i] for i in live],
+                                            ctx.needs_input_grad[2 + 2 * k], bs[k] is not None and ctx.needs_input_grad[3 + 2 * k])
+            grads += [gw, gb]
+        return (None, None) + tuple(grads) + tuple(gxs)
+
+
+def conv_multi_group(xs, specs):
+    """specs: [(w, b, relu_in), ...] applied to the same tensors; returns one list of outputs per spec."""
+    n = len(xs)
+    flat = []
+    for w, b, _ in specs:
+        flat += [w, b]
+    out = ConvMultiG.apply(tuple(bool(r) for _, _, r in specs), len(specs), *(flat + list(xs)))
+    return [list(out[k * n:(k + 1) * n]) for k in range(len(specs))]
 
 
 def conv_out_like(x, w):

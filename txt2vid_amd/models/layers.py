@@ -113,9 +113,10 @@ def nonlocal_levels(att, xs):
     levels together (layers.py:52-68)."""
     if len(xs) > 8:
         raise ValueError('at most 8 tensors per grouped non-local block')
-    thetas = TF.conv_group(xs, att.theta.weight, None)
-    phis = TF.max_pool2x2_group(TF.conv_group(xs, att.phi.weight, None))
-    gs = TF.max_pool2x2_group(TF.conv_group(xs, att.g.weight, None))
+    thetas, phis, gs = TF.conv_multi_group(xs, [(att.theta.weight, None, False), (att.phi.weight, None, False),
+                                                (att.g.weight, None, False)])
+    phis = TF.max_pool2x2_group(phis)
+    gs = TF.max_pool2x2_group(gs)
     bs = [x.size(0) for x in xs]
     thetas = [t.reshape(b, att.ch // 8, -1) for t, b in zip(thetas, bs)]
     phis = [t.reshape(b, att.ch // 8, -1) for t, b in zip(phis, bs)]
@@ -295,9 +296,9 @@ def down_block_levels(block, xs):
     """DownBlock over a list of pyramid levels, layer by layer: each convolution is one grouped launch."""
     m = block.main.inner_module
     idm = block.main.identity_map
-    hs = TF.conv_group(xs, m[1].weight, m[1].bias, relu_in=True)
+    # main conv1 and the skip conv read the same tensors: one Function, so their data gradients land in one buffer
+    hs, ss = TF.conv_multi_group(xs, [(m[1].weight, m[1].bias, True), (idm[0].weight, idm[0].bias, False)])
     hs = TF.conv_group(hs, m[3].weight, m[3].bias, relu_in=True)
-    ss = TF.conv_group(xs, idm[0].weight, idm[0].bias)
     if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
         return TF.avg_pool3d_group(ss, [downsample_cfg(s_) for s_ in ss], x2s=hs)     # one launch for all levels
     return [TF.add(idm[1](s_), m[4](h)) for s_, h in zip(ss, hs)]
