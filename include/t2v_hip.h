@@ -227,6 +227,14 @@ int t2v_softmax_bwd(const float* y, const float* gy, float* gx, int64_t rows, in
 /* adjoint of softmax_bwd w.r.t. y: gyv = gg*(gy - s) - gy*sum(gg*y), s = sum(gy*y) */
 int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, float* out, int64_t rows, int n, void* stream);
 
+/* ---- sentence encoder (txt2vid/models/txt/basic.py:49-70: packed-sequence nn.LSTM, forward only) -----------------
+ * One time step of one (layer, direction): pre = xproj_t[b] (row stride xstride; = x_t W_ih^T + b_ih + b_hh from one GEMM
+ * over all steps) + h_prev[b] W_hh^T; gates i,f,g,o; samples with t >= lengths[b] keep (h, c) and emit 0 into out_t[b]
+ * (row stride ostride). h/c are ping-pong buffers [B,H]. */
+int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, const float* c_prev,
+                      float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B, int H,
+                      void* stream);
+
 /* ---- multi-job launches: the non-local block's small ops over all pyramid levels at once -------------------------
  * Up to 8 differently shaped jobs per call (HOST array; the descriptors travel in the kernel arguments). Field roles:
  *   T2V_MJ_SCALE            out = scalar[0] * a                         n = elements
@@ -278,6 +286,9 @@ int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 typedef struct t2v_adam_job { void* p; const void* g; void* m; void* v; int64_t n; } t2v_adam_job;
 int t2v_adam_multi(const t2v_adam_job* jobs, int njobs, float lr, float b1, float b2, float eps, float bc1, float bc2,
                    float gscale, const float* step_dev, void* stream);
+/* torch.optim.SGD(lr, momentum) semantics, multi-tensor (the reference's --sgd branch, train/gan.py:86-89): jobs[i].m is the
+   momentum buffer (may be NULL when momentum == 0), .v unused; first_step: buf = g (torch's first-step rule). */
+int t2v_sgd_multi(const t2v_adam_job* jobs, int njobs, float lr, float momentum, float gscale, int first_step, void* stream);
 int t2v_adam_tick(float* state, float b1, float b2, void* stream);
 
 /* ---- pyramid (trainer.py:131-165, layers.py:106-111) ------------------------------------------- */

@@ -442,6 +442,30 @@ def test_adam_matches_torch():
         close(pd, pr, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('momentum', [0.0, 0.5])
+def test_sgd_matches_torch(momentum):
+    """`txt2vid_amd.optim.SGD` (t2v_sgd_multi) == torch.optim.SGD(lr, momentum) over 3 steps, ragged sizes, a frozen parameter."""
+    from txt2vid_amd.optim import SGD
+    shapes = [(5,), (4099,), (3, 7, 11), (1,)]
+    ps0 = [rnd(100 + i, *sh) for i, sh in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps0]
+    got = [torch.nn.Parameter(p.clone().to(dev())) for p in ps0]
+    o_ref, o_got = torch.optim.SGD(ref, lr=0.05, momentum=momentum), SGD(got, lr=0.05, momentum=momentum)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if i == 3 and step == 1:
+                a.grad = b.grad = None
+                continue
+            g = rnd(200 + 10 * step + i, *a.shape)
+            a.grad, b.grad = g.clone(), g.to(dev())
+        o_ref.step()
+        o_got.step()
+        for a, b in zip(ref, got):
+            close(b, a, rtol=1e-6, atol=1e-6)
+    if momentum:
+        close(o_got.state[got[1]]['momentum_buffer'], o_ref.state[ref[1]]['momentum_buffer'], rtol=1e-6, atol=1e-6)
+
+
 def test_pyramid_gather():
     from txt2vid_amd import functional as TF
     x = rnd(1, 5, 2, 8, 16, 16)

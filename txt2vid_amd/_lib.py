@@ -119,6 +119,7 @@ SIGNATURES = {
     't2v_softmax': [_P, _P, _L, _I, _P],
     't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],
     't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
+    't2v_lstm_seq_step': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _P],
     't2v_multi_ws_floats': [_I, _P, _I],
     't2v_multi': [_I, _P, _I, _P, _P, _P],
     't2v_rsgan': [_P, _P, _P, _I, _P],
@@ -130,6 +131,7 @@ SIGNATURES = {
     't2v_row_scale': [_P, _F, _P, _P, _I, _L, _P],
     't2v_adam': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P, _P],
     't2v_adam_multi': [_P, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P],
+    't2v_sgd_multi': [_P, _I, _F, _F, _F, _I, _P],
     't2v_adam_tick': [_P, _F, _F, _P],
     't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     't2v_copy2d': [_P, _L, _P, _L, _L, _L, _P],

@@ -936,6 +936,46 @@ extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const floa
     return launch_status();
 }
 
+// ---------------------------------------------------------------- sentence encoder (models/txt/basic.py:49-70)
+// One time step of one (layer, direction) of the packed-sequence LSTM: thread (b, u) adds the recurrent product
+// h_prev[b] . W_hh[g*H + u] to the input projection of step t (computed for all steps by one GEMM), applies the gates
+// (order i, f, g, o) and — pack_padded_sequence semantics — only advances samples with t < length[b]; the others keep
+// their state and emit zeros. H <= 256, B*H threads: the whole step is one small launch.
+__global__ __launch_bounds__(256) void lstm_seq_step_k(const float* __restrict__ xproj, long xstride, const float* __restrict__ whh,
+                                                       const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                       float* __restrict__ h_next, float* __restrict__ c_next,
+                                                       float* __restrict__ out, long ostride, const int32_t* __restrict__ lengths,
+                                                       int t, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, u = i - b * H;
+    const float* hp = h_prev + (size_t)b * H;
+    float acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = xproj[(size_t)b * xstride + g * H + u];
+    for (int k = 0; k < H; ++k) {
+        const float hv = hp[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += hv * whh[((size_t)g * H + u) * H + k];
+    }
+    const bool active = t < lengths[b];
+    const float gi = sigm(acc[0]), gf = sigm(acc[1]), gg = tanhf(acc[2]), go = sigm(acc[3]);
+    const float cc = gf * c_prev[i] + gi * gg;
+    const float hh = go * tanhf(cc);
+    c_next[i] = active ? cc : c_prev[i];
+    h_next[i] = active ? hh : h_prev[i];
+    out[(size_t)b * ostride + u] = active ? hh : 0.f;
+}
+extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, const float* c_prev,
+                                 float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B,
+                                 int H, void* st) {
+    if (!xproj_t || !w_hh || !h_prev || !c_prev || !h_next || !c_next || !out_t || !lengths || B < 1 || H < 1 || t < 0 ||
+        h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_seq_step_k, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, S_(st), xproj_t, (long)xstride, w_hh, h_prev,
+               c_prev, h_next, c_next, out_t, (long)ostride, lengths, t, B, H);
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- multi-job launches (non-local block over pyramid levels)
 // The non-local block runs the same tiny op on every pyramid level (and on the real||fake and x-hat members of a level):
 // up to 8 differently shaped jobs share ONE launch; the job descriptors travel in the kernel arguments and a workgroup
@@ -1467,6 +1507,47 @@ extern "C" int t2v_adam_multi(const t2v_adam_job* jobs, int njobs, float lr, flo
         tb.njobs = cnt;
         if (blocks > 0x7fffffffL) return T2V_EINVAL;
         T2V_LAUNCH(adam_multi_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb, lr, b1, b2, eps, bc1, bc2, gscale, step_dev);
+    }
+    return launch_status();
+}
+// torch.optim.SGD(lr, momentum) semantics (the reference's --sgd branch, train/gan.py:86-89), multi-tensor like adam_multi_k:
+// buf = first ? g : momentum * buf + g ;  p -= lr * (momentum != 0 ? buf : g).   jobs[i].m = momentum buffer, .v unused
+__global__ __launch_bounds__(256) void sgd_multi_k(AdamBatch tb, float lr, float momentum, float gscale, int first) {
+    int lo = 0, hi = tb.njobs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tb.begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const int j = lo;
+    const long base = (long)((int)blockIdx.x - tb.begin[j]) * ADAM_CHUNK;
+    const int len = (int)min((long)ADAM_CHUNK, (long)tb.n[j] - base);
+    float* __restrict__ p = tb.p[j] + base;
+    const float* __restrict__ g = tb.g[j] + base;
+    float* __restrict__ m = tb.m[j] ? tb.m[j] + base : nullptr;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const float gi = g[i] * gscale;
+        float d = gi;
+        if (m) { d = first ? gi : momentum * m[i] + gi; m[i] = d; }
+        p[i] = p[i] - lr * d;
+    }
+}
+extern "C" int t2v_sgd_multi(const t2v_adam_job* jobs, int njobs, float lr, float momentum, float gscale, int first_step, void* st) {
+    if (!jobs || njobs < 1) return T2V_EINVAL;
+    for (int i = 0; i < njobs; ++i)
+        if (!jobs[i].p || !jobs[i].g || (momentum != 0.f && !jobs[i].m) || jobs[i].n < 1 || jobs[i].n > 0x7fffffffL) return T2V_EINVAL;
+    for (int at = 0; at < njobs; at += ADAM_MT) {
+        AdamBatch tb;
+        const int cnt = njobs - at < ADAM_MT ? njobs - at : ADAM_MT;
+        long blocks = 0;
+        for (int i = 0; i < ADAM_MT; ++i) {
+            if (i < cnt) {
+                const t2v_adam_job& jb = jobs[at + i];
+                tb.p[i] = (float*)jb.p; tb.g[i] = (const float*)jb.g; tb.m[i] = momentum != 0.f ? (float*)jb.m : nullptr; tb.v[i] = nullptr;
+                tb.n[i] = (int)jb.n; tb.begin[i] = (int)blocks;
+                blocks += (jb.n + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            } else { tb.p[i] = nullptr; tb.g[i] = nullptr; tb.m[i] = nullptr; tb.v[i] = nullptr; tb.n[i] = 0; tb.begin[i] = (int)blocks; }
+        }
+        tb.begin[ADAM_MT] = (int)blocks;
+        tb.njobs = cnt;
+        if (blocks > 0x7fffffffL) return T2V_EINVAL;
+        T2V_LAUNCH(sgd_multi_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb, lr, momentum, gscale, first_step);
     }
     return launch_status();
 }

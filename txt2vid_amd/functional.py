@@ -2054,6 +2054,44 @@ def gather_rows(x, perm):
     return GatherRows.apply(x, perm_dev, False)
 
 
+def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bidirectional):
+    """Packed-sequence (Bi-)LSTM forward of the sentence encoder on the HIP kernels (models/txt/basic.py:49-70), no autograd
+    (the GAN loop detaches the sentence code unless --end2end). tokens [B,L] int64 (sorted by length, desc), lengths: list.
+    `lstm` is the nn.LSTM that holds the parameters (state_dict layout of the reference). Returns
+    (out [B,L,D*H] zero beyond each length, (h_n, c_n) [layers*D,B,H]) like nn.LSTM on a packed batch."""
+    B, L = int(tokens.shape[0]), int(lengths[0])
+    dev = embed_weight.device
+    H, D = hidden_size, (2 if bidirectional else 1)
+    with torch.no_grad():
+        tok = tokens[:, :L].to(device=dev, dtype=torch.int32).contiguous().view(-1)
+        len_dev = torch.tensor([int(l) for l in lengths], dtype=torch.int32).to(dev)
+        E = embed_weight.shape[1]
+        x = torch.empty((B * L, E), device=dev, dtype=torch.float32)
+        check(lib().t2v_gather_rows(_p(_c(embed_weight.detach())), _p(tok), _p(x), B * L, E, 0, _stream()), 't2v_gather_rows')
+        h_n = torch.empty((num_layers * D, B, H), device=dev, dtype=torch.float32)
+        c_n = torch.empty((num_layers * D, B, H), device=dev, dtype=torch.float32)
+        zero = _zeros_like(h_n[0])
+        inp = x                                                   # [B*L, In]
+        for layer in range(num_layers):
+            out = torch.empty((B, L, D * H), device=dev, dtype=torch.float32)
+            for d in range(D):
+                sfx = '_l%d%s' % (layer, '_reverse' if d else '')
+                w_ih, w_hh = getattr(lstm, 'weight_ih' + sfx).detach(), getattr(lstm, 'weight_hh' + sfx).detach()
+                bsum = _ew(lib().t2v_add, 't2v_add', getattr(lstm, 'bias_ih' + sfx).detach(), getattr(lstm, 'bias_hh' + sfx).detach())
+                xproj = conv_fwd_raw(_as5(inp), _as5(w_ih), bsum).view(B, L, 4 * H)      # all time steps: one GEMM
+                bufs = [(torch.empty_like(zero), torch.empty_like(zero)) for _ in range(2)]      # ping-pong (h, c)
+                for step in range(L):
+                    t = L - 1 - step if d else step
+                    hp, cp = (zero, zero) if step == 0 else bufs[(step - 1) & 1]
+                    hn_, cn_ = (h_n[layer * D + d], c_n[layer * D + d]) if step == L - 1 else bufs[step & 1]
+                    xp = C.c_void_p(xproj.data_ptr() + 4 * t * 4 * H)
+                    op = C.c_void_p(out.data_ptr() + 4 * (t * D * H + d * H))
+                    check(lib().t2v_lstm_seq_step(xp, L * 4 * H, _p(_c(w_hh)), _p(hp), _p(cp), _p(hn_), _p(cn_), op, L * D * H,
+                                                  _p(len_dev), t, B, H, _stream()), 't2v_lstm_seq_step')
+            inp = out.view(B * L, D * H)
+        return out, (h_n, c_n)
+
+
 def head_rows(x, n):
     """x[0:n] — a leading-rows slice of a contiguous tensor is a view (no kernel, no copy)."""
     return x[0:n]

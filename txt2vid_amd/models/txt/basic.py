@@ -1,6 +1,8 @@
 """Bi-LSTM sentence encoder — same surface / state_dict as txt2vid/models/txt/basic.py:4-70 (encode path).
-Negligible FLOPs: it stays `torch.nn.Embedding` + `torch.nn.LSTM` (MIOpen on ROCm) and is
-NOT one of the hand-written kernels; the decoder / `sample` (pre-training only) is out of scope."""
+`nn.Embedding` / `nn.LSTM` only HOLD the parameters (reference checkpoint layout); the forward runs on the HIP kernels
+(`functional.lstm_encode`: embedding gather, one GEMM per layer and direction for the input projections of all time steps,
+one small launch per time step for the recurrence with packed-sequence masking). Forward only: the GAN loop detaches the
+sentence code (trainer.py:211-215) unless --end2end, which is not built. The decoder / `sample` (pre-training) is out of scope."""
 import torch
 import torch.nn as nn
 
@@ -23,14 +25,15 @@ class RecurrentModel(nn.Module):
 
     def forward(self, x, lengths=None, initial_state=None, raw_output=True):
         """tokens [B,L] (sorted by length, desc), lengths -> (out, hidden, hn[B, encoding])  (basic.py:49-70)."""
-        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
-        max_len = lengths[0]
-        packed = pack_padded_sequence(self.embed(x), [int(l) for l in lengths], batch_first=True)
-        out, hidden = self.lstm(packed, initial_state)
-        out, _ = pad_packed_sequence(out, batch_first=True, total_length=int(max_len))
+        from ... import functional as TF
+        if initial_state is not None:
+            raise NotImplementedError('an initial state is only used by the decoder (pre-training), outside the hot path')
+        if not self.embed.weight.is_cuda:
+            raise RuntimeError('the sentence encoder runs on the MI355X kernels only (no CPU path)')
+        out, hidden = TF.lstm_encode(x, lengths, self.embed.weight, self.lstm, self.hidden_size, self.num_layers, self.bi)
         if self.bi:
             hn = hidden[0].view(self.num_layers, 2, -1, self.hidden_size)
-            hn = torch.cat((hn[-1, 0], hn[-1, 1]), dim=1)
+            hn = TF.cat_features(hn[-1, 0], hn[-1, 1])
         else:
             hn = hidden[0].view(self.num_layers, 1, -1, self.hidden_size)[-1]
         if not raw_output:

@@ -47,3 +47,44 @@ class Adam(torch.optim.Optimizer):
         TF.bump_weight_epoch(touched)   # their packed weights are stale ...
         TF.repack_params(touched)       # ... refresh them in place right away (same addresses for graph replay)
         return None
+
+
+class SGD(torch.optim.Optimizer):
+    """`torch.optim.SGD(params, lr, momentum)` on the multi-tensor HIP kernel — the reference's `--sgd` branch
+    (train/gan.py:86-89: momentum = beta1). Same `state_dict()` layout (momentum_buffer)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0, nesterov=False):
+        if dampening != 0 or weight_decay != 0 or nesterov:
+            raise NotImplementedError('the reference only passes lr and momentum')
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=0, nesterov=False))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from ._lib import AdamJob
+        touched = []
+        for group in self.param_groups:
+            mu = float(group['momentum'])
+            first, later = [], []
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if mu != 0 and 'momentum_buffer' not in st:
+                    st['momentum_buffer'] = torch.empty_like(p, memory_format=torch.preserve_format)
+                    first.append((p, g, st['momentum_buffer']))
+                else:
+                    later.append((p, g, st.get('momentum_buffer')))
+                touched.append(p)
+            for items, is_first in ((first, 1), (later, 0)):
+                if not items:
+                    continue
+                arr = (AdamJob * len(items))()
+                for a, (p, g, m) in zip(arr, items):
+                    a.p, a.g, a.m, a.v, a.n = p.data_ptr(), g.data_ptr(), (m.data_ptr() if m is not None else None), None, p.numel()
+                TF.check(TF.lib().t2v_sgd_multi(arr, len(items), group['lr'], mu, self.grad_scale, is_first, TF._stream()),
+                         't2v_sgd_multi')
+        TF.bump_weight_epoch(touched)
+        TF.repack_params(touched)
+        return None

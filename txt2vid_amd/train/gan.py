@@ -13,7 +13,7 @@ from .. import data
 from ..gan.cond_gan import CondGan
 from ..gan.losses import MixedGanLoss
 from ..gan.trainer import add_params_to_parser, train, test
-from ..optim import Adam
+from ..optim import Adam, SGD
 from ..util.log import status
 from ..util.pick import load
 from ..util.reflection import create_object
@@ -55,14 +55,17 @@ def main(args):
     discrims = [d.to(device) for d in discrims]
     if args.M:
         raise NotImplementedError('--M sample mappings (TCWYT baseline) are outside the hot path')
-    if args.sgd:
-        raise NotImplementedError('--sgd is outside the hot path (canonical runs use Adam)')
     D_params = [{'params': d.parameters()} for d in discrims]
     G_params = [{'params': gen.parameters()}]
     if args.end2end and txt_encoder is not None:
         raise NotImplementedError('--end2end (training the text encoder through the GAN) is not built yet')
-    optD = Adam(D_params, lr=args.D_lr, betas=(args.D_beta1, args.D_beta2))
-    optG = Adam(G_params, lr=args.G_lr, betas=(args.G_beta1, args.G_beta2))
+    if args.sgd:                                   # train/gan.py:86-89: momentum = beta1
+        status('Using SGD')
+        optD = SGD(D_params, lr=args.D_lr, momentum=args.D_beta1)
+        optG = SGD(G_params, lr=args.G_lr, momentum=args.G_beta1)
+    else:
+        optD = Adam(D_params, lr=args.D_lr, betas=(args.D_beta1, args.D_beta2))
+        optG = Adam(G_params, lr=args.G_lr, betas=(args.G_beta1, args.G_beta2))
     gan = CondGan(gen=gen, discrims=discrims, cond_encoder=txt_encoder, discrim_names=args.D_names,
                   discrim_lambdas=args.D_lambdas, gp_scale=float(world))
     if args.weights is not None:
