@@ -72,7 +72,7 @@ def pmc_traffic():
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
         for k, v in d['kernels'].items():
-            if 'conv_igemm_kernel' in k:
+            if 'conv_igemm' in k and v.get('FETCH_SIZE_KB_per_launch') and v.get('WRITE_SIZE_KB_per_launch'):
                 b = (v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
                 return b, ('profiles/r01_pmc_traffic.json: %s, per launch; algorithmic %.0f MB; FETCH_SIZE may under-count '
                            'streaming reads by up to 2x on gfx950' % (d['workload'].split(':')[1].split(',')[0].strip(),

@@ -1,0 +1,44 @@
+"""Assemble profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over tools/conv_micro.py:
+
+    cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/conv_micro.py both 3
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/conv_micro.py both 3
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json
+
+(one counter family per pass, MI355X_MICROARCH.md; FETCH_SIZE / WRITE_SIZE are in KB, summed over the TCC instances)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    agg = collections.defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        name = r['Kernel_Name'].split('(')[0]
+        agg[name][0] += float(r['Counter_Value'])
+        agg[name][1].add(r['Dispatch_Id'])
+    return {k: (v[0] / len(v[1]), len(v[1])) for k, v in agg.items()}
+
+
+fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+kern = {}
+for k in sorted(set(fetch) | set(write)):
+    if not any(t in k for t in ('conv_igemm', 'conv_wgrad', 'wgrad_reduce')):
+        continue
+    kern[k] = {'FETCH_SIZE_KB_per_launch': fetch.get(k, (None, 0))[0], 'WRITE_SIZE_KB_per_launch': write.get(k, (None, 0))[0],
+               'launches': fetch.get(k, write.get(k))[1]}
+M, C, T = 262144, 64, 27
+alg = (M * C * 4) * 2 + C * C * T * 4
+print(json.dumps({
+    'workload': 'tools/conv_micro.py: grouped stem conv2 (64->64, 3x3x3) over the 4 pyramid levels at B=32 x2 (M=262144 voxels), '
+                'forward+dgrad = conv_igemm_strip_kernel<128,64,2,32>, wgrad = conv_wgrad3_kernel + wgrad_reduce',
+    'algorithmic_bytes_per_launch': {'igemm (x + y + w)': alg, 'wgrad (x + gy + dw)': alg},
+    'notes': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md: TCC slots). Units KB. '
+             'WRITE_SIZE calibrates exactly on the known 64 MiB output of the forward; FETCH_SIZE may read low by up to 2x on '
+             'gfx950 for streaming reads (guide), so 2 x FETCH is the upper bound.',
+    'kernels': kern}, indent=1))
