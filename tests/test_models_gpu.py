@@ -415,6 +415,41 @@ def _make_cond(V=21):
     return gan, optD, optG, losses, Prm()
 
 
+def test_graph_replay_matches_eager_cond(golden):
+    """The text-conditioned iteration under HIP-graph replay (sentence codes in a fixed buffer, caption permutations among
+    the device-resident draws) reproduces the eager iteration: same seeds -> same losses, captured or replayed."""
+    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
+    tokens = T(golden('steps_cond')['tokens']).to(DEV)
+
+    def batches():
+        g = torch.Generator()
+        g.manual_seed(12)
+        return [(torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(4)]
+
+    def seed():
+        random.seed(6)
+        np.random.seed(6)
+        torch.manual_seed(6)
+    gan, optD, optG, losses, prm = _make_cond()
+    seed()
+    eager = []
+    for x in batches():
+        _, _, cond = gan.cond_encoder.encode(tokens, [8] * 4)
+        lD, lG, _, _ = train_iteration(gan, x, cond.detach(), optD, optG, losses, prm, DEV)
+        eager.append((float(lD), float(lG)))
+    gan, optD, optG, losses, prm = _make_cond()
+    seed()
+    gs = GraphedTrainStep(gan, optD, optG, losses, prm, DEV, (4, 1, 16, 64, 64), warmup=2, cond_dim=256)
+    for i, x in enumerate(batches()):
+        _, _, cond = gan.cond_encoder.encode(tokens, [8] * 4)
+        lD, lG = gs.step(x, cond)
+        got = (float(lD), float(lG))
+        print('cond step %d (%s): %s vs eager %s' % (i, 'replay' if i >= 2 else 'eager', got, eager[i]))
+        tol = 2e-5 if i < 2 else 2e-3
+        assert abs(got[0] - eager[i][0]) < tol and abs(got[1] - eager[i][1]) < tol, (i, got, eager[i])
+    assert gs.graphs is not None
+
+
 def test_train_steps_cond_vs_reference_golden(golden):
     """Text-conditioned path (Bi-LSTM cond, cat(z,cond), 2-D + 3-D non-local blocks, second D head,
     mismatched-caption loss, GP with interpolated captions): 3 free-running iterations vs the reference's

@@ -2178,9 +2178,19 @@ class HostDraws(object):
     def alpha(self, b, ndim, device):
         return torch.rand(b, *([1] * (ndim - 1))).reshape(b).to(device=device, dtype=torch.float32)
 
+    def perm(self, n, device):
+        """A non-identity permutation of range(n) from numpy's global RNG (util/misc.gen_perm), as a device int32 tensor."""
+        import numpy as _np
+        from .util.misc import gen_perm
+        return torch.from_numpy(_np.ascontiguousarray(gen_perm(n), dtype=_np.int32)).to(device)
+
 
 class StaticDraws(object):
-    def __init__(self, device, batch, latent, n_levels, n_gen_phases=3, gp=True, subsample_input=True):
+    def __init__(self, device, batch, latent, n_levels, n_gen_phases=3, gp=True, subsample_input=True, n_perms=0):
+        self.n_perms = n_perms                      # caption permutations per iteration (conditional path: D step, G step)
+        self.h_perm = torch.zeros(max(1, n_perms), batch, dtype=torch.int32).pin_memory()
+        self.d_perm = torch.zeros(max(1, n_perms), batch, dtype=torch.int32, device=device)
+        self._p = 0
         self.device, self.batch, self.latent = device, batch, latent
         self.n_levels, self.n_gen, self.gp, self.sub = n_levels, n_gen_phases, gp, subsample_input
         self.bs = [batch]
@@ -2211,10 +2221,15 @@ class StaticDraws(object):
             for b in self.bs:
                 self.h_a[off:off + b] = torch.rand(b, 1, 1, 1, 1).reshape(b)
                 off += b
+        if self.n_perms:
+            from .util.misc import gen_perm
+            for k in range(self.n_perms):
+                self.h_perm[k].copy_(torch.from_numpy(gen_perm(self.batch).astype('int32')))
+            self.d_perm.copy_(self.h_perm, non_blocking=True)
         self.d_int.copy_(self.h_int, non_blocking=True)
         self.d_z.copy_(self.h_z, non_blocking=True)
         self.d_a.copy_(self.h_a, non_blocking=True)
-        self._i = self._a = 0
+        self._i = self._a = self._p = 0
 
     def multiscale_t0(self, n):
         assert n == self.n_levels
@@ -2233,8 +2248,14 @@ class StaticDraws(object):
         self._a += b
         return self.d_a[off:off + b]
 
+    def perm(self, n, device):
+        assert n == self.batch and self._p < self.n_perms
+        k = self._p
+        self._p += 1
+        return self.d_perm[k]
+
     def rewind(self):
-        self._i = self._a = 0
+        self._i = self._a = self._p = 0
 
 
 draws = HostDraws()

@@ -5,7 +5,6 @@ import numpy as np
 import torch
 
 from .. import functional as TF
-from ..util.misc import gen_perm
 from .losses import gradient_penalty
 
 
@@ -122,7 +121,7 @@ class CondGan(object):
         if self.cond_encoder is not None:
             self.cond_encoder.zero_grad()
         if cond is not None:
-            gen_perm(cond[0].size(0))                 # the reference's all_discrim_forward draws a permutation here
+            TF.draws.perm(cond[0].size(0), cond[0].device)        # the reference's all_discrim_forward draws a permutation here
         losses = []
         n = len(fake)
         for name, discrim in zip(self.discrim_names, self.discrims):
@@ -179,8 +178,8 @@ class CondGan(object):
         for name, discrim in zip(self.discrim_names, self.discrims):
             real_cond, fake_cond = cond, None
             if cond is not None:
-                perm = gen_perm(real_cond[0].size(0))                     # numpy global RNG, like the reference
-                fc0 = TF.gather_rows(real_cond[0], perm)
+                perm = TF.draws.perm(real_cond[0].size(0), real_cond[0].device)      # numpy global RNG, like the reference
+                fc0 = TF.GatherRows.apply(real_cond[0], perm, False)
                 fake_cond = [TF.head_rows(fc0, r.size(0)) for r in real_cond]
             l, f, r = self.discrim_forward(name=name, discrim=discrim, real=real, real_cond=real_cond, fake=fake,
                                            fake_cond=fake_cond, loss=loss, gp_lambda=gp_lambda)

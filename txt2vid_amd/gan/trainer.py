@@ -25,6 +25,7 @@ def add_params_to_parser(parser):
     parser.add_argument('--loss_window_size', type=int, default=20)
     parser.add_argument('--no_mean_discrim_loss', action='store_false', default=True)
     parser.add_argument('--no_mean_gen_loss', action='store_false', default=True)
+    parser.add_argument('--no_graph', action='store_true', default=False, help='(new) eager launches instead of HIP-graph replay')
     parser.add_argument('--sample_batch_size', type=int, default=None)
     parser.add_argument('--discrim_steps', type=int, default=1)
     parser.add_argument('--gen_steps', type=int, default=1)
@@ -162,13 +163,16 @@ class GraphedTrainStep(object):
     on the host in the reference's order and uploaded into fixed buffers before the replay
     (`functional.StaticDraws`); the batch is copied into a fixed input buffer."""
 
-    def __init__(self, gan, optD, optG, losses, params, device, batch_shape, grad_sync=None, warmup=3):
+    def __init__(self, gan, optD, optG, losses, params, device, batch_shape, grad_sync=None, warmup=3, cond_dim=0):
         self.ts = TrainStep(gan, optD, optG, losses, params, device, False, grad_sync)
         self.device, self.grad_sync, self.warmup = device, grad_sync, warmup
         n_levels = len(params.frame_sizes)
         self.draws = TF.StaticDraws(device, batch_shape[0], gan.gen.latent_size, n_levels, n_gen_phases=n_levels - 1,
-                                    gp=params.gp_lambda > 0, subsample_input=params.subsample_input)
+                                    gp=params.gp_lambda > 0, subsample_input=params.subsample_input,
+                                    n_perms=2 * len(gan.discrims) if cond_dim else 0)
         self.x = torch.empty(batch_shape, device=device, dtype=torch.float32)
+        # conditional path: the sentence code is computed outside the graphs (its sequence length varies) into a fixed buffer
+        self.cond = torch.empty((batch_shape[0], cond_dim), device=device, dtype=torch.float32) if cond_dim else None
         self.graphs = None
         self.n = 0
         # warm-up and capture run on ONE side stream (the autograd graph's AccumulateGrad nodes remember
@@ -176,7 +180,7 @@ class GraphedTrainStep(object):
         self.side = torch.cuda.Stream(device=device)
 
     def _eager(self):
-        self.ts.run(self.x, None)
+        self.ts.run(self.x, self.cond)
 
     def _capture(self):
         for opt in (self.ts.optD, self.ts.optG):
@@ -188,7 +192,7 @@ class GraphedTrainStep(object):
         self.draws.rewind()
         gs = self.grad_sync
         with torch.cuda.graph(g1, stream=self.side):
-            self.ts.part_d(self.x, None)
+            self.ts.part_d(self.x, self.cond)
             if gs is not None:
                 gs.pre('D')                 # p.grad -> arena: captured (the replayed backward rewrites the same buffers)
         if gs is not None:
@@ -206,13 +210,15 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         self.graphs = (g1, g2, g3)
 
-    def step(self, x):
-        """x: [B,C,T,H,W] device (or pinned host) tensor. Returns (lossD, lossG) 0-d device tensors that are
-        overwritten by the next call."""
+    def step(self, x, cond=None):
+        """x: [B,C,T,H,W] device (or pinned host) tensor; cond: [B,cond_dim] sentence codes (conditional path). Returns
+        (lossD, lossG) 0-d device tensors that are overwritten by the next call."""
         old = TF.draws
         TF.set_draws(self.draws)
         try:
             self.x.copy_(x, non_blocking=True)
+            if self.cond is not None:
+                TF.copy_into(cond.detach(), self.cond)
             self.draws.begin_step()
             if self.graphs is None and self.n >= self.warmup:
                 self._capture()          # the capture pass also executes nothing: replay right after
@@ -280,6 +286,10 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
     load_watch, iter_watch = Stopwatch(), Stopwatch()
     from ..data import DevicePrefetcher
     iteration = 0
+    # HIP-graph replay of the iteration (3 graphs, see GraphedTrainStep) unless --no_graph / --end2end: the eager loop is
+    # host-bound (~1 000 launches at ~20 us of Python each)
+    use_graph = not end2end and not getattr(params, 'no_graph', False) and torch.device(device).type == 'cuda'
+    graphed, graphed_key = None, None
     for epoch in range(num_epoch):
         if params.log_period > 0:
             status('Epoch %d started' % (epoch + 1))
@@ -300,8 +310,17 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
                 _, _, cond = gan.cond_encoder.encode(y[0], y[1])
                 if not end2end:
                     cond = cond.detach()
-            lD, lG, fake, xs = train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=end2end,
-                                               grad_sync=grad_sync)
+            if use_graph:
+                key = (tuple(x.shape), None if cond is None else tuple(cond.shape))
+                if graphed is None or key != graphed_key:          # first batch (or a new batch shape): capture again
+                    graphed = GraphedTrainStep(gan, optD, optG, losses, params, device, tuple(x.shape), grad_sync=grad_sync,
+                                               warmup=2, cond_dim=0 if cond is None else cond.shape[1])
+                    graphed_key = key
+                lD, lG = graphed.step(x, cond)
+                fake, xs = graphed.ts.fake, graphed.ts.xs
+            else:
+                lD, lG, fake, xs = train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=end2end,
+                                                   grad_sync=grad_sync)
             discrim_loss.update(float(lD))
             gen_loss.update(float(lG))
             # checkpoint: the reference tests `save_example_period` here (trainer.py:269) and never reads

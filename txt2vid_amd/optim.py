@@ -21,6 +21,16 @@ class Adam(torch.optim.Optimizer):
             raise NotImplementedError('graph capture: one (beta1, beta2) per optimiser')
         self.step_dev = torch.tensor([float(max(steps) if steps else 0), 0.0, 0.0], device=device, dtype=torch.float32)
 
+    def state_dict(self):
+        """Same layout as torch.optim.Adam. Under graph replay the step counter advances on the device only: fold it back
+        into the per-parameter `step` entries first, so that a checkpoint resumes with the right bias corrections."""
+        if self.step_dev is not None:
+            n = int(self.step_dev[0].item())
+            for st in self.state.values():
+                if st:
+                    st['step'] = n
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, closure=None):
         if self.step_dev is not None:
@@ -58,6 +68,9 @@ class SGD(torch.optim.Optimizer):
             raise NotImplementedError('the reference only passes lr and momentum')
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=0, nesterov=False))
         self.grad_scale = 1.0
+
+    def make_capturable(self, device):
+        """Nothing step-dependent lives on the host once the momentum buffers exist (they do after the eager warm-up)."""
 
     @torch.no_grad()
     def step(self, closure=None):
