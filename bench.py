@@ -34,9 +34,13 @@ class Params(object):
     no_mean_discrim_loss = no_mean_gen_loss = True
 
 
-def build_models(dev, seed=100):
-    from txt2vid_amd.models.tganv2.gen import MultiScaleGen
-    from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+def build_models(dev, seed=100, cond=False):
+    if cond:
+        from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2_cond.discrim import MultiScaleDiscrim
+    else:
+        from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
     from txt2vid_amd.gan.cond_gan import CondGan
     from txt2vid_amd.gan.losses import MixedGanLoss, RSGANLoss
     from txt2vid_amd.optim import Adam
@@ -44,8 +48,9 @@ def build_models(dev, seed=100):
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
-    gen = MultiScaleGen(width=64, height=64, num_channels=1)
-    dis = MultiScaleDiscrim(num_channels=1)
+    kw = {'cond_dim': 256} if cond else {}
+    gen = MultiScaleGen(width=64, height=64, num_channels=1, **kw)
+    dis = MultiScaleDiscrim(num_channels=1, **kw)
     init(gen, 'xavier')
     init(dis, 'xavier')
     gen.to(dev).train()
@@ -135,6 +140,8 @@ def main():
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_d_roofline', action='store_true', help='skip the D forward+backward roofline pass')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay (eager launches)')
+    ap.add_argument('--cond', action='store_true', help='text-conditioned TGANv2 (BASELINE configs[2] shape, at fp32) instead of '
+                                                       'the unconditional configs[1] workload the metric is quoted on')
     args = ap.parse_args()
 
     from txt2vid_amd import dist as tdist
@@ -150,8 +157,17 @@ def main():
     dev = torch.device('cuda', local)
 
     T0 = time.perf_counter()
-    gen, dis, optD, optG, losses, CondGan = build_models(dev)
-    gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'], gp_scale=float(world))
+    gen, dis, optD, optG, losses, CondGan = build_models(dev, cond=args.cond)
+    txt = tokens = None
+    if args.cond:                    # Bi-LSTM sentence encoder (random init) + 8-token synthetic captions
+        from txt2vid_amd.data import Vocab
+        from txt2vid_amd.models.txt.basic import Seq2Seq
+        from txt2vid_amd.util.torch.init import init
+        txt = Seq2Seq(vocab_size=len(Vocab()))
+        init(txt, 'xavier')
+        txt.to(dev)
+        tokens = torch.randint(4, len(Vocab()), (args.batch, 8)).to(dev)
+    gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'], gp_scale=float(world))
     grad_sync = None
     if world > 1:
         arenas = {'D': tdist.GradArena(dis.parameters(), TF.copy_into), 'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
@@ -166,12 +182,18 @@ def main():
 
     graphed = None
     if not args.eager:
-        graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2)
+        graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2,
+                                   cond_dim=256 if args.cond else 0)
+
+    def sentence_codes():            # part of every iteration (outside the graphs: caption lengths vary in real data)
+        if txt is None:
+            return None
+        return txt.encode(tokens, [8] * args.batch)[2].detach()
 
     def step(i):
         if graphed is not None:
-            return graphed.step(pool[i % len(pool)]) + (None, None)
-        return train_iteration(gan, pool[i % len(pool)], None, optD, optG, losses, prm, dev, grad_sync=grad_sync)
+            return graphed.step(pool[i % len(pool)], sentence_codes()) + (None, None)
+        return train_iteration(gan, pool[i % len(pool)], sentence_codes(), optD, optG, losses, prm, dev, grad_sync=grad_sync)
 
     def log(msg):
         if rank == 0:
@@ -216,8 +238,14 @@ def main():
         torch.cuda.synchronize()
         lib().t2v_prof_begin(min(1 << 16, 4096 * prof_steps))
         t1 = time.perf_counter()
-        for i in range(prof_steps):
-            train_iteration(gan, pool[i % len(pool)], None, optD, optG, losses, prm, dev, grad_sync=grad_sync)
+        import contextlib
+        # (on the stream the graphs were captured on: the parameters' AccumulateGrad nodes remember it)
+        side = torch.cuda.stream(graphed.side) if graphed is not None else contextlib.nullcontext()
+        if graphed is not None:
+            graphed.side.wait_stream(torch.cuda.current_stream())
+        with side:
+            for i in range(prof_steps):
+                train_iteration(gan, pool[i % len(pool)], sentence_codes(), optD, optG, losses, prm, dev, grad_sync=grad_sync)
         torch.cuda.synchronize()
         prof_dt = time.perf_counter() - t1
         log('instrumented eager pass done: %.1f ms/step' % (prof_dt / prof_steps * 1e3))
@@ -252,7 +280,9 @@ def main():
         'value': gb * args.steps / dt, 'unit': 'videos/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'steps_per_sec': args.steps / dt, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: unconditional TGANv2 16x64x64x1, per-GPU batch %d, fp32, RSGAN + GP 0.5, '
+        'config': {'workload': ('BASELINE configs[2] shape at fp32 (bf16 tiles not built): text-conditioned TGANv2 (Bi-LSTM sentence codes, '
+                                '2-D + 3-D non-local blocks) ' if args.cond else 'BASELINE configs[1]: unconditional TGANv2 ') +
+                               '16x64x64x1, per-GPU batch %d, fp32, RSGAN + GP 0.5, '
                                'Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid 8/16/32/64' % args.batch,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
                    'as_written_tflop_per_step': GFLOP_PER_SAMPLE_AS_WRITTEN * gb / 1e3},
@@ -266,7 +296,7 @@ def main():
         from txt2vid_amd.util.roofline import d_fwdbwd_roofline
         log('D forward+backward roofline pass')
         res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond:
         log('timing the CPU oracle on %d host threads' % host_threads())
         res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:
