@@ -87,19 +87,7 @@ def pmc_traffic():
     return None, None
 
 
-def host_threads():
-    """Cores this process may actually run on (cgroup / affinity aware), not the machine's logical CPU count."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:                                      # cgroup v2 quota, e.g. "1600000 100000" = 16 cores
-        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
-        if q != 'max':
-            n = min(n, max(1, int(int(q) / int(per))))
-    except Exception:
-        pass
-    return max(1, min(n, 64))
+from txt2vid_amd.util.misc import host_threads          # noqa: E402  (cgroup-aware core count)
 
 
 def cpu_baseline(threads, budget_s=45.0):
@@ -150,6 +138,8 @@ def main():
     import torch.distributed as dist
 
     rank, world = tdist.init_from_env('nccl')
+    from txt2vid_amd.util.misc import limit_host_threads
+    limit_host_threads()                 # the default CPU pool (one spinning thread per logical CPU) starves the HIP runtime
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     local = tdist.local_device_index()

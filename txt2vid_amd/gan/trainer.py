@@ -191,21 +191,24 @@ class GraphedTrainStep(object):
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.draws.rewind()
         gs = self.grad_sync
-        with torch.cuda.graph(g1, stream=self.side):
+        # thread-local capture mode: the data loader's pin-memory thread keeps issuing pinned allocations and H2D copies
+        # while this thread captures; in the default (global) mode any such call invalidates the capture
+        mode = 'thread_local'
+        with torch.cuda.graph(g1, stream=self.side, capture_error_mode=mode):
             self.ts.part_d(self.x, self.cond)
             if gs is not None:
                 gs.pre('D')                 # p.grad -> arena: captured (the replayed backward rewrites the same buffers)
         if gs is not None:
             gs.exchange('D')
             gs.post('D')                    # Adam (captured next) reads the arena views
-        with torch.cuda.graph(g2, pool=g1.pool(), stream=self.side):
+        with torch.cuda.graph(g2, pool=g1.pool(), stream=self.side, capture_error_mode=mode):
             self.ts.part_g()
             if gs is not None:
                 gs.pre('G')
         if gs is not None:
             gs.exchange('G')
             gs.post('G')
-        with torch.cuda.graph(g3, pool=g1.pool(), stream=self.side):
+        with torch.cuda.graph(g3, pool=g1.pool(), stream=self.side, capture_error_mode=mode):
             self.ts.part_end()
         torch.cuda.synchronize()
         self.graphs = (g1, g2, g3)
@@ -289,7 +292,7 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
     # HIP-graph replay of the iteration (3 graphs, see GraphedTrainStep) unless --no_graph / --end2end: the eager loop is
     # host-bound (~1 000 launches at ~20 us of Python each)
     use_graph = not end2end and not getattr(params, 'no_graph', False) and torch.device(device).type == 'cuda'
-    graphed, graphed_key = None, None
+    graphed, graphed_key, pending, loss_ring = None, None, None, None
     for epoch in range(num_epoch):
         if params.log_period > 0:
             status('Epoch %d started' % (epoch + 1))
@@ -316,13 +319,30 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
                     graphed = GraphedTrainStep(gan, optD, optG, losses, params, device, tuple(x.shape), grad_sync=grad_sync,
                                                warmup=2, cond_dim=0 if cond is None else cond.shape[1])
                     graphed_key = key
+                    if params.log_period > 0:
+                        status('HIP-graph replay of the iteration for batches of shape %s (2 eager iterations, then capture)' % (key[0],))
                 lD, lG = graphed.step(x, cond)
                 fake, xs = graphed.ts.fake, graphed.ts.xs
+                # Read the losses ONE iteration late, through a pinned buffer and an event: the host goes on to prepare
+                # and launch the next iteration while this one runs (the replay overwrites its loss scalars, hence the
+                # copies). The rolling averages lag by one iteration.
+                if loss_ring is None:
+                    loss_ring = [(torch.empty(2, device=lD.device), torch.empty(2).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+                dbuf, hbuf, ev = loss_ring[iteration & 1]
+                TF.copy_into(lD.reshape(1), dbuf[0:1])
+                TF.copy_into(lG.reshape(1), dbuf[1:2])
+                hbuf.copy_(dbuf, non_blocking=True)
+                ev.record()
+                if pending is not None:
+                    pending[1].synchronize()
+                    discrim_loss.update(float(pending[0][0]))
+                    gen_loss.update(float(pending[0][1]))
+                pending = (hbuf, ev)
             else:
                 lD, lG, fake, xs = train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=end2end,
                                                    grad_sync=grad_sync)
-            discrim_loss.update(float(lD))
-            gen_loss.update(float(lG))
+                discrim_loss.update(float(lD))
+                gen_loss.update(float(lG))
             # checkpoint: the reference tests `save_example_period` here (trainer.py:269) and never reads
             # --save_model_period; the intended flag is used (SURVEY §8a defect 3).
             if (iteration == 1 and params.save_initial) or (params.save_model_period > 0 and

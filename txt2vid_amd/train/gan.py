@@ -21,17 +21,23 @@ from ..util.torch.init import init
 from .setup import setup
 
 
-def _model(spec, args, **kw):
+def _model(spec, args, kind='D', **kw):
     """`create_object(spec, cond_dim=...)` like the reference; convenience: a bare class name also gets
-    `num_channels=--num_channels` (the reference needs a JSON spec for anything but its 3-channel default)."""
+    `num_channels=--num_channels`, and a bare generator class `width = height = --frame_sizes[-1]` (the reference needs a
+    JSON spec for anything but its 3-channel / 128x128 defaults)."""
     if isinstance(spec, str) and not os.path.exists(spec):
         kw.setdefault('num_channels', args.num_channels)
+        if kind == 'G':                       # the reference's default generator is 128x128 whatever --frame_sizes says
+            kw.setdefault('width', args.frame_sizes[-1])
+            kw.setdefault('height', args.frame_sizes[-1])
     return create_object(spec, **kw)
 
 
 def main(args):
     from .. import dist as tdist
     rank, world = tdist.init_from_env('nccl')
+    from ..util.misc import limit_host_threads
+    limit_host_threads()                 # an oversubscribed CPU thread pool starves the HIP runtime's submission thread
     seed, device = setup(args)
     status('%d cuda devices available; rank %d of %d' % (torch.cuda.device_count(), rank, world))
     vocab = load(args.vocab) if args.vocab else data.Vocab()
@@ -46,7 +52,7 @@ def main(args):
             txt_encoder = create_object(args.sent, vocab_size=len(vocab)).to(device)
             init(txt_encoder, init_method=args.sent_init_method or args.init_method)
     cond_dim = txt_encoder.encoder.encoding_size if txt_encoder is not None else 0
-    gen = _model(args.G, args, cond_dim=cond_dim)
+    gen = _model(args.G, args, kind='G', cond_dim=cond_dim)
     discrims = [_model(d, args, cond_dim=cond_dim) for d in args.D]
     init(gen, init_method=args.init_method)
     for d in discrims:
