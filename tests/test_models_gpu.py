@@ -525,3 +525,45 @@ def test_sentence_encoder_matches_packed_nn_lstm(bi):
     np.testing.assert_allclose(c.cpu().numpy(), ref_c.numpy(), rtol=1e-4, atol=2e-6)
     want = torch.cat((ref_h[-2], ref_h[-1]), 1) if bi else ref_h.view(3, 1, B, -1)[-1]      # basic.py:58-64 (keeps the 1)
     np.testing.assert_allclose(hn.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('channels,batch,frame_sizes,size', [(3, 2, [8, 16, 32, 64], 64), (1, 3, [8, 16, 32, 64], 64), (1, 2, [16, 32, 64, 128], 128)])
+def test_iteration_vs_oracle_other_shapes(channels, batch, frame_sizes, size):
+    """One full training iteration against the CPU oracle (identical weights / batch / draws) away from the benchmark shape:
+    RGB clips (the reference's default `num_channels=3`: Cin = 3 stem, Cout = 3 render convs, 3-channel stem gradient),
+    an odd batch (ragged sub-sampled pyramid: 3 -> 2 -> 1 -> 1 clips), and 128x128 frames (`run_tganv2.sh`'s
+    `--frame_sizes 16 32 64 128`, 2x2 ConvLSTM state)."""
+    from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+    from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+    from txt2vid_amd.gan.cond_gan import CondGan
+    from txt2vid_amd.gan.losses import MixedGanLoss, RSGANLoss
+    from txt2vid_amd.gan.trainer import train_iteration
+    from txt2vid_amd.optim import Adam
+    gen = MultiScaleGen(width=size, height=size, num_channels=channels)
+    dis = MultiScaleDiscrim(num_channels=channels)
+    for m in (gen, dis):
+        m.load_state_dict({k: O.recipe_tensor(k, v.shape) for k, v in m.state_dict().items()})
+        m.to(DEV).train()
+    gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'])
+    losses = MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss())
+    optD = Adam([{'params': dis.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = Adam([{'params': gen.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+
+    class Prm(object):
+        subsample_input = True
+        discrim_steps = gen_steps = 1
+        gp_lambda = 0.5
+        no_mean_discrim_loss = no_mean_gen_loss = True
+    Prm.frame_sizes = frame_sizes
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=channels, width=size, height=size)),
+                         O.recipe_state(O.resnet3d_shapes('single_discrim.', channels, 64, 0)), frame_sizes=frame_sizes)
+    random.seed(4)
+    np.random.seed(4)
+    torch.manual_seed(4)
+    x = (torch.rand(batch, 16, channels, size, size) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+    st = torch.get_rng_state()
+    lD, lG, _, _ = train_iteration(gan, x.to(DEV), None, optD, optG, losses, Prm(), DEV)
+    torch.set_rng_state(st)
+    lDo, lGo = tr.step(x)
+    print('C=%d B=%d %dx%d: HIP lossD %.6f lossG %.6f | oracle %.6f %.6f' % (channels, batch, size, size, float(lD), float(lG), lDo, lGo))
+    assert abs(float(lD) - lDo) < 1e-3 and abs(float(lG) - lGo) < 1e-3
