@@ -160,7 +160,7 @@ def main():
     gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'], gp_scale=float(world))
     grad_sync = None
     if world > 1:
-        arenas = {'D': tdist.GradArena(dis.parameters(), TF.copy_into), 'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
+        arenas = {'D': tdist.model_arena(dis, TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
         grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
     prm = Params()
     pool = synthetic_batches(args.batch, 4, 100 + rank, dev)
@@ -279,6 +279,8 @@ def main():
         'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (3 graphs/step)',
         'as_written_tflops': GFLOP_PER_SAMPLE_AS_WRITTEN * gb * args.steps / dt / 1e3,
     }
+    if grad_sync is not None:
+        res['config']['grad_exchange_mb_per_step'] = sum(a.exchanged_bytes() for a in grad_sync.arenas.values()) / 1e6
     if roof is not None:
         res['roofline'] = roof
     if rank == 0 and world == 1 and prof and not args.no_d_roofline:

@@ -41,6 +41,47 @@ def _arena_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _sparse_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from txt2vid_amd import dist as tdist
+    tdist.init_from_env('gloo')
+    w = torch.nn.Parameter(torch.zeros(4, 3, 3, 3))               # conv weight whose gradient only lives in taps 4 and 7
+    b = torch.nn.Parameter(torch.zeros(5))
+    g = torch.zeros(4, 3, 9)
+    g[:, :, 4] = rank + 1.0
+    g[:, :, 7] = 10.0 * (rank + 1)
+    w.grad = g.view(4, 3, 3, 3).clone()
+    b.grad = torch.arange(5.0) + rank
+    arena = tdist.GradArena([w, b], live_taps={w: [4, 7]})
+
+    class Opt(object):
+        grad_scale = 1.0
+    sync = tdist.make_grad_sync({'G': arena}, {'G': Opt()}, world)
+    sync('G')
+    q.put((rank, w.grad.clone(), b.grad.clone(), arena.exchanged_bytes(), [p is w for p in arena.params]))
+    dist.destroy_process_group()
+
+
+def test_structurally_sparse_taps_exchange_world2():
+    """Only the live taps of a structurally sparse weight gradient travel (ConvLSTM on a 1x1 map): same result as the dense
+    exchange, a fraction of the bytes; dense parameters come first in the arena."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = torch.zeros(4, 3, 9)
+    want[:, :, 4], want[:, :, 7] = 3.0, 30.0
+    for rank, gw, gb, nbytes, order in res:
+        assert torch.equal(gw.view(4, 3, 9), want) and torch.equal(gb, torch.arange(5.0) * 2 + 1)
+        assert nbytes == 4 * (5 + 4 * 3 * 2) and order == [False, True]
+
+
 def test_grad_arena_allreduce_world2():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -30,7 +30,7 @@ def run(sync):
     gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'], gp_scale=float(world if sync else 1))
     gs = None
     if sync:
-        arenas = {'D': tdist.GradArena(dis.parameters(), TF.copy_into), 'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
+        arenas = {'D': tdist.model_arena(dis, TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
         gs = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
     pool = bench.synthetic_batches(B, 2, 100 + rank, dev)                       # different data per rank
     random.seed(100 + rank)

@@ -38,18 +38,40 @@ def local_device_index():
 
 
 class GradArena(object):
-    """Flat gradient buffer of one model + the per-step exchange."""
+    """Flat gradient buffer of one model + the per-step exchange.
 
-    def __init__(self, params, copy_fn=None):
-        self.params = [p for p in params if p.requires_grad]
+    `live_taps` (optional): {parameter: [tap indices]} for convolution weights whose gradient is structurally zero outside
+    those kernel taps — the generator's ConvLSTM runs 3x3 kernels on a 1x1 feature map, so only the centre tap of its eight
+    [1024,1024,3,3] weights (302 of G's 345 MB) ever receives a gradient. Such parameters sit at the end of the arena and
+    only their live taps, packed into a compact buffer, take part in the all-reduce."""
+
+    def __init__(self, params, copy_fn=None, live_taps=None):
+        params = [p for p in params if p.requires_grad]
+        live_taps = live_taps or {}
+        sparse_ids = {id(p) for p in live_taps}
+        dense = [p for p in params if id(p) not in sparse_ids]
+        sparse = [p for p in params if id(p) in sparse_ids]
+        self.params = dense + sparse
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
             n += p.numel()
         self.numel = n
+        self.numel_dense = sum(p.numel() for p in dense)
         p0 = self.params[0]
         self.flat = torch.zeros(n, device=p0.device, dtype=p0.dtype)
         self.copy_fn = copy_fn
+        self.sparse = []                       # (offset in flat, rows = Cout*Cin, taps per row T, live tap list, offset in compact)
+        m = 0
+        for p in sparse:
+            taps = [int(t) for t in live_taps[p]]
+            T = 1
+            for d in p.shape[2:]:
+                T *= int(d)
+            rows = p.numel() // T
+            self.sparse.append((self.offsets[len(dense) + len(self.sparse)], rows, T, taps, m))
+            m += rows * len(taps)
+        self.compact = torch.zeros(m, device=p0.device, dtype=p0.dtype) if m else None
 
     def views(self):
         return [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
@@ -66,14 +88,55 @@ class GradArena(object):
             else:
                 v.copy_(p.grad)
 
+    def _taps(self, pack):
+        """live taps: arena -> compact (pack) or compact -> arena (unpack); strided column copies."""
+        for off, rows, T, taps, coff in self.sparse:
+            src = self.flat[off:off + rows * T].view(rows, T)
+            dst = self.compact[coff:coff + rows * len(taps)].view(rows, len(taps))
+            for j, t in enumerate(taps):
+                if self.flat.is_cuda:
+                    from . import functional as TF
+                    if pack:
+                        TF._copy2d(self.flat, off + t, T, self.compact, coff + j, len(taps), rows, 1)
+                    else:
+                        TF._copy2d(self.compact, coff + j, len(taps), self.flat, off + t, T, rows, 1)
+                elif pack:
+                    dst[:, j].copy_(src[:, t])
+                else:
+                    src[:, t].copy_(dst[:, j])
+
     def all_reduce(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if not self.sparse:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            return
+        if self.numel_dense:
+            dist.all_reduce(self.flat[:self.numel_dense], op=dist.ReduceOp.SUM)
+        self._taps(True)
+        dist.all_reduce(self.compact, op=dist.ReduceOp.SUM)
+        self._taps(False)
+
+    def exchanged_bytes(self):
+        return 4 * (self.numel_dense + (self.compact.numel() if self.compact is not None else 0))
 
     def scatter_as_grads(self):
         """Point every p.grad at its (reduced) arena slice; the optimiser applies `1/world` itself."""
         for v, p in zip(self.views(), self.params):
             p.grad = v
+
+
+def model_arena(modules, copy_fn=None):
+    """GradArena over the parameters of one module (or a list of modules); modules that know which kernel taps of their
+    convolution weights can ever receive a gradient (`structurally_live_taps()`) have only those exchanged."""
+    if not isinstance(modules, (list, tuple)):
+        modules = [modules]
+    params, live = [], {}
+    for m in modules:
+        params += list(m.parameters())
+        if hasattr(m, 'structurally_live_taps'):
+            live.update(m.structurally_live_taps())
+    return GradArena(params, copy_fn, live_taps=live)
 
 
 class GradSync(object):

@@ -95,10 +95,9 @@ class TrainStep(object):
         if not end2end and torch.device(device).type == 'cuda':
             cached = gan.__dict__.get('_t2v_grad_sink')
             if cached is None or cached[0] is not grad_sync:
-                from ..dist import GradArena
+                from ..dist import model_arena
                 arenas = list(grad_sync.arenas.values()) if grad_sync is not None else [
-                    GradArena([q for d in gan.discrims for q in d.parameters()], TF.copy_into),
-                    GradArena(gan.gen.parameters(), TF.copy_into)]
+                    model_arena(list(gan.discrims), TF.copy_into), model_arena(gan.gen, TF.copy_into)]
                 cached = (grad_sync, TF.GradSink(arenas))
                 gan.__dict__['_t2v_grad_sink'] = cached          # one pair of arenas per model, reused by every step
             self.grad_sink = cached[1]

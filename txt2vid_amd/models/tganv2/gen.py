@@ -51,6 +51,17 @@ class MultiScaleGen(nn.Module):
         self.abstract_blocks = nn.ModuleList(self.abstract_blocks)
         self.render_blocks = nn.ModuleList(self.render_blocks)
 
+    def structurally_live_taps(self):
+        """{weight: live kernel taps} for the ConvLSTM when its state is 1x1 (frames below 128x128): a 3x3 kernel on a 1x1
+        map only ever multiplies — and only ever receives a gradient through — its centre tap. Used by `dist.model_arena`:
+        8 x [1024,1024,3,3] weights = 302 MB of gradients of which 33.5 MB can be non-zero."""
+        if self.fm_width != 1 or self.fm_height != 1:
+            return {}
+        cell = self.clstm.cell0
+        k = cell.kernel_size
+        centre = (k // 2) * k + k // 2
+        return {m.weight: [centre] for m in (cell.Wxi, cell.Wxf, cell.Wxc, cell.Wxo, cell.Whi, cell.Whf, cell.Whc, cell.Who)}
+
     def forward(self, x, cond=None, return_abstract_maps=False, output_blocks=None):
         from ... import functional as TF
         if cond is not None:

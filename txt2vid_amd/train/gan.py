@@ -94,8 +94,7 @@ def main(args):
     grad_sync = None
     if world > 1:
         from .. import functional as TF
-        arenas = {'D': tdist.GradArena([p for d in discrims for p in d.parameters()], TF.copy_into),
-                  'G': tdist.GradArena(gen.parameters(), TF.copy_into)}
+        arenas = {'D': tdist.model_arena(list(discrims), TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
         grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
     if args.test:
         test(gan=gan, num_samples=args.num_samples, dataset=dataset, device=device, params=args,
