@@ -128,6 +128,8 @@ def main():
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_d_roofline', action='store_true', help='skip the D forward+backward roofline pass')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay (eager launches)')
+    ap.add_argument('--bf16', action='store_true', help='bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA, fp32 storage and '
+                                                       'accumulation): an extra, NOT the precision the metric is quoted on')
     ap.add_argument('--cond', action='store_true', help='text-conditioned TGANv2 (BASELINE configs[2] shape, at fp32) instead of '
                                                        'the unconditional configs[1] workload the metric is quoted on')
     args = ap.parse_args()
@@ -137,6 +139,9 @@ def main():
     from txt2vid_amd._lib import lib
     import torch.distributed as dist
 
+    if args.bf16:
+        TF.set_conv_precision('bf16')
+    bf16 = TF.CONV_PRECISION == 'bf16'
     rank, world = tdist.init_from_env('nccl')
     from txt2vid_amd.util.misc import limit_host_threads
     limit_host_threads()                 # the default CPU pool (one spinning thread per logical CPU) starves the HIP runtime
@@ -269,7 +274,9 @@ def main():
         'metric': 'TGANv2 GAN train throughput (G+D steps x global batch), 16x64x64 videos/sec',
         'value': gb * args.steps / dt, 'unit': 'videos/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'steps_per_sec': args.steps / dt, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16 compute (forward / data-gradient MFMA), f32 storage + accumulation + weight gradient' if bf16 else 'f32',
+        'data': 'synthetic',
         'config': {'workload': ('BASELINE configs[2] shape at fp32 (bf16 tiles not built): text-conditioned TGANv2 (Bi-LSTM sentence codes, '
                                 '2-D + 3-D non-local blocks) ' if args.cond else 'BASELINE configs[1]: unconditional TGANv2 ') +
                                '16x64x64x1, per-GPU batch %d, fp32, RSGAN + GP 0.5, '

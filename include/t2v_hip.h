@@ -125,6 +125,16 @@ int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group* groups, in
 int t2v_conv_wgrad_grouped_bias(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                                 float* dw, float* dbias, float* slab, int flags, void* stream);
 
+/* ---- bf16 compute / fp32 storage (BASELINE configs 2-4: "bf16 compute / fp32 master") -------------------------------
+ * Forward / data gradient with the tiles rounded to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16
+ * (fp32 accumulation, fp32 tensors in HBM). wpb: bf16 [ntaps][rows][K] from t2v_pack_weight_bf16 (mode 0: rows = Cout,
+ * K = Cin; mode 1: rows = Cin, K = Cout, mirrored taps). t2v_conv_fwd_grouped_bf16_ok() says whether the bf16 kernel takes a
+ * shape (Cin % 32 == 0, Cout > 4); otherwise use the fp32 entry point. Workspace: t2v_conv_fwd_grouped_ws_floats(). */
+int t2v_pack_weight_bf16(const float* w, void* wpb, int Cout, int Cin, int T, const int32_t* taps, int ntaps, int mode, void* stream);
+int t2v_conv_fwd_grouped_bf16_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout);
+int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const void* wpb, const float* bias,
+                              float* ws, int flags, void* stream);
+
 /* out[c] = sum_{n,s} x[n,c,s]  (bias gradient; also BatchNorm reductions).  accum: out += */
 int64_t t2v_channel_sum_ws_floats(int N, int C, int64_t S);   /* floats of `ws` needed (0: none) */
 int t2v_channel_sum(const float* x, float* out, float* ws, int N, int C, int64_t S, int accum, void* stream);

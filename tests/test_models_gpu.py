@@ -567,3 +567,28 @@ def test_iteration_vs_oracle_other_shapes(channels, batch, frame_sizes, size):
     lDo, lGo = tr.step(x)
     print('C=%d B=%d %dx%d: HIP lossD %.6f lossG %.6f | oracle %.6f %.6f' % (channels, batch, size, size, float(lD), float(lG), lDo, lGo))
     assert abs(float(lD) - lDo) < 1e-3 and abs(float(lG) - lGo) < 1e-3
+
+
+def test_iteration_bf16_compute_mode_vs_oracle():
+    """bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA; BASELINE configs 2-4 "bf16 compute / fp32 master"): one
+    full iteration against the fp32 CPU oracle. bf16 operands carry 8 mantissa bits, so this is a LOOSER, separately stated
+    bound: |dlossD| < 2e-2, |dlossG| < 5e-2 (fp32 mode: 1e-3)."""
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.gan.trainer import train_iteration
+    gan, optD, optG, losses, prm = _make_uncond()
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1)), O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0)))
+    random.seed(9)
+    np.random.seed(9)
+    torch.manual_seed(9)
+    x = (torch.rand(4, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+    st = torch.get_rng_state()
+    old = TF.set_conv_precision('bf16')
+    try:
+        lD, lG, _, _ = train_iteration(gan, x.to(DEV), None, optD, optG, losses, prm, DEV)
+        lD, lG = float(lD), float(lG)
+    finally:
+        TF.set_conv_precision(old)
+    torch.set_rng_state(st)
+    lDo, lGo = tr.step(x)
+    print('bf16 compute: HIP lossD %.6f lossG %.6f | fp32 oracle %.6f %.6f' % (lD, lG, lDo, lGo))
+    assert abs(lD - lDo) < 2e-2 and abs(lG - lGo) < 5e-2

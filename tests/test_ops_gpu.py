@@ -183,6 +183,41 @@ def test_conv_multi_group_accumulates_data_gradients_in_kernel():
             close(a_, r_.float(), rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize('shapes,cin,cout,k', [
+    ([(2, 64, 4, 8, 8)], 64, 96, (3, 3, 3)),
+    ([(4, 64, 2, 16, 16), (2, 64, 4, 8, 8), (3, 64, 1, 1, 1)], 64, 64, (3, 3, 3)),        # grouped, one 1x1x1 member
+    ([(2, 128, 1, 16, 16)], 128, 40, (1, 3, 3)),                                           # 2-D, Cout not a tile multiple
+    ([(8, 32, 8, 32, 32)], 32, 128, (1, 1, 1)),                                            # big M: 128-voxel tiles
+    ([(3, 256, 1, 2, 2)], 256, 512, (1, 3, 3)),                                            # tiny M, long K: split-K
+])
+def test_bf16_compute_convolution(shapes, cin, cout, k):
+    """bf16-compute mode (`T2V_CONV_PRECISION=bf16` / `set_conv_precision('bf16')`, BASELINE configs 2-4): forward (+bias, fused
+    input ReLU) and data gradient (+ masked epilogue) equal the EXACT convolution of the bf16-rounded operands (fp32
+    accumulation) and stay within bf16 rounding of the fp32 result."""
+    from txt2vid_amd import functional as TF
+    xs = [rnd(300 + i, *sh) for i, sh in enumerate(shapes)]
+    w, b = rnd(310, cout, cin, *k) * 0.1, rnd(311, cout) * 0.1
+    pad = tuple(kk // 2 for kk in k)
+    r16 = lambda t: t.bfloat16().double()
+    old = TF.set_conv_precision('bf16')
+    try:
+        wd = torch.nn.Parameter(w.to(dev()))
+        ys = TF.conv_group_raw([x.to(dev()) for x in xs], wd, b.to(dev()), True, 0)
+        gys = [rnd(320 + i, *y.shape) for i, y in enumerate(ys)]
+        masks = [rnd(330 + i, *x.shape) for i, x in enumerate(xs)]
+        gxs = TF.conv_group_raw([g.to(dev()) for g in gys], wd, None, False, 1, masks=[m.to(dev()) for m in masks])
+    finally:
+        TF.set_conv_precision(old)
+    for x, y, g, m, gx in zip(xs, ys, gys, masks, gxs):
+        exact = F.conv3d(r16(F.relu(x)), r16(w), b.double(), padding=pad)
+        close(y, exact.float(), rtol=2e-5, atol=2e-5)
+        full = F.conv3d(F.relu(x).double(), w.double(), b.double(), padding=pad)
+        assert float((y.cpu().double() - full).abs().max()) <= 2e-2 * float(full.abs().max())
+        rg = r16 if cout % 32 == 0 else (lambda t: t.double())       # K = Cout of the data gradient: not a multiple of 32 -> fp32 kernel
+        exact_g = F.conv_transpose3d(rg(g), rg(w), padding=pad) * (m > 0).double()
+        close(gx, exact_g.float(), rtol=2e-5, atol=2e-5)
+
+
 def test_avgpool():
     from txt2vid_amd import functional as TF
     for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),

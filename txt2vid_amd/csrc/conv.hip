@@ -769,6 +769,176 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-compute variant of the implicit GEMM ("bf16 compute / fp32 master", BASELINE configs 2-4): activations and
+// results stay fp32 in HBM; the tiles are rounded to bf16 on their way into LDS and multiplied by
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate) with fp32 accumulation. Weights come pre-packed as bf16
+// wpb[slot][Cout][Cin] (K contiguous). LDS tiles are [row][k] with k contiguous (one ds_read_b128 = the 8 k of a lane's
+// fragment); same workgroup tile, grouping, split-K and epilogue as conv_igemm_kernel. Cin % 32 == 0 only.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define B16_KP 40      // LDS row pitch in bf16: 32 k + 8 pad (80 B: 16-byte aligned rows, 2-way at worst on b128 reads)
+
+template <int BM>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const GroupTable tab, const __bf16* __restrict__ wpb,
+                                                              const float* __restrict__ bias, float* __restrict__ slab,
+                                                              const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr int BN = 64, BKT = 32, WAVES_CO = 2;
+    constexpr int WAVES_M = 2;
+    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int KPT = BKT * BM / 256;          // k values per thread of the activation tile (16 for BM = 128, 8 for 64)
+    constexpr int KQ = BKT / KPT;                // threads per voxel
+    static_assert(NCO == 1 && NM >= 1 && (KPT == 16 || KPT == 8), "tile");
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[2 * BM * B16_KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2 * BN * B16_KP];
+    __shared__ int s_off[T2V_MAX_TAPS];
+    __shared__ int s_widx[T2V_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const float* __restrict__ x = gd.x;
+    const int D = gd.D, H = gd.H, W = gd.W;
+    const int HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    if (tid < ntaps) {
+        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        s_widx[tid] = gd.widx[tid];
+    }
+    // activation staging: thread -> (voxel, group of KPT consecutive channels)
+    const int ma_l = tid % BM, kq = tid / BM;
+    const int m_a = m0 + ma_l;
+    uint32_t tapmask = 0;
+    size_t xbase = 0;
+    if (m_a < M) {
+        const int n = m_a / DHW, sp = m_a - n * DHW;
+        const int d = sp / HW, r = sp - d * HW;
+        const int h = r / W, w_ = r - h * W;
+        xbase = (size_t)n * Cin * DHW + sp;
+        for (int t = 0; t < ntaps; ++t) {
+            const int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
+            if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) tapmask |= 1u << t;
+        }
+    }
+    // weight staging: thread -> (output channel, 8 consecutive k)
+    const int wc_l = tid >> 2, wk_l = (tid & 3) * 8;
+    const bool w_ok = co0 + wc_l < Cout;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+
+    f32x16 acc[NCO][NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    float ra[KPT];
+    bf16x8 rw;
+    bool pend_v = false;
+    const int cpt = Cin / BKT;
+    const int nchunks = ntaps * cpt;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * cps;
+    int q1 = q0 + cps;
+    if (q1 > nchunks) q1 = nchunks;
+    __syncthreads();
+
+    int t_cur = q0 / cpt, c_cur = (q0 - t_cur * cpt) * BKT;
+    auto advance = [&]() {
+        c_cur += BKT;
+        if (c_cur >= Cin) { c_cur = 0; ++t_cur; }
+    };
+    auto load_chunk = [&]() {
+        pend_v = (tapmask >> t_cur) & 1u;
+        const float* px = x + xbase + (pend_v ? (ptrdiff_t)s_off[t_cur] : 0) + (size_t)(c_cur + kq * KPT) * DHW;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) ra[j] = px[(size_t)j * DHW];
+        const __bf16* pw = wpb + ((size_t)s_widx[t_cur] * Cout + (w_ok ? co0 + wc_l : 0)) * Cin + c_cur + wk_l;
+        rw = *reinterpret_cast<const bf16x8*>(pw);
+    };
+    auto stage = [&](int b) {
+        __bf16* xs = Xs + b * (BM * B16_KP) + ma_l * B16_KP + kq * KPT;
+#pragma unroll
+        for (int g = 0; g < KPT / 8; ++g) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = pend_v ? ra[g * 8 + j] : 0.f;
+                if (relu_in) f = fmaxf(f, 0.f);
+                v[j] = (__bf16)f;
+            }
+            *reinterpret_cast<bf16x8*>(xs + g * 8) = v;
+        }
+        bf16x8 wv = rw;
+        if (!w_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(Ws + b * (BN * B16_KP) + wc_l * B16_KP + wk_l) = wv;
+    };
+
+    int cur = 0;
+    if (q0 < q1) {
+        load_chunk();
+        stage(0);
+        __syncthreads();
+        if (q0 + 1 < q1) { advance(); load_chunk(); }
+    }
+    for (int q = q0; q < q1; ++q) {
+        const __bf16* xs = Xs + cur * (BM * B16_KP) + (wm * WM + l31) * B16_KP + 8 * hi;
+        const __bf16* ws = Ws + cur * (BN * B16_KP) + (wco * WCO + l31) * B16_KP + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + j * 32 * B16_KP + ks * 16);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0);
+            }
+        }
+        if (q + 1 < q1) stage(cur ^ 1);
+        __syncthreads();
+        if (q + 2 < q1) { advance(); load_chunk(); }
+        cur ^= 1;
+    }
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+}
+
+// w[Cout][Cin][T] fp32 -> bf16 wpb[j][rows][K] with K contiguous: mode 0 rows = co, K = ci (forward);
+// mode 1 rows = ci, K = co, mirrored taps (data gradient)
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wpb, int Cout, int Cin, int T,
+                                        TapList taps, int mode) {
+    const int j = blockIdx.y;
+    const int t = mode ? (T - 1 - taps.t[j]) : taps.t[j];
+    const long n = (long)Cout * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int row, k;
+        if (mode == 0) { row = (int)(i / Cin); k = (int)(i - (long)row * Cin); wpb[(size_t)j * n + i] = (__bf16)w[((size_t)row * Cin + k) * T + t]; }
+        else { row = (int)(i / Cout); k = (int)(i - (long)row * Cout); wpb[(size_t)j * n + i] = (__bf16)w[((size_t)k * Cin + row) * T + t]; }
+    }
+}
+extern "C" int t2v_pack_weight_bf16(const float* w, void* wpb, int Cout, int Cin, int T, const int32_t* taps, int ntaps, int mode,
+                                    void* stream) {
+    if (!w || !wpb || !taps || Cout < 1 || Cin < 1 || T < 1 || ntaps < 1 || ntaps > T2V_MAX_TAPS) return T2V_EINVAL;
+    TapList tl;
+    tl.n = ntaps;
+    for (int i = 0; i < T2V_MAX_TAPS; ++i) tl.t[i] = i < ntaps ? taps[i] : 0;
+    long nb = ((long)Cout * Cin + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    T2V_LAUNCH(pack_weight_bf16_kernel, dim3((unsigned)nb, (unsigned)ntaps), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wpb, Cout, Cin,
+               T, tl, mode);
+    return launch_status();
+}
+
 // y_g = (accum ? y_g : 0) + bias[co] + sum_s slab[s]   (fixed summation order), for every group
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GroupTable tab, const float* __restrict__ slab,
                                                             const float* __restrict__ bias, int S, int Cout, int flags) {
@@ -1222,6 +1392,67 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         long blocks = (tab.out_start[ngroups] + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         ProfScope prof_r(4, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);     // the split-K pass, timed on its own
+        T2V_LAUNCH_PROF(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
+    }
+    return launch_status();
+}
+
+// bf16-compute forward / data gradient: same contract as t2v_conv_fwd_grouped with wpb from t2v_pack_weight_bf16.
+// Returns T2V_EINVAL for shapes the bf16 kernel does not take (Cin % 32, thin outputs): the caller uses the fp32 entry point.
+extern "C" int t2v_conv_fwd_grouped_bf16_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout) {
+    GroupTable tab;
+    ConvPlan p;
+    int nslots;
+    if (!build_table(groups, ngroups, Cin, Cout, false, tab, p)) return 0;
+    if ((Cin % 32) != 0 || Cout <= 4 || thin_ok(groups, ngroups, Cin, Cout, nslots)) return 0;
+    return 1;
+}
+extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const void* wpb,
+                                         const float* bias, float* ws, int flags, void* stream) {
+    GroupTable tab;
+    ConvPlan p;
+    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p))
+        return T2V_EINVAL;
+    if (flags & T2V_CONV_MASK_OUT) {
+        if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
+        for (int i = 0; i < ngroups; ++i)
+            if (!groups[i].mask) return T2V_EINVAL;
+    }
+    // same tiling decisions as the fp32 path, restricted to BN = 64 (build_table picks 128x32 for Cout <= 32: re-tile)
+    if (p.bn != 64) {
+        long mt = 0;
+        p.bn = 64;
+        p.bm = 128;
+        for (int i = 0; i < ngroups; ++i) {
+            const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+            tab.tile_start[i] = (int32_t)mt;
+            mt += (M + p.bm - 1) / p.bm;
+        }
+        for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
+    }
+    if (p.S > 1 && !ws) return T2V_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    long Mtot_ = 0;
+    int taps_ = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        flops += 2.0 * (double)M * Cout * Cin * groups[i].ntaps;
+        Mtot_ += M;
+        if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
+    }
+    {
+        ProfScope prof(5, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
+        dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
+        if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        else T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+    }
+    int st = launch_status();
+    if (st) return st;
+    if (p.S > 1) {
+        long blocks = (tab.out_start[ngroups] + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        ProfScope prof_r(4, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
         T2V_LAUNCH_PROF(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
     }
     return launch_status();

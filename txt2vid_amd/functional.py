@@ -11,6 +11,7 @@ these kernels (conv fwd <-> dgrad <-> wgrad form a closed triple).
 """
 import contextlib
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -219,6 +220,47 @@ def packed_weight(w5, geom, mode):
     return wp
 
 
+CONV_PRECISION = os.environ.get('T2V_CONV_PRECISION', 'fp32')     # 'bf16': forward / data-gradient GEMMs on bf16 MFMA (fp32 storage
+#                                                                   and accumulation); opt-in, see set_conv_precision
+
+
+def set_conv_precision(p):
+    """'fp32' (default: what the parity tests and the benchmark metric use) or 'bf16' (BASELINE configs 2-4)."""
+    global CONV_PRECISION
+    if p not in ('fp32', 'bf16'):
+        raise ValueError(p)
+    old, CONV_PRECISION = CONV_PRECISION, p
+    return old
+
+
+def packed_weight_bf16(w5, ts, mode):
+    """bf16 wpb[ntaps][rows][K] (K contiguous) for the bf16-compute GEMM; persistent per (parameter, tap set, mode) and
+    refreshed lazily when the parameter changed (inside the captured graph under replay)."""
+    Cout, Cin = w5.shape[0], w5.shape[1]
+    base = w5._base if w5._base is not None else w5
+
+    def pack(dst):
+        check(lib().t2v_pack_weight_bf16(_p(w5), _p(dst), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode, _stream()),
+              't2v_pack_weight_bf16')
+    if not isinstance(base, torch.nn.Parameter):
+        wp = torch.empty((len(ts.taps), Cin * Cout), device=w5.device, dtype=torch.bfloat16)
+        pack(wp)
+        return wp
+    key = ('bf16', tuple(w5.shape), ts.mask, mode)
+    tag = _wtag(base, w5.data_ptr())
+    ent = _pack_cache.setdefault(id(base), {})
+    hit = ent.get(key)
+    if hit is not None and hit[0]() is base:
+        if hit[1] != tag:
+            pack(hit[2])
+            hit[1] = tag
+        return hit[2]
+    wp = torch.empty((len(ts.taps), Cin * Cout), device=w5.device, dtype=torch.bfloat16)
+    pack(wp)
+    ent[key] = [weakref.ref(base), tag, wp, None]
+    return wp
+
+
 _repack_tables = {}
 
 
@@ -243,7 +285,7 @@ def repack_params(params):
         if not ent:
             continue
         for key, hit in ent.items():
-            if hit[0]() is p:
+            if hit[0]() is p and key[0] != 'bf16':          # bf16 packs refresh lazily on their next use
                 jobs.append((p, key, hit))
     if not jobs:
         return
@@ -358,6 +400,8 @@ def _conv_ws(g, device):
 
 
 def conv_fwd_raw(x5, w5, bias=None, relu_in=False, out=None, accum=False):
+    if CONV_PRECISION == 'bf16':
+        return conv_group_raw([x5], w5, bias, relu_in, 0, outs=None if out is None else [out], accum=accum)[0]
     x5, w5 = _c(x5), _c(w5)
     g = _geom_for(x5, w5)
     wp = packed_weight(w5, g, 0)
@@ -371,6 +415,8 @@ def conv_fwd_raw(x5, w5, bias=None, relu_in=False, out=None, accum=False):
 
 def conv_dgrad_raw(gy5, w5, out=None, accum=False):
     """gx[N,Cin,...] = sum_taps,co gy * w (mirrored): the forward kernel on the mode-1 packed weight."""
+    if CONV_PRECISION == 'bf16':
+        return conv_group_raw([gy5], w5, None, False, 1, outs=None if out is None else [out], accum=accum)[0]
     gy5, w5 = _c(gy5), _c(w5)
     Cout, Cin = w5.shape[0], w5.shape[1]
     # geometry of the transposed problem: input channels = Cout, output channels = Cin
@@ -2320,7 +2366,6 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=N
     for g in geoms:
         mask |= g.mask
     ts = _tapset(geoms[0].T, mask)
-    wp = packed_weight(w5, ts, mode)
     slot_of = {t: j for j, t in enumerate(ts.taps)}
     ys = outs if outs is not None else [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32)
                                         for t in xs5]
@@ -2335,6 +2380,12 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=N
     ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
     flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0) |
              (FLAG_ACCUM if accum else 0))
+    if CONV_PRECISION == 'bf16' and lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs5), cin, cout):
+        wpb = packed_weight_bf16(w5, ts, mode)
+        check(lib().t2v_conv_fwd_grouped_bf16(arr, len(xs5), cin, cout, _p(wpb), _p(bias), _p(ws), flags, _stream()),
+              't2v_conv_fwd_grouped_bf16')
+        return ys
+    wp = packed_weight(w5, ts, mode)
     check(lib().t2v_conv_fwd_grouped(arr, len(xs5), cin, cout, _p(wp), _p(bias), _p(ws), flags, _stream()), 't2v_conv_fwd_grouped')
     return ys
 
