@@ -218,6 +218,32 @@ def test_bf16_compute_convolution(shapes, cin, cout, k):
         close(gx, exact_g.float(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('shapes,cin,cout,k', [
+    ([(2, 64, 4, 8, 8), (1, 64, 2, 16, 16)], 64, 96, (3, 3, 3)),
+    ([(4, 128, 1, 16, 16)], 128, 64, (1, 3, 3)),
+])
+def test_bf16_compute_weight_gradient(shapes, cin, cout, k):
+    """bf16-compute mode, 3-tap-row weight gradient (+ the bias side-sum, which stays fp32): equals the EXACT weight gradient
+    of the bf16-rounded operands (fp32 accumulation), with the fused input ReLU."""
+    from txt2vid_amd import functional as TF
+    xs = [rnd(400 + i, *sh) for i, sh in enumerate(shapes)]
+    gys = [rnd(410 + i, sh[0], cout, *sh[2:]) for i, sh in enumerate(shapes)]
+    pad = tuple(kk // 2 for kk in k)
+    r16 = lambda t: t.bfloat16().double()
+    w = torch.zeros(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    sum((F.conv3d(r16(F.relu(x)), w, None, padding=pad) * r16(g)).sum() for x, g in zip(xs, gys)).backward()
+    db_ref = sum(g.double().sum(dim=(0, 2, 3, 4)) for g in gys)
+    old = TF.set_conv_precision('bf16')
+    try:
+        dw = torch.empty((cout, cin) + k, device=dev())
+        db = torch.empty((cout,), device=dev())
+        TF.conv_group_wgrad_raw([x.to(dev()) for x in xs], [g.to(dev()) for g in gys], (cout, cin) + k, True, out=dw, dbias=db)
+    finally:
+        TF.set_conv_precision(old)
+    close(dw, w.grad.float(), rtol=5e-5, atol=5e-5)
+    close(db, db_ref.float(), rtol=1e-5, atol=1e-5)
+
+
 def test_avgpool():
     from txt2vid_amd import functional as TF
     for shape, k, s, p in (((2, 3, 4, 6, 6), (1, 2, 2), (2, 2, 2), (0, 0, 0)),

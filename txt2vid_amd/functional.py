@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, MAX_TAPS, MAX_GROUPS
 
-FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT, FLAG_ACCUM_BIAS = 1, 2, 4, 8, 16
+FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT, FLAG_ACCUM_BIAS, FLAG_BF16 = 1, 2, 4, 8, 16, 32
 
 # ------------------------------------------------------------------------------------------------
 # small helpers
@@ -430,6 +430,8 @@ def conv_dgrad_raw(gy5, w5, out=None, accum=False):
 
 
 def conv_wgrad_raw(x5, gy5, wshape, relu_in=False, out=None, accum=False):
+    if CONV_PRECISION == 'bf16':
+        return conv_group_wgrad_raw([x5], [gy5], wshape, relu_in, out=out, accum=accum)
     x5, gy5 = _c(x5), _c(gy5)
     g = conv_geom(x5.shape[0], wshape[1], x5.shape[2], x5.shape[3], x5.shape[4], wshape[0], wshape[2], wshape[3], wshape[4])
     n = lib().t2v_conv_wgrad_slab_floats(C.byref(g.cg), g.T)
@@ -2402,7 +2404,7 @@ def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False
         raise RuntimeError('bad grouped wgrad geometry')
     slab = torch.empty((n,), device=xs5[0].device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(tuple(wshape), device=xs5[0].device, dtype=torch.float32)
-    flags = (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0)
+    flags = (FLAG_RELU_IN if relu_in else 0) | (FLAG_ACCUM if accum else 0) | (FLAG_BF16 if CONV_PRECISION == 'bf16' else 0)
     if dbias is not None:
         check(lib().t2v_conv_wgrad_grouped_bias(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(dw), _p(dbias), _p(slab),
                                                 flags | (FLAG_ACCUM_BIAS if accum_bias else 0), _stream()),
