@@ -130,8 +130,8 @@ def main():
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay (eager launches)')
     ap.add_argument('--bf16', action='store_true', help='bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA, fp32 storage and '
                                                        'accumulation): an extra, NOT the precision the metric is quoted on')
-    ap.add_argument('--cond', action='store_true', help='text-conditioned TGANv2 (BASELINE configs[2] shape, at fp32) instead of '
-                                                       'the unconditional configs[1] workload the metric is quoted on')
+    ap.add_argument('--cond', action='store_true', help='text-conditioned TGANv2 (BASELINE configs[2] shape) instead of '
+                                                       'the unconditional configs[1] workload the metric is quoted on; with --bf16 = configs[2]')
     args = ap.parse_args()
 
     from txt2vid_amd import dist as tdist
@@ -270,17 +270,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     gb = args.batch * world
+    if args.cond:
+        workload = ('BASELINE configs[2]%s: text-conditioned TGANv2 (Bi-LSTM sentence codes, 2-D + 3-D non-local blocks) ' %
+                    ('' if bf16 else ' shape at fp32'))
+    else:
+        workload = 'BASELINE configs[1]: unconditional TGANv2 '
+    workload += ('16x64x64x1, per-GPU batch %d, %s, RSGAN + GP 0.5, Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid '
+                 '8/16/32/64' % (args.batch, 'bf16 compute' if bf16 else 'fp32'))
     res = {
         'metric': 'TGANv2 GAN train throughput (G+D steps x global batch), 16x64x64 videos/sec',
         'value': gb * args.steps / dt, 'unit': 'videos/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'steps_per_sec': args.steps / dt, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16 compute (forward / data-gradient MFMA), f32 storage + accumulation + weight gradient' if bf16 else 'f32',
+        'dtype': 'bf16 compute (forward / data-gradient / 3-tap weight-gradient MFMA), f32 storage + accumulation' if bf16 else 'f32',
         'data': 'synthetic',
-        'config': {'workload': ('BASELINE configs[2] shape at fp32 (bf16 tiles not built): text-conditioned TGANv2 (Bi-LSTM sentence codes, '
-                                '2-D + 3-D non-local blocks) ' if args.cond else 'BASELINE configs[1]: unconditional TGANv2 ') +
-                               '16x64x64x1, per-GPU batch %d, fp32, RSGAN + GP 0.5, '
-                               'Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid 8/16/32/64' % args.batch,
+        'config': {'workload': workload,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
                    'as_written_tflop_per_step': GFLOP_PER_SAMPLE_AS_WRITTEN * gb / 1e3},
         'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (3 graphs/step)',
