@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 matrix rate (dense bf16, no sparsity); only used by --bf16
 GFLOP_PER_SAMPLE_AS_WRITTEN = 49.27      # reference-executed FLOPs per base sample, uncond, GP on
 
 
@@ -245,15 +246,20 @@ def main():
         prof_dt = time.perf_counter() - t1
         log('instrumented eager pass done: %.1f ms/step' % (prof_dt / prof_steps * 1e3))
     if prof:
-        out = (C.c_double * 15)()
-        over = lib().t2v_prof_end(out, 5)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce
+        out = (C.c_double * 18)()
+        over = lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
+        if bf16:                                   # bf16-compute mode: the dominant kernel is the bf16 GEMM, priced against the bf16 peak
+            out[0], out[1], out[2] = out[15], out[16], out[17]
         ms, fl, cnt = out[0] + out[12], out[1], out[2]
         if cnt > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic()[0], 'traffic_note': pmc_traffic()[1],
-                    'kernel': 'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2; '
-                              'includes its split-K reduce pass)',
+            peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': ach / peak, 'traffic': pmc_traffic()[0], 'traffic_note': pmc_traffic()[1],
+                    'kernel': ('conv_igemm_bf16_kernel (implicit-GEMM conv forward + data-gradient, bf16 MFMA 32x32x16, fp32 tensors; '
+                               'includes its split-K reduce pass)' if bf16 else
+                               'conv_igemm_kernel (implicit-GEMM conv forward + data-gradient, fp32 MFMA 32x32x2; '
+                               'includes its split-K reduce pass)'),
                     'launches_per_step': cnt / prof_steps, 'avg_launch_us': out[0] * 1e3 / cnt,
                     'splitk_reduce': {'launches_per_step': out[14] / prof_steps, 'gpu_ms_per_step': out[12] / prof_steps},
                     'timing': 'hipExtLaunchKernelGGL start/stop events = the dispatch\'s own begin/end (same clock as the rocprofv3 kernel trace)',

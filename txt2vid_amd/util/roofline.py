@@ -45,8 +45,11 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
     for _ in range(iters):
         fwd_bwd()
     torch.cuda.synchronize()
-    out = (C.c_double * 15)()
-    lib().t2v_prof_end(out, 5)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce
+    out = (C.c_double * 18)()
+    lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
+    out[0] += out[15]                   # (bf16-compute mode: its GEMM launches count as forward / data-gradient work)
+    out[1] += out[16]
+    out[2] += out[17]
     ig_ms, ig_fl, ig_n, wg_ms, wg_fl, wg_n, red_ms = [out[i] / iters for i in range(7)]
     ig_ms += (out[9] + out[12]) / iters          # thin convs and split-K passes belong to forward / data-gradient
     ig_fl += out[10] / iters
