@@ -56,7 +56,7 @@ typedef struct {
 #define T2V_CONV_RELU_IN 2   /* apply max(.,0) to the input while gathering (ReLU->conv fusion)  */
 #define T2V_CONV_ACCUM 4     /* y += result instead of y = result                                */
 #define T2V_CONV_ACCUM_BIAS 16 /* t2v_conv_wgrad_grouped_bias: dbias += result (T2V_CONV_ACCUM covers dw only)      */
-#define T2V_CONV_BF16 32      /* t2v_conv_wgrad_grouped[_bias]: bf16-compute mode for the 3-tap-row kernel (fp32 tensors)   */
+#define T2V_CONV_BF16 32      /* t2v_conv_wgrad_grouped[_bias]: bf16-compute mode for the MFMA kernels (fp32 tensors)        */
 #define T2V_CONV_MASK_OUT 8  /* zero the result where groups[i].mask <= 0: the ReLU adjoint fused into the data
                                 gradient of a ReLU->conv pair (layers.py:230-233). Not combined with ACCUM. */
 

@@ -221,6 +221,8 @@ def test_bf16_compute_convolution(shapes, cin, cout, k):
 @pytest.mark.parametrize('shapes,cin,cout,k', [
     ([(2, 64, 4, 8, 8), (1, 64, 2, 16, 16)], 64, 96, (3, 3, 3)),
     ([(4, 128, 1, 16, 16)], 128, 64, (1, 3, 3)),
+    ([(2, 128, 4, 8, 8), (5, 128, 1, 1, 1)], 128, 40, (1, 1, 1)),            # per-tap kernel (1x1x1)
+    ([(3, 64, 2, 1, 1)], 64, 32, (3, 3, 3)),                                 # per-tap kernel, 3^3 on W = 1 maps
 ])
 def test_bf16_compute_weight_gradient(shapes, cin, cout, k):
     """bf16-compute mode, 3-tap-row weight gradient (+ the bias side-sum, which stays fp32): equals the EXACT weight gradient

@@ -1633,6 +1633,139 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 }
 
 
+// bf16-compute variant of conv_wgrad_kernel (opt-in mode): tiles rounded to bf16 at the LDS write, v_mfma_f32_32x32x16_bf16.
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                         const int Cout, const int T, const int kH, const int kW,
+                                                         const int flags, const int chunks_per_split, const LiveTaps live,
+                                                         float* __restrict__ bias_slab) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[64 * B16_KP];    // gy^T tile  [co][m], m contiguous
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[64 * B16_KP];    // x   tile   [ci][m]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int nco_t = (Cout + 63) / 64;
+    const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
+    // (slot, split) from an XCD-aware linear id: the taps of one k-split (same x / gy voxels) share an L2
+    const int lin = xcd_remap((int)(blockIdx.y + blockIdx.z * gridDim.y), (int)(gridDim.y * gridDim.z));
+    const int slot = lin % (int)gridDim.y;
+    const int split = lin / (int)gridDim.y;
+    const int t = live.t[slot];         // ORIGINAL tap index of slab slot
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    // offset of original tap t (k in {1,3} per dim, centred)
+    const int kD = T / (kH * kW);
+    const int ta = t / (kH * kW), tb = (t / kW) % kH, tc = t % kW;
+    const int dz = ta - kD / 2, dy = tb - kH / 2, dx = tc - kW / 2;
+
+    const int ml = tid & 31, rl = tid >> 5;     // 32 m x 8 rows per pass, 8 passes -> 64 rows
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+
+    float ra[8], rb[8];
+    bool pend_v = false;
+    // bias gradient on the side (see conv_wgrad3_kernel): the centre tap's workgroups of the first channel tile see every
+    // voxel of every member exactly once
+    const bool do_bias = bias_slab != nullptr && ci0 == 0 && t == T / 2;
+    bool pend_mv = false;
+    float bsum[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
+    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
+    auto load_chunk = [&](int q) {
+        if (dbg_noload && q != q0) return;
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+        // a dim of extent 1 keeps its centre tap only (same rule as the forward)
+        const bool tap_live = !((D == 1 && dz) || (H == 1 && dy) || (W == 1 && dx));
+        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
+        const bool mv = tap_live && m < M;
+        bool xv = false;
+        size_t gbase = 0, xb = 0;      // clamped: voxel 0 of sample 0 when this lane has nothing to load
+        if (mv) {
+            const bool small = M < (1 << 24);
+            int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+            int sp = m - n * DHW;
+            int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            int r = sp - d * HW;
+            int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            int w_ = r - h * W;
+            gbase = (size_t)n * Cout * DHW + sp;
+            int dd = d + dz, hh = h + dy, ww = w_ + dx;
+            xv = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            xb = (size_t)n * Cin * DHW + sp + (xv ? (ptrdiff_t)(dz * HW + dy * W + dx) : 0);
+        }
+        const float* __restrict__ gy = gd.y;
+        const float* __restrict__ x = gd.x;
+        // unconditional loads from clamped addresses, masked afterwards (no branch + wait per element)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
+            rb[p] = x[xb + (size_t)(ci < Cin ? ci : Cin - 1) * DHW];
+        }
+        pend_v = xv;
+        pend_mv = mv;
+    };
+
+    if (q0 < q1) load_chunk(q0);
+    for (int q = q0; q < q1; ++q) {
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
+        }
+        if (!(dbg_nostage && q != q0))
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {          // masking + fused ReLU at the LDS write, one chunk after the loads
+            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+            As[(rl + p * 8) * B16_KP + ml] = (__bf16)((pend_v && co < Cout) ? ra[p] : 0.f);
+            const float v = (pend_v && ci < Cin) ? rb[p] : 0.f;
+            Bs[(rl + p * 8) * B16_KP + ml] = (__bf16)(relu_in ? fmaxf(v, 0.f) : v);
+        }
+        __syncthreads();
+        if (q + 1 < q1) load_chunk(q + 1);
+#pragma unroll
+        for (int ks = 0; ks < WG_BK / 16; ++ks) {
+            const int kc = ks * 16 + 8 * hi;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wco * 32 + l31) * B16_KP + kc);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wci * 32 + l31) * B16_KP + kc);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = bsum[p];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int co = co0 + rl + p * 8;
+            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
+        }
+    }
+    // slab[((split*nlive + slot)*Cout + co)*Cin + ci]; rows = co (registers), cols = ci (lanes)
+    const int ci = ci0 + wci * 32 + l31;
+    if (ci < Cin) {
+        float* ps = slab + ((size_t)split * live.n + slot) * Cout * Cin + ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) ps[(size_t)co * Cin] = acc[r];
+        }
+    }
+}
+
+
+
 // Weight gradient for Cin < 64: the 64 tile columns run over (tap, ci) pairs instead of one tap's channels
 // (C -> 64 stem convs: 27 columns instead of 27 tiles that are 1/64 full).
 __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
@@ -2336,8 +2469,12 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
             T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
         } else {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
-            T2V_LAUNCH_PROF(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
-                            dbias ? bias_part : (float*)nullptr);
+            if (flags & T2V_CONV_BF16)
+                T2V_LAUNCH_PROF(conv_wgrad_bf16_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
+                                dbias ? bias_part : (float*)nullptr);
+            else
+                T2V_LAUNCH_PROF(conv_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
+                                dbias ? bias_part : (float*)nullptr);
         }
     }
     int st = launch_status();
