@@ -207,12 +207,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     const int b = (int)blockIdx.x - job.block_begin;
     const int bxi = b % job.bx, byi = (b / job.bx) % job.by, j = b / (job.bx * job.by);
     const int Cout = job.Cout, Cin = job.Cin, T = job.T;
-    const int t = job.mode ? (T - 1 - job.taps[j]) : job.taps[j];
+    // mode 0 / 1: fp32 forward / mirrored data-gradient layouts (see t2v_pack_weight); mode 2 / 3: the bf16-compute layouts
+    // (t2v_pack_weight_bf16 mode 0 / 1): 2 = dst[j][co][ci], 3 = dst[j][ci][co] mirrored, both bf16
+    const bool mirror = job.mode == 1 || job.mode == 3, transpose = job.mode == 0 || job.mode == 3, b16 = job.mode >= 2;
+    const int t = mirror ? (T - 1 - job.taps[j]) : job.taps[j];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int co0 = byi * 32, ci0 = bxi * 32;
     const float* __restrict__ w = job.src;
     float* __restrict__ wp = job.dst;
-    if (job.mode == 0) {
+    __bf16* __restrict__ wpb = reinterpret_cast<__bf16*>(job.dst);
+    if (transpose) {
         for (int r = ty; r < 32; r += 8) {
             int co = co0 + r, ci = ci0 + tx;
             tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
@@ -220,13 +224,19 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
             int ci = ci0 + r, co = co0 + tx;
-            if (ci < Cin && co < Cout) wp[((size_t)j * job.dst_rows + job.row_off + ci) * job.dst_cols + job.col_off + co] = tile[tx][r];
+            if (ci < Cin && co < Cout) {
+                const size_t o = ((size_t)j * job.dst_rows + job.row_off + ci) * job.dst_cols + job.col_off + co;
+                if (b16) wpb[o] = (__bf16)tile[tx][r]; else wp[o] = tile[tx][r];
+            }
         }
     } else {
         for (int r = ty; r < 32; r += 8) {
             int co = co0 + r, ci = ci0 + tx;
-            if (co < Cout && ci < Cin)
-                wp[((size_t)j * job.dst_rows + job.row_off + co) * job.dst_cols + job.col_off + ci] = w[((size_t)co * Cin + ci) * T + t];
+            if (co < Cout && ci < Cin) {
+                const size_t o = ((size_t)j * job.dst_rows + job.row_off + co) * job.dst_cols + job.col_off + ci;
+                const float v = w[((size_t)co * Cin + ci) * T + t];
+                if (b16) wpb[o] = (__bf16)v; else wp[o] = v;
+            }
         }
     }
 }

@@ -257,7 +257,7 @@ def packed_weight_bf16(w5, ts, mode):
         return hit[2]
     wp = torch.empty((len(ts.taps), Cin * Cout), device=w5.device, dtype=torch.bfloat16)
     pack(wp)
-    ent[key] = [weakref.ref(base), tag, wp, None]
+    ent[key] = [weakref.ref(base), tag, wp, ts]
     return wp
 
 
@@ -268,6 +268,12 @@ def _pack_job_of(p, key, hit):
     """(src, dst, Cout, Cin, T, taps, mode, dst_rows, dst_cols, row_off, col_off) of one cached packed variant."""
     if callable(hit[3]):
         return hit[4]                    # member of a fused matrix: its job tuple was recorded at creation
+    if key[0] == 'bf16':                 # bf16-compute layouts: pack_multi modes 2 (forward) / 3 (data gradient)
+        _, shape5, _, mode = key
+        ts = hit[3]
+        Cout, Cin = shape5[0], shape5[1]
+        src = p if tuple(p.shape) == tuple(shape5) else p.view(shape5)
+        return (src, hit[2], Cout, Cin, ts.T, list(ts.taps), 2 + mode, (Cin if mode else Cout), (Cout if mode else Cin), 0, 0)
     shape5, _, mode = key
     geom = hit[3]
     Cout, Cin = shape5[0], shape5[1]
@@ -285,7 +291,7 @@ def repack_params(params):
         if not ent:
             continue
         for key, hit in ent.items():
-            if hit[0]() is p and key[0] != 'bf16':          # bf16 packs refresh lazily on their next use
+            if hit[0]() is p:
                 jobs.append((p, key, hit))
     if not jobs:
         return
