@@ -922,6 +922,197 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const GroupTable t
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
 
+// Strip form of the bf16-compute GEMM (see conv_igemm_strip_kernel): the activation tile of a (kernel row, channel block) is
+// staged once as BM + 2 voxel rows and serves the three dx taps; in the [voxel][k] LDS layout a dx shift is a whole row, so the
+// fragment reads stay 16-byte aligned. Row ends are masked at read time (a vector select per fragment).
+template <int BM>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_strip_kernel(const GroupTable tab, const __bf16* __restrict__ wpb,
+                                                                    const float* __restrict__ bias, float* __restrict__ slab,
+                                                                    const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int KPT = BKT * BM / 256;
+    constexpr int HT = BKT / KPT;                // threads that cover the 32 channels of ONE halo voxel
+    static_assert(NCO == 1 && NM >= 1 && (KPT == 16 || KPT == 8), "tile");
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[2 * (BM + 2) * B16_KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2 * BN * B16_KP];
+    __shared__ int s_roff[T2V_MAX_TAPS];
+    __shared__ int s_widx[T2V_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const float* __restrict__ x = gd.x;
+    const int D = gd.D, H = gd.H, W = gd.W;
+    const int HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    const int ndx = gd.dx[0] < 0 ? 3 : 1;
+    const int nrow = ntaps / ndx;
+    if (tid < nrow) s_roff[tid] = gd.dz[tid * ndx] * HW + gd.dy[tid * ndx] * W;
+    if (tid < ntaps) s_widx[tid] = gd.widx[tid];
+
+    const int ma_l = tid % BM, kq = tid / BM;
+    const bool halo_thread = tid < 2 * HT;
+    const int he = tid / HT, hq = tid % HT;          // halo: he = 0 left (voxel m0 - 1), 1 right (voxel m0 + BM)
+    uint32_t rowmask = 0, rowmask_h = 0;
+    size_t xbase = 0, xbase_h = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {
+            const int n = m_a / DHW, sp = m_a - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase = (size_t)n * Cin * DHW + sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
+            }
+        }
+        const int m_h = he ? m0 + BM : m0 - 1;
+        if (halo_thread && m_h >= 0 && m_h < M) {
+            const int n = m_h / DHW, sp = m_h - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase_h = (size_t)n * Cin * DHW + sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
+            }
+        }
+    }
+    bool can_l[NM], can_r[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int m = m0 + wm * WM + j * 32 + l31;
+        const int w_ = m % W;
+        can_l[j] = w_ > 0;
+        can_r[j] = w_ < W - 1;
+    }
+    const int wc_l = tid >> 2, wk_l = (tid & 3) * 8;
+    const bool w_ok = co0 + wc_l < Cout;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+
+    f32x16 acc[NCO][NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    float ra[KPT], rh[KPT];
+    bf16x8 rw;
+    const int ncb = Cin / BKT;
+    const int nchunks = ntaps * ncb;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * cps;
+    int q1 = q0 + cps;
+    if (q1 > nchunks) q1 = nchunks;
+    __syncthreads();
+
+    int r_cur = q0 / (ncb * ndx);
+    int cb_cur = (q0 - r_cur * ncb * ndx) / ndx;
+    int d_cur = q0 - (r_cur * ncb + cb_cur) * ndx;
+    auto advance = [&]() {
+        if (++d_cur == ndx) { d_cur = 0; if (++cb_cur == ncb) { cb_cur = 0; ++r_cur; } }
+    };
+    bool pend_has_a = false, pend_av = false, pend_hv = false;
+    int pend_dx = 0;
+    auto load_chunk = [&](bool force_a) {
+        const int c0 = cb_cur * BKT;
+        pend_has_a = force_a || d_cur == 0;
+        pend_dx = ndx == 3 ? d_cur - 1 : 0;
+        if (pend_has_a) {
+            pend_av = (rowmask >> r_cur) & 1u;
+            const float* px = x + xbase + (pend_av ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + kq * KPT) * DHW;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) ra[j] = px[(size_t)j * DHW];
+            if (halo_thread) {
+                pend_hv = (rowmask_h >> r_cur) & 1u;
+                const float* ph = x + xbase_h + (pend_hv ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + hq * KPT) * DHW;
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) rh[j] = ph[(size_t)j * DHW];
+            }
+        }
+        const int t = r_cur * ndx + d_cur;
+        const __bf16* pw = wpb + ((size_t)s_widx[t] * Cout + (w_ok ? co0 + wc_l : 0)) * Cin + c0 + wk_l;
+        rw = *reinterpret_cast<const bf16x8*>(pw);
+    };
+    auto put_row = [&](__bf16* dst, const float* v, bool ok) {
+#pragma unroll
+        for (int g = 0; g < KPT / 8; ++g) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = ok ? v[g * 8 + j] : 0.f;
+                if (relu_in) f = fmaxf(f, 0.f);
+                o[j] = (__bf16)f;
+            }
+            *reinterpret_cast<bf16x8*>(dst + g * 8) = o;
+        }
+    };
+    auto stage = [&](int ab, int bb) {
+        if (pend_has_a) {
+            __bf16* xs = Xs + ab * ((BM + 2) * B16_KP);
+            put_row(xs + (1 + ma_l) * B16_KP + kq * KPT, ra, pend_av);
+            if (halo_thread) put_row(xs + (he ? BM + 1 : 0) * B16_KP + hq * KPT, rh, pend_hv);
+        }
+        bf16x8 wv = rw;
+        if (!w_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(Ws + bb * (BN * B16_KP) + wc_l * B16_KP + wk_l) = wv;
+    };
+
+    int acur = 0, bcur = 0, dx_now = 0;
+    if (q0 < q1) {
+        load_chunk(true);
+        stage(0, 0);
+        dx_now = pend_dx;
+        __syncthreads();
+        if (q0 + 1 < q1) { advance(); load_chunk(false); }
+    }
+    bf16x8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
+    for (int q = q0; q < q1; ++q) {
+        const __bf16* xs = Xs + acur * ((BM + 2) * B16_KP) + (1 + dx_now + wm * WM + l31) * B16_KP + 8 * hi;
+        const __bf16* ws = Ws + bcur * (BN * B16_KP) + (wco * WCO + l31) * B16_KP + 8 * hi;
+        bool keep[NM];
+#pragma unroll
+        for (int j = 0; j < NM; ++j) keep[j] = dx_now < 0 ? can_l[j] : (dx_now > 0 ? can_r[j] : true);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + j * 32 * B16_KP + ks * 16);
+                b = keep[j] ? b : zero8;
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0);
+            }
+        }
+        const bool more = q + 1 < q1;
+        const bool next_a = more && pend_has_a;
+        int dx_next = dx_now;
+        if (more) { stage(acur ^ 1, bcur ^ 1); dx_next = pend_dx; }
+        __syncthreads();
+        if (q + 2 < q1) { advance(); load_chunk(false); }
+        bcur ^= 1;
+        if (next_a) acur ^= 1;
+        dx_now = dx_next;
+    }
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+}
+
 // w[Cout][Cin][T] fp32 -> bf16 wpb[j][rows][K] with K contiguous: mode 0 rows = co, K = ci (forward);
 // mode 1 rows = ci, K = co, mirrored taps (data gradient)
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wpb, int Cout, int Cin, int T,
@@ -1453,7 +1644,11 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
     {
         ProfScope prof(5, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
-        if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        static const bool strip16 = getenv("T2V_NO_STRIP") == nullptr;
+        if (strip16 && strip_ok(tab)) {
+            if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+            else T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        } else if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
         else T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
     }
     int st = launch_status();
