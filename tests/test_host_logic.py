@@ -136,3 +136,22 @@ def test_cli_flags_match_reference():
     p = add_params_to_parser(argparse.ArgumentParser())
     a = p.parse_args(['--gp_lambda', '.5', '--subsample_input', '--no_mean_discrim_loss'])
     assert a.gp_lambda == 0.5 and a.subsample_input and a.no_mean_discrim_loss is False and a.no_mean_gen_loss is True
+
+
+def test_reference_pickled_sentence_encoder_resolves(tmp_path):
+    """`--sent_weights`: the reference saves `{'optim': ..., 'txt': seq2seq}` with the objects pickled whole under
+    `txt2vid.models.txt.basic` (train/txt.py:185); with the module aliases the same file loads into the drop-in class."""
+    import pickle
+    import sys
+    import torch
+    from txt2vid_amd.models.txt.basic import Seq2Seq
+    from txt2vid_amd.util.reflection import alias_reference_modules
+    m = Seq2Seq(vocab_size=11)
+    # (a text protocol: binary protocols prefix the module path with its length, which the rename would break)
+    blob = pickle.dumps({'txt': m, 'optim': None}, protocol=0).replace(b'txt2vid_amd.models.txt.basic', b'txt2vid.models.txt.basic')
+    for k in [k for k in sys.modules if k == 'txt2vid' or k.startswith('txt2vid.')]:
+        del sys.modules[k]
+    alias_reference_modules()
+    got = pickle.loads(blob)['txt']
+    assert isinstance(got, Seq2Seq) and got.encoder.lstm.weight_hh_l0.shape == m.encoder.lstm.weight_hh_l0.shape
+    assert torch.equal(got.encoder.embed.weight, m.encoder.embed.weight)

@@ -44,7 +44,9 @@ def main(args):
     txt_encoder = None
     if not args.dont_use_sent:
         if args.sent_weights:
-            txt_encoder = torch.load(args.sent_weights, weights_only=False)
+            from ..util.reflection import alias_reference_modules
+            alias_reference_modules()            # the reference pickles the whole Seq2Seq object under its own module path
+            txt_encoder = torch.load(args.sent_weights, weights_only=False, map_location='cpu')
             if isinstance(txt_encoder, dict) and 'txt' in txt_encoder:
                 txt_encoder = txt_encoder['txt']
             txt_encoder = txt_encoder.to(device)

@@ -36,3 +36,18 @@ def create_object_file(json_file_path, **kwargs):
         params = json.load(f)
     assert 'class' in params
     return create_object(params, **kwargs)
+
+
+def alias_reference_modules():
+    """Let pickles written by the reference (whole-module checkpoints such as `--sent_weights`: train/txt.py:185 saves
+    `{'optim': optimizer, 'txt': seq2seq}`) resolve their `txt2vid.*` class paths to this package's drop-in classes."""
+    import sys
+    for ours in ('', '.models', '.models.txt', '.models.txt.basic', '.models.layers', '.models.conv_lstm', '.models.resnet3d',
+                 '.models.tganv2', '.models.tganv2.gen', '.models.tganv2.discrim', '.models.tganv2_cond', '.models.tganv2_cond.gen',
+                 '.models.tganv2_cond.discrim', '.gan', '.gan.losses', '.gan.cond_gan', '.data', '.util', '.util.pick'):
+        theirs = 'txt2vid' + ours
+        if theirs not in sys.modules:
+            try:
+                sys.modules[theirs] = importlib.import_module('txt2vid_amd' + ours)
+            except ImportError:
+                pass
