@@ -1,7 +1,8 @@
-import os
+"""Output directories (txt2vid/util/dir.py)."""
+from pathlib import Path
 
 
 def ensure_exists(path):
-    """txt2vid/util/dir.py:3-8."""
-    if path and not os.path.exists(path):
-        os.makedirs(path, exist_ok=True)
+    """mkdir -p; returns the path as given."""
+    Path(path).mkdir(parents=True, exist_ok=True)
+    return path
