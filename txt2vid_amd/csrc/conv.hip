@@ -1418,7 +1418,11 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         p.bn = 64;
         const long t128 = ((Mtot + 127) / 128) * ((Cout + 63) / 64);
         p.bm = (t128 >= 768) ? 128 : 64;
-        if (p.bk > 32) p.bk = 32;                  // two LDS stages: 48 KB (128x64) / 32 KB (64x64) per workgroup
+        // 256 x 64 tiles, K chunks of 16, one wave = 64 co x 64 m (four accumulator chains, one LDS read per MFMA) for the
+        // launches big enough to fill the chip with them (+3-6 % over the 128 x 64 tile there)
+        static const long tile256_min = getenv("T2V_TILE256_MIN") ? atol(getenv("T2V_TILE256_MIN")) : 512;
+        if (p.fast && (Cin % 16) == 0 && ((Mtot + 255) / 256) * ((Cout + 63) / 64) >= tile256_min) { p.bm = 256; p.bk = 16; }
+        if (p.bk > 32 && p.bm != 256) p.bk = 32;   // two LDS stages: 48 KB (128x64) / 32 KB (64x64) per workgroup
     }
     if (!p.fast) p.bk = 16;
     long mt = 0, ot = 0;
@@ -1477,7 +1481,7 @@ template <int BM, int BN, int WAVES_CO, int BKT>
 static void launch_conv_t(const GroupTable& tab, const float* wp, const float* bias, float* slab, int Cin, int Cout, int flags,
                           const ConvPlan& p, hipStream_t s) {
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
-    if (p.fast && BKT == 32 && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
+    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
         constexpr int KS = (BM == 64 && BN == 64 && BKT == 32) ? 2 : 1;
         // two accumulator chains per wave cost a VGPR occupancy step (3 instead of 4 waves per SIMD): worth it only for
         // launches that cannot put 4 workgroups on every CU anyway
@@ -1579,6 +1583,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     if (p.bn == 32) {
         if (bk == 32) launch_conv_t<128, 32, 1, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
         else launch_conv_t<128, 32, 1, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
+    } else if (p.bm == 256) {
+        launch_conv_t<256, 64, 1, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
     } else if (p.bm == 128) {
         if (bk == 32) launch_conv_t<128, 64, 2, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
         else launch_conv_t<128, 64, 2, 16>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
@@ -1618,8 +1624,9 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
         for (int i = 0; i < ngroups; ++i)
             if (!groups[i].mask) return T2V_EINVAL;
     }
-    // same tiling decisions as the fp32 path, restricted to BN = 64 (build_table picks 128x32 for Cout <= 32: re-tile)
-    if (p.bn != 64) {
+    // same tiling decisions as the fp32 path, restricted to the tiles the bf16 kernels have (128 x 64, 64 x 64): re-tile when
+    // build_table picked 128 x 32 (Cout <= 32) or 256 x 64
+    if (p.bn != 64 || p.bm == 256) {
         long mt = 0;
         p.bn = 64;
         p.bm = 128;
