@@ -66,7 +66,11 @@ def main(args):
     D_params = [{'params': d.parameters()} for d in discrims]
     G_params = [{'params': gen.parameters()}]
     if args.end2end and txt_encoder is not None:
-        raise NotImplementedError('--end2end (training the text encoder through the GAN) is not built yet')
+        raise NotImplementedError(
+            '--end2end is not built: as written it cannot run — the reference puts the text encoder in BOTH optimisers '
+            '(train/gan.py:82-85), so optD.step() rewrites the LSTM weights in place between the two backward passes '
+            'through one encoder graph (trainer.py:240 retain_graph) and autograd rejects the generator backward '
+            '("modified by an inplace operation"); see DESIGN.md §7')
     if args.sgd:                                   # train/gan.py:86-89: momentum = beta1
         status('Using SGD')
         optD = SGD(D_params, lr=args.D_lr, momentum=args.D_beta1)
