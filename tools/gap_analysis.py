@@ -1,8 +1,8 @@
 """Timeline of the graph-replayed steps from a rocprofv3 --kernel-trace CSV: GPU-busy time, idle gaps, and which
 kernels the gaps follow. Usage: python tools/gap_analysis.py <rocprof dir> <ms_per_step> [n_steps_to_analyse]
 
-Takes the window of the last n steps before the trace's final `skip_tail_ms` (the bench's eager instrumented pass runs
-after the timed region, so the window is located by --end_frac of the trace span)."""
+[auto | start fraction]. The bench's eager warm-ups run before the timed region and its instrumented pass after it, so the
+window of n steps is placed on the densest stretch of the trace (the graph replays) unless a start fraction is given."""
 import collections
 import csv
 import glob
@@ -14,12 +14,27 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:60]) for r in csv.DictReader(open(f))]
 rows.sort()
-# the replayed region = the longest run of launches without adam_k eager markers is hard to find; use a time window given
-# as the fraction of the span passed in argv[4:6] (default: 40%..70% of the trace span)
-lo_f = float(sys.argv[4]) if len(sys.argv) > 4 else 0.40
+# the replayed region is the densest stretch of the trace: with argv[4] = 'auto' (default) slide a window of n steps over the
+# span and keep the start with the most kernel time inside; a number instead places the window at that fraction of the span
+import bisect
 t0, t1 = rows[0][0], rows[-1][1]
-w0 = t0 + (t1 - t0) * lo_f
-w1 = w0 + n * ms_step * 1e6
+wlen = n * ms_step * 1e6
+arg = sys.argv[4] if len(sys.argv) > 4 else 'auto'
+if arg == 'auto':
+    starts = [r[0] for r in rows]
+    cum = [0]
+    for s_, e_, _ in rows:
+        cum.append(cum[-1] + e_ - s_)
+    best, w0 = -1, t0
+    cand = t0
+    while cand + wlen <= t1:
+        i0, i1 = bisect.bisect_left(starts, cand), bisect.bisect_left(starts, cand + wlen)
+        if cum[i1] - cum[i0] > best:
+            best, w0 = cum[i1] - cum[i0], cand
+        cand += ms_step * 1e6 / 4
+else:
+    w0 = t0 + (t1 - t0) * float(arg)
+w1 = w0 + wlen
 win = [r for r in rows if r[0] >= w0 and r[1] <= w1]
 busy = sum(e - s for s, e, _ in win)
 span = win[-1][1] - win[0][0]
