@@ -2566,7 +2566,8 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     const long base = p.rows3 ? (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows
                     : (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
-    long S = (1536 + base - 1) / base;            // aim at ~6 workgroups per CU
+    static const long wg_target = getenv("T2V_WGRAD_TARGET") ? atol(getenv("T2V_WGRAD_TARGET")) : 1536;
+    long S = (wg_target + base - 1) / base;       // aim at ~6 workgroups per CU
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
