@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2516.6           # 16 x the fp32 matrix rate (dense bf16, no sparsity); only used by --bf16
-GFLOP_PER_SAMPLE_AS_WRITTEN = 49.27      # reference-executed FLOPs per base sample, uncond, GP on
+# reference-executed GFLOP per base sample of one G+D iteration with GP on, keyed by (cond, size, channels)
+GFLOP_AS_WRITTEN = {(False, 64, 1): 49.27, (True, 64, 1): 54.9, (False, 128, 3): 196.6, (True, 128, 3): 219.3}
 
 
 class Params(object):
@@ -35,7 +36,7 @@ class Params(object):
     no_mean_discrim_loss = no_mean_gen_loss = True
 
 
-def build_models(dev, seed=100, cond=False):
+def build_models(dev, seed=100, cond=False, size=64, channels=1):
     if cond:
         from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
         from txt2vid_amd.models.tganv2_cond.discrim import MultiScaleDiscrim
@@ -50,8 +51,8 @@ def build_models(dev, seed=100, cond=False):
     np.random.seed(seed)
     torch.manual_seed(seed)
     kw = {'cond_dim': 256} if cond else {}
-    gen = MultiScaleGen(width=64, height=64, num_channels=1, **kw)
-    dis = MultiScaleDiscrim(num_channels=1, **kw)
+    gen = MultiScaleGen(width=size, height=size, num_channels=channels, **kw)
+    dis = MultiScaleDiscrim(num_channels=channels, **kw)
     init(gen, 'xavier')
     init(dis, 'xavier')
     gen.to(dev).train()
@@ -61,9 +62,9 @@ def build_models(dev, seed=100, cond=False):
     return gen, dis, optD, optG, MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss()), CondGan
 
 
-def synthetic_batches(batch, n, seed, dev):
+def synthetic_batches(batch, n, seed, dev, size=64, channels=1):
     from txt2vid_amd.data import SyntheticMovingDigits
-    ds = SyntheticMovingDigits(length=batch * n, seed=seed)
+    ds = SyntheticMovingDigits(length=batch * n, seed=seed, size=size, channels=channels)
     out = []
     for i in range(n):
         vids = torch.stack([ds[i * batch + j][0] for j in range(batch)], 0)          # [B,T,C,H,W]
@@ -133,6 +134,9 @@ def main():
                                                        'accumulation): an extra, NOT the precision the metric is quoted on')
     ap.add_argument('--cond', action='store_true', help='text-conditioned TGANv2 (BASELINE configs[2] shape) instead of '
                                                        'the unconditional configs[1] workload the metric is quoted on; with --bf16 = configs[2]')
+    ap.add_argument('--size', type=int, default=64, choices=(64, 128), help='frame side; 128 with --channels 3 --cond --bf16 --batch 16 '
+                                                                          '= the per-GPU share of BASELINE configs[4] (MSRVDC shape)')
+    ap.add_argument('--channels', type=int, default=1, choices=(1, 3))
     args = ap.parse_args()
 
     from txt2vid_amd import dist as tdist
@@ -153,7 +157,7 @@ def main():
     dev = torch.device('cuda', local)
 
     T0 = time.perf_counter()
-    gen, dis, optD, optG, losses, CondGan = build_models(dev, cond=args.cond)
+    gen, dis, optD, optG, losses, CondGan = build_models(dev, cond=args.cond, size=args.size, channels=args.channels)
     txt = tokens = None
     if args.cond:                    # Bi-LSTM sentence encoder (random init) + 8-token synthetic captions
         from txt2vid_amd.data import Vocab
@@ -169,7 +173,8 @@ def main():
         arenas = {'D': tdist.model_arena(dis, TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
         grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
     prm = Params()
-    pool = synthetic_batches(args.batch, 4, 100 + rank, dev)
+    prm.frame_sizes = [args.size // 8, args.size // 4, args.size // 2, args.size]
+    pool = synthetic_batches(args.batch, 4, 100 + rank, dev, args.size, args.channels)
     random.seed(100 + rank)
     np.random.seed(100 + rank)
     torch.manual_seed(100 + rank)
@@ -276,15 +281,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     gb = args.batch * world
-    if args.cond:
+    default_shape = args.size == 64 and args.channels == 1
+    if not default_shape:
+        workload = ('%s TGANv2 at the MSRVDC shape of BASELINE configs[4] ' % ('text-conditioned' if args.cond else 'unconditional'))
+    elif args.cond:
         workload = ('BASELINE configs[2]%s: text-conditioned TGANv2 (Bi-LSTM sentence codes, 2-D + 3-D non-local blocks) ' %
                     ('' if bf16 else ' shape at fp32'))
     else:
         workload = 'BASELINE configs[1]: unconditional TGANv2 '
-    workload += ('16x64x64x1, per-GPU batch %d, %s, RSGAN + GP 0.5, Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid '
-                 '8/16/32/64' % (args.batch, 'bf16 compute' if bf16 else 'fp32'))
+    workload += ('16x%dx%dx%d, per-GPU batch %d, %s, RSGAN + GP 0.5, Adam 2e-4 (0.5,0.999), 1 D + 1 G step, subsample_input pyramid %s'
+                 % (args.size, args.size, args.channels, args.batch, 'bf16 compute' if bf16 else 'fp32', '/'.join(map(str, prm.frame_sizes))))
+    gf = GFLOP_AS_WRITTEN.get((bool(args.cond), args.size, args.channels))
     res = {
-        'metric': 'TGANv2 GAN train throughput (G+D steps x global batch), 16x64x64 videos/sec',
+        'metric': 'TGANv2 GAN train throughput (G+D steps x global batch), 16x%dx%d videos/sec' % (args.size, args.size),
         'value': gb * args.steps / dt, 'unit': 'videos/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'steps_per_sec': args.steps / dt, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
@@ -292,20 +301,20 @@ def main():
         'data': 'synthetic',
         'config': {'workload': workload,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
-                   'as_written_tflop_per_step': GFLOP_PER_SAMPLE_AS_WRITTEN * gb / 1e3},
+                   'as_written_tflop_per_step': gf * gb / 1e3 if gf else None},
         'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (3 graphs/step)',
-        'as_written_tflops': GFLOP_PER_SAMPLE_AS_WRITTEN * gb * args.steps / dt / 1e3,
+        'as_written_tflops': gf * gb * args.steps / dt / 1e3 if gf else None,
     }
     if grad_sync is not None:
         res['config']['grad_exchange_mb_per_step'] = sum(a.exchanged_bytes() for a in grad_sync.arenas.values()) / 1e6
     if roof is not None:
         res['roofline'] = roof
-    if rank == 0 and world == 1 and prof and not args.no_d_roofline:
+    if rank == 0 and world == 1 and prof and not args.no_d_roofline and default_shape:
         # the north-star's own target line: D forward+backward on un-subsampled 16x64x64 clips
         from txt2vid_amd.util.roofline import d_fwdbwd_roofline
         log('D forward+backward roofline pass')
         res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond and default_shape:
         log('timing the CPU oracle on %d host threads' % host_threads())
         res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:
