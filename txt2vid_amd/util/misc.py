@@ -39,7 +39,8 @@ def limit_host_threads(reserve=4, cap=8):
     logical CPUs the default pool (one thread per logical CPU, spinning after every parallel region) starves the HIP
     runtime's submission thread: the replayed iteration took 41 ms instead of 21 ms (tools/cli_timing.py)."""
     import torch
-    n = max(1, min(cap, host_threads() - reserve))
+    ranks_here = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))      # one process per GPU shares the node's cores
+    n = max(1, min(cap, (host_threads() - reserve) // ranks_here))
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return n
