@@ -246,6 +246,33 @@ int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, 
                       float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B, int H,
                       void* stream);
 
+/* ---- text-encoder pre-training (txt2vid/train/txt.py:160-178: encode -> greedy / teacher-forced decode -> cross entropy;
+ *      models/txt/basic.py:49-101). The nn.LSTM / nn.Embedding / nn.Linear / nn.CrossEntropyLoss calls of the reference map to:
+ * t2v_lstm_train_step      the step of t2v_lstm_seq_step, keeping what the adjoint needs: (pointer, row stride) pairs address the
+ *                          state ENTERING (h_prev, c_prev) and LEAVING (h_next, c_next) the step inside [B,L,H] buffers (or h_n / c_n
+ *                          for the last step); gates_t receives the post-activation i,f,g,o of the step.
+ * t2v_lstm_train_step_bwd  adjoint of one step, called for the steps in reverse order. DH / DC [B,H] hold dL/dh, dL/dc of the state
+ *                          leaving the step and are updated in place. Unless `first`, DH is first rebuilt from the later step:
+ *                          samples that were active there get dG_later[b] . W_hh, carried samples keep DH. Then the gate adjoints
+ *                          (pre-activation, order i,f,g,o) go to dG_t and DC <- dc * f; samples with t >= lengths[b] get dG_t = 0.
+ *                          epilogue_only = 1 performs just the DH rebuild (gradient w.r.t. the initial state).
+ * t2v_embedding_bwd        dW[tokens[n]] += g[n], n in order, without atomics (fixed summation order); dW zero-filled by the caller.
+ * t2v_xent_fwd / _bwd      rows of nn.CrossEntropyLoss: loss[n] = lse[n] - x[n][target[n]];  dx = gloss[n] * (softmax(x[n]) - onehot).
+ * t2v_argmax_rows          greedy decoding (basic.py:86): first index of each row's maximum. */
+int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, int64_t hp_stride,
+                        const float* c_prev, int64_t cp_stride, float* h_next, int64_t hn_stride, float* c_next, int64_t cn_stride,
+                        float* out_t, int64_t ostride, float* gates_t, int64_t gstride, const int32_t* lengths, int t, int B, int H,
+                        void* stream);
+int t2v_lstm_train_step_bwd(const float* dout_t, int64_t ostride, const float* dG_later, int64_t gl_stride, int t_later,
+                            const float* w_hh, float* DH, float* DC, const float* gates_t, int64_t gstride, const float* c_in,
+                            int64_t ci_stride, const float* c_out, int64_t co_stride, float* dG_t, int64_t dg_stride,
+                            const int32_t* lengths, int t, int B, int H, int first, int epilogue_only, void* stream);
+int t2v_embedding_bwd(const float* g, const int32_t* tokens, float* dW, int64_t N, int E, int V, void* stream);
+int t2v_xent_fwd(const float* logits, const int32_t* target, float* loss_rows, float* lse, int64_t rows, int V, void* stream);
+int t2v_xent_bwd(const float* logits, const int32_t* target, const float* lse, const float* gloss_rows, float* dlogits, int64_t rows,
+                 int V, void* stream);
+int t2v_argmax_rows(const float* x, int32_t* idx, int64_t rows, int V, void* stream);
+
 /* ---- multi-job launches: the non-local block's small ops over all pyramid levels at once -------------------------
  * Up to 8 differently shaped jobs per call (HOST array; the descriptors travel in the kernel arguments). Field roles:
  *   T2V_MJ_SCALE            out = scalar[0] * a                         n = elements

@@ -396,10 +396,57 @@ def golden_losses():
     save('losses', **out)
 
 
+def golden_txt_pretrain():
+    """One iteration of the text auto-encoder pre-training exactly as train/txt.py:160-178 runs it — `encode`, `decode` from the
+    encoder's state (teacher-forced and greedy), `nn.CrossEntropyLoss` on `decoded.permute(0, 2, 1)`, backward — on a ragged
+    batch (lengths 7,6,6,4,2), V=37, recipe weights (encoder and decoder are ONE module)."""
+    out = {}
+    V, B = 37, 5
+    lengths = [7, 6, 6, 4, 2]
+    txt = Seq2Seq(vocab_size=V)
+    # matrices x4: with the plain xavier-scale recipe the logits are bias-dominated and greedy decoding emits one constant symbol
+    txt.load_state_dict({k: recipe_tensor('encoder.' + k.split('.', 1)[1], v.shape) * (4.0 if v.dim() >= 2 else 1.0)
+                         for k, v in txt.state_dict().items()})
+    tg = torch.Generator()
+    tg.manual_seed(4321)
+    sent = torch.zeros(B, lengths[0], dtype=torch.long)
+    for b, n in enumerate(lengths):
+        sent[b, :n] = torch.randint(4, V, (n,), generator=tg)
+        sent[b, 0], sent[b, n - 1] = 1, 2
+    out['tokens'] = sent.numpy()
+    out['lengths'] = np.array(lengths)
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    criteria = torch.nn.CrossEntropyLoss()
+    for tag, tf in (('tf', True), ('greedy', False)):
+        txt.zero_grad()
+        enc_out, hs, hn = txt.encode(sent, lengths=lengths)
+        packed = pack_padded_sequence(sent, lengths, batch_first=True)
+        targets, _ = pad_packed_sequence(packed, batch_first=True, total_length=lengths[0])
+        decoded, symbols = txt.decode(true_inputs=sent, initial_hidden=hs, max_seq_len=lengths[0], teacher_force=tf)
+        loss = criteria(decoded.permute(0, 2, 1), targets)
+        loss.backward()
+        out[tag + '_loss'] = np.float64(loss.item())
+        out[tag + '_sum_loss'] = np.float64(torch.nn.CrossEntropyLoss(reduction='sum')(decoded.permute(0, 2, 1), targets).item())
+        out[tag + '_decoded'] = npy(decoded)
+        out[tag + '_symbols'] = symbols.numpy()
+        out[tag + '_hn'] = npy(hn)
+        out[tag + '_enc_out'] = npy(enc_out)
+        out[tag + '_h_n'] = npy(hs[0])
+        out[tag + '_c_n'] = npy(hs[1])
+        pack_norms(tag + '_gn', {k: v for k, v in grad_norms(txt).items() if k.startswith('encoder.')}, out)
+        named = dict(txt.named_parameters())
+        for k in ('encoder.embed.weight', 'encoder.to_vocab.bias', 'encoder.lstm.bias_hh_l0', 'encoder.lstm.bias_ih_l3_reverse',
+                  'encoder.lstm.weight_hh_l1_reverse'):
+            out[tag + '_g_' + k] = npy(named[k].grad)
+    save('txt_pretrain', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond', 'losses']
+    which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond', 'losses', 'txt_pretrain']
     if 'losses' in which:
         golden_losses()
+    if 'txt_pretrain' in which:
+        golden_txt_pretrain()
     if 'layers' in which:
         golden_layers()
     if 'resnet3d' in which:

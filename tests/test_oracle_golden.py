@@ -272,3 +272,39 @@ def test_loss_zoo(golden, name):
         close(loss, g['%s.%d.loss' % (name, side)], rtol=1e-6, atol=1e-7)
         close(gr if gr is not None else torch.zeros_like(r), g['%s.%d.g_real' % (name, side)], rtol=1e-5, atol=1e-8)
         close(gf if gf is not None else torch.zeros_like(f), g['%s.%d.g_fake' % (name, side)], rtol=1e-5, atol=1e-8)
+
+
+def txt_params(V=37):
+    """The recipe the golden generator poured into the reference's Seq2Seq: matrices x4 (see make_golden.golden_txt_pretrain)."""
+    from oracle import txt_oracle as TO
+    P = {}
+    for k, shp in TO.seq2seq_shapes(V).items():
+        t = O.recipe_tensor(k, shp)
+        P[k] = (t * 4.0 if t.dim() >= 2 else t).requires_grad_(True)
+    return P
+
+
+@pytest.mark.parametrize('tag,teacher', [('tf', True), ('greedy', False)])
+def test_txt_pretrain(golden, tag, teacher):
+    """oracle/txt_oracle.py (explicit time loops) == the reference's Seq2Seq encode -> decode -> CrossEntropyLoss -> backward
+    (train/txt.py:160-178, models/txt/basic.py:49-101) on a ragged batch: loss, logits, greedy symbols, sentence code, per-key
+    gradient norms and five full gradients."""
+    from oracle import txt_oracle as TO
+    g = golden('txt_pretrain')
+    P = txt_params()
+    tokens, lengths = T(g['tokens']), [int(v) for v in g['lengths']]
+    out, (h_n, c_n), hn = TO.encode(P, tokens, lengths)
+    close(out, g[tag + '_enc_out'])
+    close(h_n, g[tag + '_h_n'])
+    close(c_n, g[tag + '_c_n'])
+    loss, decoded, symbols, hn = TO.pretrain_loss(P, tokens, lengths, teacher)
+    close(hn, g[tag + '_hn'])
+    close(decoded, g[tag + '_decoded'], rtol=2e-4, atol=2e-5)
+    assert (symbols.numpy() == g[tag + '_symbols']).all()
+    close(loss, g[tag + '_loss'], rtol=1e-5, atol=1e-6)
+    close(TO.pretrain_loss(P, tokens, lengths, teacher, reduction='sum')[0], g[tag + '_sum_loss'], rtol=1e-5, atol=1e-5)
+    loss.backward()
+    norms_close(P, g, tag + '_gn')
+    for k in ('encoder.embed.weight', 'encoder.to_vocab.bias', 'encoder.lstm.bias_hh_l0', 'encoder.lstm.bias_ih_l3_reverse',
+              'encoder.lstm.weight_hh_l1_reverse'):
+        close(P[k].grad, g[tag + '_g_' + k], rtol=1e-3, atol=1e-5)

@@ -123,6 +123,12 @@ SIGNATURES = {
     't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],
     't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
     't2v_lstm_seq_step': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _P],
+    't2v_lstm_train_step': [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P],
+    't2v_lstm_train_step_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    't2v_embedding_bwd': [_P, _P, _P, _L, _I, _I, _P],
+    't2v_xent_fwd': [_P, _P, _P, _P, _L, _I, _P],
+    't2v_xent_bwd': [_P, _P, _P, _P, _P, _L, _I, _P],
+    't2v_argmax_rows': [_P, _P, _L, _I, _P],
     't2v_multi_ws_floats': [_I, _P, _I],
     't2v_multi': [_I, _P, _I, _P, _P, _P],
     't2v_rsgan': [_P, _P, _P, _I, _P],

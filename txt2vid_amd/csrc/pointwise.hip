@@ -976,6 +976,195 @@ extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const fl
     return launch_status();
 }
 
+// ---------------------------------------------------------------- text-encoder PRE-training (txt2vid/train/txt.py:160-178)
+// Same step as lstm_seq_step_k with everything the backward needs kept: states live in [B,L,H] buffers indexed by the time
+// step they ENTER (h_prev / c_prev / h_next / c_next are (pointer, row stride) pairs, so the last step can write h_n / c_n
+// directly) and the post-activation gates of the step are stored (row stride gstride, order i,f,g,o).
+__global__ __launch_bounds__(256) void lstm_train_step_k(const float* __restrict__ xproj, long xs, const float* __restrict__ whh,
+                                                         const float* __restrict__ hp, long hps, const float* __restrict__ cp, long cps,
+                                                         float* __restrict__ hn, long hns, float* __restrict__ cn, long cns,
+                                                         float* __restrict__ out, long os, float* __restrict__ gates, long gs,
+                                                         const int32_t* __restrict__ lengths, int t, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, u = i - b * H;
+    const float* hrow = hp + (size_t)b * hps;
+    float acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = xproj[(size_t)b * xs + g * H + u];
+    for (int k = 0; k < H; ++k) {
+        const float hv = hrow[k];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += hv * whh[((size_t)g * H + u) * H + k];
+    }
+    const bool active = t < lengths[b];
+    const float gi = sigm(acc[0]), gf = sigm(acc[1]), gg = tanhf(acc[2]), go = sigm(acc[3]);
+    const float c0 = cp[(size_t)b * cps + u], h0 = hrow[u];
+    const float cc = gf * c0 + gi * gg;
+    const float hh = go * tanhf(cc);
+    float* gr = gates + (size_t)b * gs + u;
+    gr[0] = gi; gr[H] = gf; gr[2 * H] = gg; gr[3 * H] = go;
+    cn[(size_t)b * cns + u] = active ? cc : c0;
+    hn[(size_t)b * hns + u] = active ? hh : h0;
+    out[(size_t)b * os + u] = active ? hh : 0.f;
+}
+extern "C" int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, int64_t hp_stride,
+                                   const float* c_prev, int64_t cp_stride, float* h_next, int64_t hn_stride, float* c_next,
+                                   int64_t cn_stride, float* out_t, int64_t ostride, float* gates_t, int64_t gstride,
+                                   const int32_t* lengths, int t, int B, int H, void* st) {
+    if (!xproj_t || !w_hh || !h_prev || !c_prev || !h_next || !c_next || !out_t || !gates_t || !lengths || B < 1 || H < 1 || t < 0 ||
+        h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_train_step_k, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, S_(st), xproj_t, (long)xstride, w_hh, h_prev,
+               (long)hp_stride, c_prev, (long)cp_stride, h_next, (long)hn_stride, c_next, (long)cn_stride, out_t, (long)ostride, gates_t,
+               (long)gstride, lengths, t, B, H);
+    return launch_status();
+}
+
+// Adjoint of one step, walking the steps backwards. DH / DC [B,H] carry dL/dh and dL/dc of the state LEAVING the step.
+//   prologue: DH <- dL/d(state leaving this step) = (first ? DH as given (dL/dh_n)
+//                    : the later step was active for b ? dG_later[b] . W_hh (column u) : DH unchanged (state was carried))
+//   then (unless epilogue_only, which just finishes DH for the initial state):
+//   active: dh = DH + dout_t[b]; gate adjoints -> dG_t[b] (pre-activation, i,f,g,o); DC <- dc * f
+//   carried sample: dG_t[b] = 0, DC unchanged.
+// DH is read and written by the same thread only (in place).
+__global__ __launch_bounds__(256) void lstm_train_step_bwd_k(const float* __restrict__ dout, long os, const float* __restrict__ dG_later,
+                                                             long gls, int t_later, const float* __restrict__ whh, float* __restrict__ DH,
+                                                             float* __restrict__ DC, const float* __restrict__ gates, long gs,
+                                                             const float* __restrict__ c_in, long cis, const float* __restrict__ c_out,
+                                                             long cos_, float* __restrict__ dG, long dgs,
+                                                             const int32_t* __restrict__ lengths, int t, int B, int H, int first,
+                                                             int epilogue_only) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, u = i - b * H;
+    const int len = lengths[b];
+    float dh_state = DH[i];
+    if (!first && t_later < len) {
+        const float* gl = dG_later + (size_t)b * gls;
+        float a = 0.f;
+        for (int j = 0; j < 4 * H; ++j) a += gl[j] * whh[(size_t)j * H + u];
+        dh_state = a;
+        DH[i] = a;
+    }
+    if (epilogue_only) return;
+    float* dg = dG + (size_t)b * dgs + u;
+    if (t >= len) { dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f; return; }
+    const float* gr = gates + (size_t)b * gs + u;
+    const float gi = gr[0], gf = gr[H], gg = gr[2 * H], go = gr[3 * H];
+    const float dh = dh_state + (dout ? dout[(size_t)b * os + u] : 0.f);
+    const float tc = tanhf(c_out[(size_t)b * cos_ + u]);
+    const float dc = DC[i] + dh * go * (1.f - tc * tc);
+    dg[0] = dc * gg * gi * (1.f - gi);
+    dg[H] = dc * c_in[(size_t)b * cis + u] * gf * (1.f - gf);
+    dg[2 * H] = dc * gi * (1.f - gg * gg);
+    dg[3 * H] = dh * tc * go * (1.f - go);
+    DC[i] = dc * gf;
+}
+extern "C" int t2v_lstm_train_step_bwd(const float* dout_t, int64_t ostride, const float* dG_later, int64_t gl_stride, int t_later,
+                                       const float* w_hh, float* DH, float* DC, const float* gates_t, int64_t gstride,
+                                       const float* c_in, int64_t ci_stride, const float* c_out, int64_t co_stride, float* dG_t,
+                                       int64_t dg_stride, const int32_t* lengths, int t, int B, int H, int first, int epilogue_only,
+                                       void* st) {
+    if (!w_hh || !DH || !DC || !lengths || B < 1 || H < 1 || (!first && !dG_later)) return T2V_EINVAL;
+    if (!epilogue_only && (!gates_t || !c_in || !c_out || !dG_t || t < 0)) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_train_step_bwd_k, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, S_(st), dout_t, (long)ostride, dG_later,
+               (long)gl_stride, t_later, w_hh, DH, DC, gates_t, (long)gstride, c_in, (long)ci_stride, c_out, (long)co_stride, dG_t,
+               (long)dg_stride, lengths, t, B, H, first, epilogue_only);
+    return launch_status();
+}
+
+// dW[tok[n]] += g[n] for n = 0..N-1 in order (no atomics: a thread owns column e of the vocabulary rows v with v % P == p and
+// walks the tokens sequentially, so repeated tokens add up in a fixed order). dW must be zero-filled (or hold the value to add to).
+__global__ __launch_bounds__(256) void embedding_bwd_k(const float* __restrict__ g, const int32_t* __restrict__ tok, float* __restrict__ dW,
+                                                       long N, int E, int V, int P) {
+    const int p = blockIdx.y;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256)
+        for (long n = 0; n < N; ++n) {
+            const int v = tok[n];
+            if (v % P == p && (unsigned)v < (unsigned)V) dW[(size_t)v * E + e] += g[n * E + e];
+        }
+}
+extern "C" int t2v_embedding_bwd(const float* g, const int32_t* tokens, float* dW, int64_t N, int E, int V, void* st) {
+    if (!g || !tokens || !dW || N < 1 || E < 1 || V < 1) return T2V_EINVAL;
+    const int P = V < 16 ? V : 16;
+    T2V_LAUNCH(embedding_bwd_k, dim3((unsigned)((E + 255) / 256), (unsigned)P), dim3(256), 0, S_(st), g, tokens, dW, (long)N, E, V, P);
+    return launch_status();
+}
+
+// Cross entropy rows (nn.CrossEntropyLoss, train/txt.py:158,172): one workgroup per row.
+//   forward: lse[n] = log sum_v exp(x[n][v]); loss[n] = lse[n] - x[n][target[n]]
+//   backward: dx[n][v] = gl[n] * (exp(x[n][v] - lse[n]) - [v == target[n]])
+__global__ __launch_bounds__(256) void xent_fwd_k(const float* __restrict__ x, const int32_t* __restrict__ target, float* __restrict__ loss,
+                                                  float* __restrict__ lse, int V) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const float* row = x + (size_t)blockIdx.x * V;
+    float m = -3.4e38f;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, row[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    m = bc;
+    float acc = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) acc += expf(row[v] - m);
+    __syncthreads();
+    const float ssum = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float l = m + logf(ssum);
+        lse[blockIdx.x] = l;
+        loss[blockIdx.x] = l - row[target[blockIdx.x]];
+    }
+}
+__global__ __launch_bounds__(256) void xent_bwd_k(const float* __restrict__ x, const int32_t* __restrict__ target, const float* __restrict__ lse,
+                                                  const float* __restrict__ gl, float* __restrict__ dx, int V) {
+    const size_t base = (size_t)blockIdx.x * V;
+    const float l = lse[blockIdx.x], g = gl[blockIdx.x];
+    const int tg = target[blockIdx.x];
+    for (int v = threadIdx.x; v < V; v += 256) dx[base + v] = g * (expf(x[base + v] - l) - (v == tg ? 1.f : 0.f));
+}
+extern "C" int t2v_xent_fwd(const float* logits, const int32_t* target, float* loss_rows, float* lse, int64_t rows, int V, void* st) {
+    if (!logits || !target || !loss_rows || !lse || rows < 1 || V < 1) return T2V_EINVAL;
+    T2V_LAUNCH(xent_fwd_k, dim3((unsigned)rows), dim3(256), 0, S_(st), logits, target, loss_rows, lse, V);
+    return launch_status();
+}
+extern "C" int t2v_xent_bwd(const float* logits, const int32_t* target, const float* lse, const float* gloss_rows, float* dlogits,
+                            int64_t rows, int V, void* st) {
+    if (!logits || !target || !lse || !gloss_rows || !dlogits || rows < 1 || V < 1) return T2V_EINVAL;
+    T2V_LAUNCH(xent_bwd_k, dim3((unsigned)rows), dim3(256), 0, S_(st), logits, target, lse, gloss_rows, dlogits, V);
+    return launch_status();
+}
+// greedy decoding (txt/basic.py:86: outputs.max(1)): first index of the row maximum
+__global__ __launch_bounds__(256) void argmax_rows_k(const float* __restrict__ x, int32_t* __restrict__ idx, int V) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* row = x + (size_t)blockIdx.x * V;
+    float m = -3.4e38f;
+    int mi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float f = row[v];
+        if (f > m) { m = f; mi = v; }
+    }
+    sv[threadIdx.x] = m; si[threadIdx.x] = mi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float a = sv[threadIdx.x + o];
+            const int ai = si[threadIdx.x + o];
+            if (a > sv[threadIdx.x] || (a == sv[threadIdx.x] && ai < si[threadIdx.x])) { sv[threadIdx.x] = a; si[threadIdx.x] = ai; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) idx[blockIdx.x] = si[0] == 0x7fffffff ? 0 : si[0];
+}
+extern "C" int t2v_argmax_rows(const float* x, int32_t* idx, int64_t rows, int V, void* st) {
+    if (!x || !idx || rows < 1 || V < 1) return T2V_EINVAL;
+    T2V_LAUNCH(argmax_rows_k, dim3((unsigned)rows), dim3(256), 0, S_(st), x, idx, V);
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- multi-job launches (non-local block over pyramid levels)
 // The non-local block runs the same tiny op on every pyramid level (and on the real||fake and x-hat members of a level):
 // up to 8 differently shaped jobs share ONE launch; the job descriptors travel in the kernel arguments and a workgroup

@@ -2146,6 +2146,209 @@ def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bi
         return out, (h_n, c_n)
 
 
+# ------------------------------------------------------------------------------------------------
+# text-encoder pre-training (train/txt.py:160-178): differentiable LSTM direction, embedding, cross entropy, arg-max
+# ------------------------------------------------------------------------------------------------
+
+def _ptr(t, off_floats=0):
+    return C.c_void_p(t.data_ptr() + 4 * off_floats)
+
+
+class LstmDirFn(Function):
+    """One direction of one nn.LSTM layer over a padded batch with pack_padded_sequence semantics (samples past their length keep
+    their state and emit zeros). xproj [B,L,4H] = x W_ih^T + b_ih + b_hh for all time steps (one GEMM, outside), w_hh [4H,H],
+    h0 / c0 [B,H]. Returns (out [B,L,H], h_n, c_n). One small launch per time step in each sweep; the recurrent weight gradient
+    is one GEMM over all steps."""
+
+    @staticmethod
+    def forward(ctx, xproj, w_hh, h0, c0, len_dev, reverse):
+        xproj, w_hh, h0, c0 = _c(xproj), _c(w_hh), _c(h0), _c(c0)
+        B, L, H4 = xproj.shape
+        H = H4 // 4
+        dev = xproj.device
+        hprev = torch.empty((B, L, H), device=dev, dtype=torch.float32)      # state ENTERING time step t
+        cprev = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+        gates = torch.empty((B, L, H4), device=dev, dtype=torch.float32)
+        out = torch.empty((B, L, H), device=dev, dtype=torch.float32)
+        h_n = torch.empty((B, H), device=dev, dtype=torch.float32)
+        c_n = torch.empty((B, H), device=dev, dtype=torch.float32)
+        order = list(range(L - 1, -1, -1)) if reverse else list(range(L))
+        _copy2d(h0, 0, H, hprev, order[0] * H, L * H, B, H)
+        _copy2d(c0, 0, H, cprev, order[0] * H, L * H, B, H)
+        for s_, t in enumerate(order):
+            last = s_ == L - 1
+            tn = t if last else order[s_ + 1]
+            check(lib().t2v_lstm_train_step(_ptr(xproj, t * H4), L * H4, _p(w_hh), _ptr(hprev, t * H), L * H, _ptr(cprev, t * H), L * H,
+                                            _p(h_n) if last else _ptr(hprev, tn * H), H if last else L * H,
+                                            _p(c_n) if last else _ptr(cprev, tn * H), H if last else L * H,
+                                            _ptr(out, t * H), L * H, _ptr(gates, t * H4), L * H4, _p(len_dev), t, B, H, _stream()),
+                  't2v_lstm_train_step')
+        ctx.save_for_backward(w_hh, hprev, cprev, gates, c_n, len_dev)
+        ctx.order = order
+        return out, h_n, c_n
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out, d_hn, d_cn):
+        w_hh, hprev, cprev, gates, c_n, len_dev = ctx.saved_tensors
+        order = ctx.order
+        B, L, H = hprev.shape
+        H4 = 4 * H
+        dev = hprev.device
+        DH = _c(d_hn).clone() if d_hn is not None else _zeros_like(c_n)
+        DC = _c(d_cn).clone() if d_cn is not None else _zeros_like(c_n)
+        d_out = _c(d_out) if d_out is not None else None
+        dG = torch.empty((B, L, H4), device=dev, dtype=torch.float32)
+        for s_ in range(L - 1, -1, -1):
+            t = order[s_]
+            first = s_ == L - 1
+            tl = t if first else order[s_ + 1]
+            check(lib().t2v_lstm_train_step_bwd(_ptr(d_out, t * H) if d_out is not None else None, L * H,
+                                                None if first else _ptr(dG, tl * H4), L * H4, tl, _p(w_hh), _p(DH), _p(DC),
+                                                _ptr(gates, t * H4), L * H4, _ptr(cprev, t * H), L * H,
+                                                _p(c_n) if first else _ptr(cprev, tl * H), H if first else L * H,
+                                                _ptr(dG, t * H4), L * H4, _p(len_dev), t, B, H, int(first), 0, _stream()),
+                  't2v_lstm_train_step_bwd')
+        dw = dh0 = dc0 = None
+        if ctx.needs_input_grad[1]:
+            dw = _bmm_raw(dG.view(1, B * L, H4), hprev.view(1, B * L, H), H4, H, B * L, True, False).view(H4, H)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            t0 = order[0]            # finish DH for the state entering the first step; DC already is dL/dc0
+            check(lib().t2v_lstm_train_step_bwd(None, 0, _ptr(dG, t0 * H4), L * H4, t0, _p(w_hh), _p(DH), _p(DC), None, 0, None, 0,
+                                                None, 0, None, 0, _p(len_dev), 0, B, H, 0, 1, _stream()), 't2v_lstm_train_step_bwd')
+            dh0, dc0 = DH, DC
+        return dG, dw, dh0, dc0, None, None
+
+
+def lstm_direction(xproj, w_hh, h0, c0, len_dev, reverse=False):
+    return LstmDirFn.apply(xproj, w_hh, h0, c0, len_dev, bool(reverse))
+
+
+class EmbeddingFn(Function):
+    """nn.Embedding lookup: weight[tokens] -> [N,E]; the adjoint adds rows in token order without atomics."""
+
+    @staticmethod
+    def forward(ctx, weight, tok_dev):
+        weight = _c(weight)
+        ctx.save_for_backward(tok_dev)
+        ctx.shape = tuple(weight.shape)
+        N = tok_dev.numel()
+        out = torch.empty((N, weight.shape[1]), device=weight.device, dtype=torch.float32)
+        check(lib().t2v_gather_rows(_p(weight), _p(tok_dev), _p(out), N, weight.shape[1], 0, _stream()), 't2v_gather_rows')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        tok_dev, = ctx.saved_tensors
+        V, E = ctx.shape
+        dW = torch.empty((V, E), device=g.device, dtype=torch.float32)
+        check(lib().t2v_fill(_p(dW), 0.0, dW.numel(), _stream()), 't2v_fill')
+        check(lib().t2v_embedding_bwd(_p(_c(g)), _p(tok_dev), _p(dW), tok_dev.numel(), E, V, _stream()), 't2v_embedding_bwd')
+        return dW, None
+
+
+def embedding(weight, tokens):
+    """tokens: integer tensor of any shape (host or device) -> [tokens.numel(), E]."""
+    tok = tokens.reshape(-1).to(device=weight.device, dtype=torch.int32).contiguous()
+    return EmbeddingFn.apply(weight, tok)
+
+
+class XentRows(Function):
+    """Per-row cross entropy of logits [N,V] against int targets [N] (nn.CrossEntropyLoss before its reduction)."""
+
+    @staticmethod
+    def forward(ctx, logits, tgt_dev):
+        logits = _c(logits)
+        N, V = logits.shape
+        loss = torch.empty((N,), device=logits.device, dtype=torch.float32)
+        lse = torch.empty((N,), device=logits.device, dtype=torch.float32)
+        check(lib().t2v_xent_fwd(_p(logits), _p(tgt_dev), _p(loss), _p(lse), N, V, _stream()), 't2v_xent_fwd')
+        ctx.save_for_backward(logits, tgt_dev, lse)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, tgt_dev, lse = ctx.saved_tensors
+        N, V = logits.shape
+        dx = torch.empty_like(logits)
+        check(lib().t2v_xent_bwd(_p(logits), _p(tgt_dev), _p(lse), _p(_c(g)), _p(dx), N, V, _stream()), 't2v_xent_bwd')
+        return dx, None
+
+
+def cross_entropy(logits, targets, reduction='mean'):
+    """nn.CrossEntropyLoss()(logits [N,V], targets [N]) with reduction 'mean' (train/txt.py:158) or 'sum' (:55)."""
+    tgt = targets.reshape(-1).to(device=logits.device, dtype=torch.int32).contiguous()
+    rows = XentRows.apply(logits, tgt)
+    return vec_sum(rows, 1.0 / rows.numel() if reduction == 'mean' else 1.0)
+
+
+def argmax_rows(logits):
+    """logits [N,V] -> int64 [N] (first index of each row's maximum)."""
+    logits = _c(logits.detach())
+    idx = torch.empty((logits.shape[0],), device=logits.device, dtype=torch.int32)
+    check(lib().t2v_argmax_rows(_p(logits), _p(idx), logits.shape[0], logits.shape[1], _stream()), 't2v_argmax_rows')
+    return idx.to(torch.int64)
+
+
+class StackSteps(Function):
+    """torch.stack(steps, 1) for T tensors [B,V] -> [B,T,V] (basic.py:98)."""
+
+    @staticmethod
+    def forward(ctx, *steps):
+        T = len(steps)
+        B, V = steps[0].shape
+        out = torch.empty((B, T, V), device=steps[0].device, dtype=torch.float32)
+        for i, st in enumerate(steps):
+            _copy2d(_c(st), 0, V, out, i * V, T * V, B, V)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, V = g.shape
+        g2 = g.reshape(B, T * V)
+        return tuple(SliceCols.apply(g2, i * V, V) if ctx.needs_input_grad[i] else None for i in range(T))
+
+
+def stack_steps(steps):
+    return StackSteps.apply(*steps)
+
+
+def lstm_stack(x, lengths_dev, lstm, hidden_size, num_layers, bidirectional, initial_state=None):
+    """Differentiable multi-layer (bi-)LSTM over a padded batch: x [B,L,In] -> (out [B,L,D*H], (h_n, c_n) [layers*D,B,H]) like
+    nn.LSTM on a packed batch (lengths sorted descending). `lstm` is the nn.LSTM holding the parameters."""
+    B, L = int(x.shape[0]), int(x.shape[1])
+    H, D = hidden_size, (2 if bidirectional else 1)
+    if initial_state is not None:
+        for part in initial_state:
+            if len(part) != num_layers * D or any(tuple(t.shape) != (B, H) for t in part):
+                raise ValueError('initial state must be %d tensors of shape [%d, %d] per (h, c); got %s'
+                                 % (num_layers * D, B, H, [tuple(t.shape) for t in part]))
+    inp = x.reshape(B * L, -1)
+    hs, cs = [], []
+    zero = None
+    for layer in range(num_layers):
+        outs = []
+        for d in range(D):
+            sfx = '_l%d%s' % (layer, '_reverse' if d else '')
+            bias = add(getattr(lstm, 'bias_ih' + sfx), getattr(lstm, 'bias_hh' + sfx))
+            xproj = linear(inp, getattr(lstm, 'weight_ih' + sfx), bias).view(B, L, 4 * H)
+            if initial_state is None:
+                if zero is None:
+                    zero = torch.empty((B, H), device=x.device, dtype=torch.float32)
+                    check(lib().t2v_fill(_p(zero), 0.0, zero.numel(), _stream()), 't2v_fill')
+                h0 = c0 = zero
+            else:
+                h0, c0 = initial_state[0][layer * D + d], initial_state[1][layer * D + d]
+            o, h_n, c_n = lstm_direction(xproj, getattr(lstm, 'weight_hh' + sfx), h0, c0, lengths_dev, reverse=bool(d))
+            outs.append(o.view(B * L, H))
+            hs.append(h_n)
+            cs.append(c_n)
+        inp = outs[0] if D == 1 else cat_features(outs[0], outs[1])
+    return inp.view(B, L, D * H), (hs, cs)
+
+
 def head_rows(x, n):
     """x[0:n] — a leading-rows slice of a contiguous tensor is a view (no kernel, no copy)."""
     return x[0:n]
