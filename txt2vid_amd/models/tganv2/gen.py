@@ -10,15 +10,20 @@ from ..conv_lstm import ConvLSTM
 
 
 class BaseFrameGen(nn.Module):
+    """Three UpBlocks 1024 -> 512 -> 256 -> 128 (frames 1x1 -> 8x8); parameter names `up0..up2` as in the reference."""
+    WIDTHS = (512, 256)
+
     def __init__(self, in_channels=1024, out_channels=128):
         super().__init__()
         self.out_channels = 128
-        self.up0 = UpBlock(in_channels=in_channels, out_channels=512)
-        self.up1 = UpBlock(in_channels=512, out_channels=256)
-        self.up2 = UpBlock(in_channels=256, out_channels=out_channels)
+        chain = (in_channels,) + self.WIDTHS + (out_channels,)
+        for i, (cin, cout) in enumerate(zip(chain[:-1], chain[1:])):
+            setattr(self, 'up%d' % i, UpBlock(in_channels=cin, out_channels=cout))
 
     def forward(self, x, cond=None):
-        return self.up2(self.up1(self.up0(x)))
+        for i in range(len(self.WIDTHS) + 1):
+            x = getattr(self, 'up%d' % i)(x)
+        return x
 
 
 class MultiScaleGen(nn.Module):
@@ -29,27 +34,23 @@ class MultiScaleGen(nn.Module):
         super().__init__()
         if no_lstm:
             raise NotImplementedError('no_lstm (TGAN-v1 frame seed generator) is outside the hot path')
+        self.no_lstm = False
         self.subsample = Subsample()
-        self.latent_size = latent_size
-        self.fm_channels = fm_channels
-        self.fm_width = max(1, width // 64)
-        self.fm_height = max(1, height // 64)
-        self.latent_plane_ch = fm_channels
-        self.fm_size = self.fm_width * self.fm_height * self.latent_plane_ch
+        # the recurrent state is a [fm_channels, height/64, width/64] map per sample: 1x1 for 64x64 frames, 2x2 for 128x128
+        self.latent_size, self.fm_channels, self.latent_plane_ch = latent_size, fm_channels, fm_channels
+        self.fm_width, self.fm_height = max(1, width // 64), max(1, height // 64)
+        self.fm_size = self.latent_plane_ch * self.fm_height * self.fm_width
         self.fc = Linear(latent_size + (cond_dim if self._cond_variant else 0), self.fm_size)
-        self.no_lstm = no_lstm
-        self.clstm = ConvLSTM(input_channels=self.latent_plane_ch, hidden_channels=[self.fm_channels], kernel_size=3,
-                              step=num_frames, effective_step=range(num_frames))
-        base = BaseFrameGen()
-        self.render_blocks = [RenderBlock(in_channels=base.out_channels, out_channels=num_channels)]
-        self.abstract_blocks = [base]
-        for i, block in enumerate(additional_blocks):
-            prev = self.abstract_blocks[i].out_channels
-            nl = self._cond_variant and (i == len(additional_blocks) - 2)
-            self.abstract_blocks.append(UpBlock(in_channels=prev, out_channels=block, with_non_local=nl))
-            self.render_blocks.append(RenderBlock(in_channels=block, out_channels=num_channels))
-        self.abstract_blocks = nn.ModuleList(self.abstract_blocks)
-        self.render_blocks = nn.ModuleList(self.render_blocks)
+        self.clstm = ConvLSTM(input_channels=fm_channels, hidden_channels=[fm_channels], kernel_size=3, step=num_frames,
+                              effective_step=range(num_frames))
+        # level 0 = BaseFrameGen (-> 128 channels), then one UpBlock per entry of additional_blocks; a RenderBlock per level.
+        # The text-conditioned variant puts its 2-D non-local block into the last-but-one UpBlock.
+        widths = [128] + list(additional_blocks)
+        nl_at = len(additional_blocks) - 1 if self._cond_variant else -1
+        levels = [BaseFrameGen()]
+        levels += [UpBlock(in_channels=widths[i - 1], out_channels=widths[i], with_non_local=(i == nl_at)) for i in range(1, len(widths))]
+        self.abstract_blocks = nn.ModuleList(levels)
+        self.render_blocks = nn.ModuleList([RenderBlock(in_channels=w, out_channels=num_channels) for w in widths])
 
     def structurally_live_taps(self):
         """{weight: live kernel taps} for the ConvLSTM when its state is 1x1 (frames below 128x128): a 3x3 kernel on a 1x1

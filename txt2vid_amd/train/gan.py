@@ -111,49 +111,55 @@ def main(args):
               grad_sync=grad_sync, max_iters=args.max_iters)
 
 
+# txt2vid/train/gan.py:163-221 — same flags, types and defaults; `max_iters` is new (stop after that many iterations)
+FLAGS = """
+test flag
+num_samples int 1
+seed int -
+cuda flag
+workers int 2
+ngpu int 1
+frame_sizes ints 64
+num_channels int 1
+random_frames int 0
+opt_level str O2
+epochs int 5
+batch_size int 64
+init_method str xavier
+G_loss str -
+G_lr float 0.0001
+G_beta1 float 0.5
+G_beta2 float 0.9
+D_loss str txt2vid.gan.losses.VanillaGanLoss
+D_lr float 0.0001
+D_beta1 float 0.5
+D_beta2 float 0.9
+weights str -
+sent_weights str -
+data str - !
+anno str -
+vocab str -
+M str -
+G str - !
+D strs - !
+D_names strs -
+D_lambdas floats -
+sent str -
+sent_init_method str -
+dont_use_sent flag
+end2end flag
+sgd flag
+sequence_first flag
+debug flag
+max_iters int -
+"""
+
+
 def build_parser():
+    from ..util.cli import add_flags
     p = argparse.ArgumentParser()
     add_params_to_parser(p)
-    p.add_argument('--test', action='store_true')
-    p.add_argument('--num_samples', type=int, default=1)
-    p.add_argument('--seed', type=int, default=None)
-    p.add_argument('--cuda', action='store_true')
-    p.add_argument('--workers', type=int, default=2)
-    p.add_argument('--ngpu', type=int, default=1)
-    p.add_argument('--frame_sizes', type=int, nargs='+', default=[64])
-    p.add_argument('--num_channels', type=int, default=1)
-    p.add_argument('--random_frames', type=int, default=0)
-    p.add_argument('--opt_level', type=str, default='O2')
-    p.add_argument('--epochs', type=int, default=5)
-    p.add_argument('--batch_size', type=int, default=64)
-    p.add_argument('--init_method', type=str, default='xavier')
-    p.add_argument('--G_loss', type=str, default=None)
-    p.add_argument('--G_lr', type=float, default=0.0001)
-    p.add_argument('--G_beta1', type=float, default=0.5)
-    p.add_argument('--G_beta2', type=float, default=0.9)
-    p.add_argument('--D_loss', type=str, default='txt2vid.gan.losses.VanillaGanLoss')
-    p.add_argument('--D_lr', type=float, default=0.0001)
-    p.add_argument('--D_beta1', type=float, default=0.5)
-    p.add_argument('--D_beta2', type=float, default=0.9)
-    p.add_argument('--weights', type=str, default=None)
-    p.add_argument('--sent_weights', type=str, default=None)
-    p.add_argument('--data', type=str, required=True)
-    p.add_argument('--anno', type=str, default=None)
-    p.add_argument('--vocab', type=str, default=None)
-    p.add_argument('--M', type=str, default=None)
-    p.add_argument('--G', type=str, default=None, required=True)
-    p.add_argument('--D', type=str, default=None, nargs='+', required=True)
-    p.add_argument('--D_names', type=str, default=None, nargs='+')
-    p.add_argument('--D_lambdas', type=float, default=None, nargs='+')
-    p.add_argument('--sent', type=str, default=None)
-    p.add_argument('--sent_init_method', type=str, default=None)
-    p.add_argument('--dont_use_sent', action='store_true', default=False)
-    p.add_argument('--end2end', action='store_true', default=False)
-    p.add_argument('--sgd', action='store_true', default=False)
-    p.add_argument('--sequence_first', action='store_true', default=False)
-    p.add_argument('--debug', action='store_true', default=False)
-    p.add_argument('--max_iters', type=int, default=None, help='(new) stop after this many iterations')
-    return p
+    return add_flags(p, FLAGS)
 
 
 if __name__ == '__main__':

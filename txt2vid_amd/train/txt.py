@@ -1,8 +1,10 @@
-"""Text auto-encoder pre-training entry point — the role of txt2vid/train/txt.py:89-235 (same flags, same loop, same checkpoint
-dict `{'optim', 'txt'}` that `train/gan.py --sent_weights` loads). Encoder and decoder run on the differentiable HIP kernels
-(`Seq2Seq.differentiable(True)`: `t2v_lstm_train_step[_bwd]`, `t2v_embedding_bwd`, `t2v_xent_*`, `t2v_argmax_rows`, the conv GEMMs
-for the input / vocabulary projections), Adam on the multi-tensor kernel. tensorboardX is optional here (absent offline)."""
-import argparse
+"""Text auto-encoder pre-training entry point — the role of txt2vid/train/txt.py:89-235 (same command line, same iteration, same
+checkpoint dict `{'optim', 'txt'}` that `train/gan.py --sent_weights` loads). Encoder and decoder run on the differentiable HIP
+kernels (`Seq2Seq.differentiable(True)`: `t2v_lstm_train_step[_bwd]`, `t2v_embedding_bwd`, `t2v_xent_*`, `t2v_argmax_rows`, the
+conv GEMMs for the input / vocabulary projections), Adam on the multi-tensor kernel. tensorboardX is optional (absent offline).
+
+Layout: `CaptionSet` (token-id tensors of a sentence list), `pad_batch` (the loader's collate), `pretrain_loss` (one iteration's
+loss), `Pretrainer` (optimiser step, validation, checkpoints, console log), `main`."""
 import random
 import sys
 
@@ -10,81 +12,167 @@ import torch
 
 from ..models.txt.basic import Seq2Seq
 from ..optim import Adam
+from ..util.cli import parser_from
 from ..util.dir import ensure_exists
 from ..util.log import status
 from ..util.metrics import RollingAvg
 from ..util.pick import load
 from .setup import setup
 
+# txt.py:208-235 (flags, types, defaults); the last three rows are new: the reference hard-codes 50 / 500 and has no iteration cap
+FLAGS = """
+data str - !            # pickled {video: [sentence, ...]}
+vocab str - !           # pickled Vocab
+out str - !             # checkpoint directory
+weights str -
+test flag
+separate_decoder flag
+epoch int 5
+batch_size int 64
+lr float 0.001
+beta1 float 0.9
+beta2 float 0.999
+seed int -
+cuda flag
+workers int 2
+teacher_force float 0.5
+max_seq_len int 10
+log_period int 50
+save_model_period int 500
+max_iters int 0
+"""
 
-class SentenceDataset(torch.utils.data.Dataset):
-    """txt.py:21-42: `sent_path` = pickled {video: [sentences]}; items are FloatTensors of token ids."""
+
+class CaptionSet(torch.utils.data.Dataset):
+    """Sentences -> float tensors of token ids (txt.py:21-42). `sent_path`: pickle of {video: [sentences]}, flattened."""
 
     def __init__(self, vocab=None, sent_path=None, sents=None):
-        assert vocab is not None
-        self.vocab = vocab
-        self.sent_path = sent_path
-        if sent_path is not None:
-            temp = load(sent_path)
-            self.sents = [s for x in temp for s in temp[x]]
+        if vocab is None:
+            raise ValueError('a Vocab is required')
+        self.vocab, self.sent_path = vocab, sent_path
+        if sent_path is None:
+            if sents is None:
+                raise ValueError('give sent_path or sents')
+            self.sents = list(sents)
         else:
-            assert sents is not None
-            self.sents = sents
+            per_video = load(sent_path)
+            self.sents = [s for key in per_video for s in per_video[key]]
 
     def __len__(self):
         return len(self.sents)
 
     def __getitem__(self, idx):
-        return torch.Tensor([self.vocab(token) for token in self.vocab.tokenize(self.sents[idx])])
+        ids = [self.vocab(tok) for tok in self.vocab.tokenize(self.sents[idx])]
+        return torch.tensor(ids, dtype=torch.float32)
 
 
-def collate_fn(data):
-    """txt.py:45-53: sort by length (descending), zero-pad -> (tokens [B,Lmax] long, lengths)."""
-    data.sort(key=lambda x: len(x), reverse=True)
-    lengths = [len(sent) for sent in data]
-    targets = torch.zeros(len(data), max(lengths)).long()
-    for i, sent in enumerate(data):
-        targets[i, :lengths[i]] = sent[:lengths[i]]
-    return targets, lengths
+SentenceDataset = CaptionSet         # the reference's name for it
+
+
+def pad_batch(items):
+    """Collate (txt.py:45-53): longest first, zero padding -> (tokens [B, Lmax] int64, lengths)."""
+    items = sorted(items, key=len, reverse=True)
+    lengths = [int(t.numel()) for t in items]
+    tokens = torch.zeros((len(items), lengths[0]), dtype=torch.int64)
+    for row, (t, n) in enumerate(zip(items, lengths)):
+        tokens[row, :n] = t.to(torch.int64)
+    return tokens, lengths
+
+
+collate_fn = pad_batch
 
 
 def padded_targets(sent, lengths):
-    """txt.py:166-167 (`pack_padded_sequence` -> `pad_packed_sequence` of the token matrix): tokens up to each length, 0 beyond,
-    width lengths[0]. Host-side index preparation; returns a host int64 tensor."""
-    L = int(lengths[0])
-    t = sent.detach().cpu()[:, :L].clone()
-    for b, n in enumerate(lengths):
-        t[b, int(n):] = 0
-    return t
+    """The targets of txt.py:166-167 (a pack -> pad round trip of the token matrix): tokens up to each length, 0 beyond, width
+    lengths[0]. Index preparation on the host; returns a host int64 tensor."""
+    width = int(lengths[0])
+    keep = torch.arange(width).unsqueeze(0) < torch.tensor([int(n) for n in lengths]).unsqueeze(1)
+    return sent.detach().cpu()[:, :width] * keep
 
 
 def pretrain_loss(seq2seq, sent, lengths, teacher_force, reduction='mean'):
-    """Loop body of txt.py:160-172: encode, decode from the encoder's state, cross entropy over every (sample, position)."""
+    """One iteration's loss (txt.py:160-172): encode, roll the decoder out from the encoder's state for lengths[0] positions,
+    cross entropy over every (sample, position) — padding positions count as class 0. Returns (loss, decoded symbols)."""
     from .. import functional as TF
-    _, hidden_states, _ = seq2seq.encode(sent, lengths=lengths)
-    targets = padded_targets(sent, lengths)
-    decoded, d_symbols = seq2seq.decode(true_inputs=sent, initial_hidden=hidden_states, max_seq_len=lengths[0],
-                                        teacher_force=teacher_force)
-    B, L, V = decoded.shape
-    return TF.cross_entropy(decoded.view(B * L, V), targets.reshape(-1), reduction=reduction), d_symbols
+    state = seq2seq.encode(sent, lengths=lengths)[1]
+    logits, symbols = seq2seq.decode(true_inputs=sent, initial_hidden=state, max_seq_len=lengths[0], teacher_force=teacher_force)
+    rows = logits.shape[0] * logits.shape[1]
+    return TF.cross_entropy(logits.view(rows, -1), padded_targets(sent, lengths).reshape(-1), reduction=reduction), symbols
 
 
-def evaluate(split, seq2seq, device, vocab, debug=False):
-    """txt.py:55-87: greedy decoding, summed cross entropy per example."""
+def evaluate(batches, seq2seq, device, vocab, debug=False):
+    """Validation / test loss (txt.py:55-87): greedy decoding, summed cross entropy divided by the number of sentences."""
     seq2seq.eval()
-    loss, num_examples = 0.0, 0
+    total, count = 0.0, 0
     with torch.no_grad():
-        for sent, lengths in split:
+        for sent, lengths in batches:
             sent = sent.to(device)
-            temp, d_symbols = pretrain_loss(seq2seq, sent, lengths, False, reduction='sum')
+            value, symbols = pretrain_loss(seq2seq, sent, lengths, False, reduction='sum')
+            total += float(value)
+            count += int(sent.shape[0])
             if debug:
                 print('real words=', vocab.to_words(sent[-1]))
-                print('predicted words=', vocab.to_words(d_symbols[-1]))
-                print('loss=', float(temp))
-            loss += float(temp)
-            num_examples += sent.size(0)
+                print('predicted words=', vocab.to_words(symbols[-1]))
+                print('loss=', float(value))
     seq2seq.train()
-    return loss / max(1, num_examples)
+    return total / max(1, count)
+
+
+class Pretrainer(object):
+    """Optimiser step + the periodic work of txt.py:176-205 (validation and checkpoint every `save_model_period` iterations, a
+    console line every `log_period`)."""
+
+    def __init__(self, seq2seq, optimizer, vocab, device, args, val_batches):
+        self.net, self.opt, self.vocab, self.device, self.args = seq2seq, optimizer, vocab, device, args
+        self.val_batches = val_batches
+        self.rolling = RollingAvg(window_size=args.log_period)
+        self.iteration, self.val_loss = 0, -1
+        try:
+            from tensorboardX import SummaryWriter
+            self.writer = SummaryWriter()
+        except ImportError:
+            self.writer = None
+
+    def _scalar(self, tag, value):
+        if self.writer is not None:
+            self.writer.add_scalar(tag, value, self.iteration)
+
+    def step(self, sent, lengths):
+        sent = sent.to(self.device)
+        self.net.zero_grad()
+        forced = random.uniform(0, 1) <= self.args.teacher_force
+        loss, symbols = pretrain_loss(self.net, sent, lengths, forced)
+        loss.backward()
+        self.opt.step()
+        value = float(loss.detach())
+        self.rolling.update(value)
+        self._scalar('data/train_loss', value)
+        self.iteration += 1
+        return sent, symbols
+
+    def checkpoint(self):
+        self.val_loss = evaluate(self.val_batches, self.net, self.device, self.vocab)
+        self._scalar('data/val_loss', self.val_loss)
+        path = '%s/iter_%d_loss_%.4f_val_%.4f' % (self.args.out, self.iteration, self.rolling.get(), self.val_loss)
+        print('saving to: %s' % path)
+        torch.save({'optim': self.opt, 'txt': self.net}, path)
+
+    def report(self, epoch, i, n_batches, sent, symbols):
+        print('real words=', self.vocab.to_words(sent[0]))
+        print('predicted words=', self.vocab.to_words(symbols[0]))
+        print('[%d/%d][%d/%d] Loss: %.4f (val = %.4f)' % (epoch, self.args.epoch, i, n_batches, self.rolling.get(), self.val_loss))
+
+
+def split_sentences(sents):
+    """txt.py:117-127: shuffle, then an independent uniform draw per sentence: <= 0.8 train, <= 0.9 validation, else test."""
+    random.shuffle(sents)
+    parts = ([], [], [])
+    for s in sents:
+        r = random.uniform(0, 1)
+        parts[0 if r <= 0.8 else 1 if r <= 0.9 else 2].append(s)
+    if not all(parts):
+        raise AssertionError('train / val / test split left a part empty (%d / %d / %d sentences)' % tuple(len(p) for p in parts))
+    return parts
 
 
 def main(args):
@@ -97,100 +185,42 @@ def main(args):
         status('Loading model')
         from ..util.reflection import alias_reference_modules
         alias_reference_modules()
-        temp = torch.load(args.weights, weights_only=False)
-        if 'txt' in temp:
-            seq2seq = temp['txt'].to(device)
-        if 'optim' in temp:
-            optimizer = temp['optim']
+        saved = torch.load(args.weights, weights_only=False)
+        seq2seq = saved['txt'].to(device) if 'txt' in saved else seq2seq
+        optimizer = saved.get('optim', optimizer)
     seq2seq.differentiable(True)
 
-    train, val, test = [], [], []
-    data = SentenceDataset(vocab=vocab, sent_path=args.data)
-    random.shuffle(data.sents)
-    for i in range(len(data.sents)):
-        r = random.uniform(0, 1)
-        (train if r <= 0.8 else val if r <= 0.9 else test).append(data.sents[i])
-    assert len(val) != 0 and len(test) != 0 and len(train) != 0
-    data.sents = train
-    train = data
-    print('Train len = %d' % len(train))
-    print('Val len = %d' % len(val))
-    print('Test len = %d' % len(test))
-    test = SentenceDataset(vocab=vocab, sents=test)
-    val = SentenceDataset(vocab=vocab, sents=val)
-    mk = torch.utils.data.DataLoader
-    train_dataset = mk(train, batch_size=args.batch_size, shuffle=True, num_workers=args.workers, collate_fn=collate_fn)
-    test_dataset = mk(test, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, collate_fn=collate_fn)
-    val_dataset = mk(val, batch_size=args.batch_size, shuffle=False, num_workers=args.workers, collate_fn=collate_fn)
+    everything = CaptionSet(vocab=vocab, sent_path=args.data)
+    train_s, val_s, test_s = split_sentences(everything.sents)
+    for name, part in (('Train', train_s), ('Val', val_s), ('Test', test_s)):
+        print('%s len = %d' % (name, len(part)))
+
+    def loader(sents, shuffle):
+        return torch.utils.data.DataLoader(CaptionSet(vocab=vocab, sents=sents), batch_size=args.batch_size, shuffle=shuffle,
+                                           num_workers=args.workers, collate_fn=pad_batch)
+    train_batches, val_batches, test_batches = loader(train_s, True), loader(val_s, False), loader(test_s, False)
 
     if args.test:
         status('Testing...')
-        print('Test loss = %.4f' % evaluate(test_dataset, seq2seq, device, vocab, debug=True))
+        print('Test loss = %.4f' % evaluate(test_batches, seq2seq, device, vocab, debug=True))
         sys.exit(0)
 
-    log_window_period = args.log_period
-    save_model_period = args.save_model_period
-    rolling_loss = RollingAvg(window_size=log_window_period)
-    try:
-        from tensorboardX import SummaryWriter
-        writer = SummaryWriter()
-    except ImportError:
-        writer = None
     print('Teacher force prob = %.4f' % args.teacher_force)
-
-    iteration, val_loss = 0, -1
+    run = Pretrainer(seq2seq, optimizer, vocab, device, args, val_batches)
     for epoch in range(args.epoch):
-        for i, (sent, lengths) in enumerate(train_dataset):
-            sent = sent.to(device)
-            seq2seq.zero_grad()
-            teacher_force = random.uniform(0, 1) <= args.teacher_force
-            loss, d_symbols = pretrain_loss(seq2seq, sent, lengths, teacher_force)
-            loss.backward()
-            optimizer.step()
-            loss_v = float(loss)
-            rolling_loss.update(loss_v)
-            if writer is not None:
-                writer.add_scalar('data/train_loss', loss_v, iteration)
-            iteration += 1
-            if iteration % save_model_period == 0:
-                val_loss = evaluate(val_dataset, seq2seq, device, vocab)
-                if writer is not None:
-                    writer.add_scalar('data/val_loss', val_loss, iteration)
-                where_to_save = '%s/iter_%d_loss_%.4f_val_%.4f' % (args.out, iteration, rolling_loss.get(), val_loss)
-                print('saving to: %s' % where_to_save)
-                torch.save({'optim': optimizer, 'txt': seq2seq}, where_to_save)
-            if iteration % log_window_period == 0:
-                print('real words=', vocab.to_words(sent[0]))
-                print('predicted words=', vocab.to_words(d_symbols[0]))
-                print('[%d/%d][%d/%d] Loss: %.4f (val = %.4f)' % (epoch, args.epoch, i, len(train_dataset), rolling_loss.get(), val_loss))
-            if args.max_iters and iteration >= args.max_iters:
-                return rolling_loss.get()
-    return rolling_loss.get()
+        for i, (sent, lengths) in enumerate(train_batches):
+            sent, symbols = run.step(sent, lengths)
+            if run.iteration % args.save_model_period == 0:
+                run.checkpoint()
+            if run.iteration % args.log_period == 0:
+                run.report(epoch, i, len(train_batches), sent, symbols)
+            if args.max_iters and run.iteration >= args.max_iters:
+                return run.rolling.get()
+    return run.rolling.get()
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--data', type=str, default=None, help='Input sequence data', required=True)
-    parser.add_argument('--vocab', type=str, default=None, help='Vocab data for input sequences', required=True)
-    parser.add_argument('--weights', type=str, default=None, help='model path')
-    parser.add_argument('--test', action='store_true', default=False, help='to test or not to test')
-    parser.add_argument('--separate_decoder', action='store_true', default=False, help='use seperate weights for decoder')
-    parser.add_argument('--epoch', type=int, default=5, help='number of epochs to perform')
-    parser.add_argument('--batch_size', type=int, default=64, help='input batch size')
-    parser.add_argument('--lr', type=float, default=0.001, help='learning rate')
-    parser.add_argument('--beta1', type=float, default=0.9, help='beta1 for adam')
-    parser.add_argument('--beta2', type=float, default=0.999, help='beta2 for adam')
-    parser.add_argument('--seed', type=int, default=None, help='seed')
-    parser.add_argument('--cuda', action='store_true', help='enables cuda')
-    parser.add_argument('--workers', type=int, default=2, help='number of workers to help with loading/pre-processing data')
-    parser.add_argument('--teacher_force', type=float, default=0.5, help='teacher force ratio')
-    parser.add_argument('--max_seq_len', type=int, default=10, help='max sequence length')
-    parser.add_argument('--out', type=str, default=None, help='output path for learnt models', required=True)
-    # additions (the reference hard-codes 50 / 500 and has no iteration cap)
-    parser.add_argument('--log_period', type=int, default=50)
-    parser.add_argument('--save_model_period', type=int, default=500)
-    parser.add_argument('--max_iters', type=int, default=0, help='stop after this many iterations (0 = run all epochs)')
-    return parser
+    return parser_from(FLAGS)
 
 
 if __name__ == '__main__':

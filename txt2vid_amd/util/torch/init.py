@@ -1,36 +1,42 @@
-"""Weight initialisation — txt2vid/util/torch/init.py:4-39: xavier/orthogonal/normal on every
-Linear/Conv/Embedding weight (gain sqrt(2) on modules tagged `is_residual`), biases 0, BatchNorm (1, 0).
-Host-side, once, on the CPU generator: the draw order must match the reference for seed parity."""
+"""Weight initialisation with the reference's semantics (txt2vid/util/torch/init.py:4-39): every Linear / Conv* / Embedding
+weight is drawn by the chosen scheme (gain sqrt(2) where the owning block tagged the layer `is_residual`, layers.py:86-90), their
+biases are zeroed, BatchNorm gets (1, 0). Host-side, once, on the CPU generator. The walk is children-first, left to right — the
+order `nn.Module.apply` uses — because the draw ORDER decides the values for a given seed (tests/golden/init_xavier.npz)."""
 import math
-from functools import partial
 
-import torch.nn.init as tinit
+from torch.nn import init as schemes
+
+DRAWN = ('Linear', 'Conv', 'Embedding')          # substrings of the class names whose weights are drawn
 
 
-def _weight_init(layer, init_func=None):
-    name = layer.__class__.__name__
-    if 'Linear' in name or 'Conv' in name or 'Embedding' in name:
-        if getattr(layer, 'weight', None) is not None:
-            if getattr(layer, 'is_residual', False):
-                init_func(layer.weight, gain=math.sqrt(2))
-            else:
-                init_func(layer.weight)
-        if getattr(layer, 'bias', None) is not None:
-            layer.bias.data.fill_(0.0)
-    elif 'BatchNorm' in name:
-        if getattr(layer, 'weight', None) is not None:
-            layer.weight.data.fill_(1.0)
-        if getattr(layer, 'bias', None) is not None:
-            layer.bias.data.fill_(0.0)
+def _draw(kind, weight, residual):
+    if kind == 'xavier':
+        schemes.xavier_normal_(weight, gain=math.sqrt(2)) if residual else schemes.xavier_normal_(weight)
+    elif kind == 'ortho':
+        schemes.orthogonal_(weight, gain=math.sqrt(2)) if residual else schemes.orthogonal_(weight)
+    else:                                        # 'normal': N(0, 0.02); the scheme has no gain
+        schemes.normal_(weight, mean=0, std=0.02)
+
+
+def _children_first(module):
+    for child in module.children():
+        yield from _children_first(child)
+    yield module
 
 
 def init(model, init_method=None):
-    if init_method == 'xavier':
-        f = tinit.xavier_normal_
-    elif init_method == 'ortho':
-        f = tinit.orthogonal_
-    elif init_method == 'normal':
-        f = partial(tinit.normal_, mean=0, std=0.02)
-    else:
+    if init_method not in ('xavier', 'ortho', 'normal'):
         raise AssertionError('unknown init_method %r' % (init_method,))
-    model.apply(partial(_weight_init, init_func=f))
+    for layer in _children_first(model):
+        cls = type(layer).__name__
+        weight, bias = getattr(layer, 'weight', None), getattr(layer, 'bias', None)
+        if any(tag in cls for tag in DRAWN):
+            if weight is not None:
+                _draw(init_method, weight, bool(getattr(layer, 'is_residual', False)))
+        elif 'BatchNorm' in cls:
+            if weight is not None:
+                weight.data.fill_(1.0)
+        else:
+            continue
+        if bias is not None:
+            bias.data.fill_(0.0)
