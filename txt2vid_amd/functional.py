@@ -321,7 +321,7 @@ def repack_params(params):
         hit[1] = _wtag(p)
     for fkey, fh in _fused_cache.items():
         if any(r() is p for r in fh[0] for p in params):
-            fh[1] = tuple(_wtag(w()) for w in fh[0] if w() is not None)
+            fh[1] = tuple(_wtag(w()) for w in fh[0] if w() is not None)      # members are whole-parameter views: same pointer
 
 
 _fused_cache = {}
@@ -330,13 +330,16 @@ _fused_cache = {}
 def packed_fused(ws, ts, mode):
     """ONE packed matrix for several same-shape weights applied to the same input (mode 0: outputs side by
     side -> wp[tap][Cin][n*Cout]) or whose data gradients add up (mode 1: wp[tap][n*Cout][Cin]).
-    Persistent and refreshed per member exactly like `packed_weight`."""
+    Persistent and refreshed per member exactly like `packed_weight` (the members usually arrive as 5-D views of the
+    parameters: the cache is keyed by the parameters behind them)."""
     n = len(ws)
     Cout, Cin = ws[0].shape[0], ws[0].shape[1]
-    key = (tuple(id(w) for w in ws), ts.mask, mode)
-    hit = _fused_cache.get(key)
-    tag = tuple(_wtag(w) for w in ws)
-    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
+    bases = [w._base if w._base is not None else w for w in ws]
+    cacheable = all(isinstance(b_, torch.nn.Parameter) for b_ in bases)
+    key = (tuple(id(b_) for b_ in bases), tuple(ws[0].shape), ts.mask, mode)
+    hit = _fused_cache.get(key) if cacheable else None
+    if hit is not None and all(r() is b_ for r, b_ in zip(hit[0], bases)):
+        tag = tuple(_wtag(b_, w.data_ptr()) for b_, w in zip(bases, ws))
         if hit[1] != tag:
             for i, w in enumerate(ws):
                 hit[3][i](w)
@@ -346,24 +349,18 @@ def packed_fused(ws, ts, mode):
     wp = torch.empty((len(ts.taps), rows * cols), device=ws[0].device, dtype=torch.float32)
     refresh = []
     for i, w in enumerate(ws):
-        def make(i):
-            def fn(wi):
-                ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
-                check(lib().t2v_pack_weight_into(_p(wi), _p(wp), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode, rows, cols,
-                                                 ro, co, _stream()), 't2v_pack_weight_into')
-                h = _fused_cache.get(key)
-                if h is not None:
-                    h[1] = tuple(_wtag(x) for x in ws)
-            return fn
-        refresh.append(make(i))
-        refresh[i](w)
-        if isinstance(w, torch.nn.Parameter):
-            ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
-            _pack_cache.setdefault(id(w), {})[('fused', key, i)] = [weakref.ref(w), _wtag(w), wp,
-                                                                    refresh[i],
-                                                                    (w, wp, Cout, Cin, ts.T, list(ts.taps), mode, rows, cols, ro, co)]
-    if all(isinstance(w, torch.nn.Parameter) for w in ws):
-        _fused_cache[key] = [[weakref.ref(w) for w in ws], tag, wp, refresh]
+        ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
+
+        def fn(wi, ro=ro, co=co):
+            check(lib().t2v_pack_weight_into(_p(wi), _p(wp), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode, rows, cols,
+                                             ro, co, _stream()), 't2v_pack_weight_into')
+        refresh.append(fn)
+        fn(w)
+        if cacheable:                      # lets `repack_params` refresh this member in its one multi-tensor launch
+            _pack_cache.setdefault(id(bases[i]), {})[('fused', key, i)] = [weakref.ref(bases[i]), _wtag(bases[i], w.data_ptr()), wp, fn,
+                                                                           (w, wp, Cout, Cin, ts.T, list(ts.taps), mode, rows, cols, ro, co)]
+    if cacheable:
+        _fused_cache[key] = [[weakref.ref(b_) for b_ in bases], tuple(_wtag(b_, w.data_ptr()) for b_, w in zip(bases, ws)), wp, refresh]
     return wp
 
 
