@@ -203,7 +203,8 @@ int t2v_bn_bwd(const float* gy, const float* x, const float* y, const float* sta
 /* Two-launch forms (partial statistics, then a pass whose workgroups merge the channel's partials themselves: no `final`
    launch): training forward = t2v_bn_stats + t2v_bn_apply, backward = t2v_bn_bwd. ws: t2v_bn_ws_floats floats. */
 int t2v_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* running_mean,
-                     float* running_var, float* ws, int N, int C, int64_t S, float momentum, float eps, int relu, void* stream);
+                     float* running_var, float* ws, int N, int C, int64_t S, float momentum, float eps, int relu,
+                     int64_t* num_batches_tracked /* nn.BatchNorm's step counter, += 1 on the device; may be NULL */, void* stream);
 int t2v_bn_train_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
                      float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* stream);
 int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta,

@@ -109,7 +109,7 @@ SIGNATURES = {
     't2v_bn_stats': [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
     't2v_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
-    't2v_bn_train_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P],
+    't2v_bn_train_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P, _P],
     't2v_bn_train_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
     't2v_lstm_gates': [_P, _P, _P, _P, _P, _I, _L, _P],

@@ -554,8 +554,10 @@ __global__ void bn_bwd_apply_k(const float* gy, const float* x, const float* y, 
 // y == 0 workgroup also publishes the merged values (stats, running stats / dgamma, dbeta). No `final` launch.
 __global__ __launch_bounds__(256) void bn_apply_merge_k(const float* x, const float* part, int split, const float* gamma,
                                                         const float* beta, float* y, float* stats, float* rmean, float* rvar,
-                                                        int N, int C, long S, float momentum, float eps, int relu) {
+                                                        int N, int C, long S, float momentum, float eps, int relu,
+                                                        long long* batches_tracked) {
     const int c = blockIdx.x;
+    if (batches_tracked && c == 0 && blockIdx.y == 0 && threadIdx.x == 0) *batches_tracked += 1;     // nn.BatchNorm's step counter
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int k = 0; k < split; ++k) {
         const float* p = part + ((size_t)c * split + k) * 3;
@@ -661,12 +663,13 @@ extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const
     return launch_status();
 }
 extern "C" int t2v_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* rm, float* rv,
-                                float* ws, int N, int C, int64_t S, float momentum, float eps, int relu, void* st) {
+                                float* ws, int N, int C, int64_t S, float momentum, float eps, int relu, int64_t* batches_tracked,
+                                void* st) {
     if (!x || !gamma || !beta || !y || !stats || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
     const int sp = bn_split(N, C, (long)S);
     T2V_LAUNCH(bn_stats_part_k, dim3(C, sp), dim3(256), 0, S_(st), x, ws, N, C, (long)S, sp);
     T2V_LAUNCH(bn_apply_merge_k, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), x, ws, sp, gamma, beta, y, stats, rm, rv, N,
-               C, (long)S, momentum, eps, relu);
+               C, (long)S, momentum, eps, relu, (long long*)batches_tracked);
     return launch_status();
 }
 extern "C" int t2v_bn_train_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,

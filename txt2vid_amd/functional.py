@@ -1518,7 +1518,7 @@ class BatchNormAct(Function):
     (momentum 0.1, unbiased variance); eval: running statistics (no grad support needed)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter=None):
         x = _c(x)
         N, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (N * Cc)
@@ -1527,7 +1527,7 @@ class BatchNormAct(Function):
             stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
             ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
             check(lib().t2v_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S, momentum,
-                                         eps, int(relu), _stream()), 't2v_bn_train_fwd')
+                                         eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd')
             ctx.save_for_backward(x, y, stats, gamma)
             ctx.relu = relu
         else:
@@ -1551,11 +1551,14 @@ class BatchNormAct(Function):
         ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
         check(lib().t2v_bn_train_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
                                      int(ctx.relu), _stream()), 't2v_bn_train_bwd')
-        return gx, gg, gb, None, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False):
-    return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu)
+def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, counter=None):
+    """`counter`: the module's int64 `num_batches_tracked` buffer, incremented by the same launch in training mode."""
+    if counter is not None and (counter.dtype != torch.int64 or not counter.is_cuda):
+        raise TypeError('num_batches_tracked must be an int64 device tensor')
+    return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter)
 
 
 def _skinny_ok(M, K, N):
@@ -2399,6 +2402,40 @@ class CatBatch(Function):
 
 def cat_batch(a, b):
     return CatBatch.apply(a, b)
+
+
+class SplitRows(Function):
+    """(x[:n], x[n:]) of a dense tensor as views; the adjoint writes both gradients into ONE buffer (the native slices cost a
+    zero-fill + copy each and an accumulation: five launches per split in the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x = _c(x)
+        ctx.n, ctx.shape = int(n), tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        if ga is not None and gb is not None:
+            return CatBatch.apply(ga, gb), None
+        out = torch.empty(ctx.shape, device=(ga if ga is not None else gb).device, dtype=torch.float32)
+        check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
+        row = out.numel() // ctx.shape[0]
+        if ga is not None:
+            ga = _c(ga)
+            _copy2d(ga, 0, ga.numel(), out, 0, ga.numel(), 1, ga.numel())
+        else:
+            gb = _c(gb)
+            _copy2d(gb, 0, gb.numel(), out, ctx.n * row, gb.numel(), 1, gb.numel())
+        return out, None
+
+
+def split_rows(x, n):
+    """(x[:n], x[n:]) with a fused adjoint."""
+    return SplitRows.apply(x, n)
 
 
 def tail_rows(x, n_skip):

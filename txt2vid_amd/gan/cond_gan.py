@@ -83,11 +83,9 @@ class CondGan(object):
         res = discrim(x=rf + xhs, cond=(conds + chs) if (cond and xhs) else conds, xbar=None)
         both, gp_res = res[:n], res[n:]
         b = [r.size(0) for r in real]
-        u_r = [TF.head_rows(o[0], b[i]) for i, o in enumerate(both)]
-        u_f = [TF.tail_rows(o[0], b[i]) for i, o in enumerate(both)]
+        u_r, u_f = zip(*[TF.split_rows(o[0], b[i]) for i, o in enumerate(both)])
         if cond:
-            c_r = [TF.head_rows(o[1], b[i]) for i, o in enumerate(both)]
-            c_f = [TF.tail_rows(o[1], b[i]) for i, o in enumerate(both)]
+            c_r, c_f = zip(*[TF.split_rows(o[1], b[i]) for i, o in enumerate(both)])
             # D(real, mismatched captions): second head on the real half's trunk features
             trunk = discrim.sub_discrims
             c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
@@ -99,7 +97,7 @@ class CondGan(object):
             fake_pred = None
         else:
             l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(u_f, u_r)])
-            real_pred, fake_pred = u_r, u_f
+            real_pred, fake_pred = list(u_r), list(u_f)
         if gp_lambda > 0:
             outs = []
             for u, c, _ in gp_res:

@@ -49,10 +49,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x, relu=False):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('only the default BatchNorm2d configuration is on the hot path')
-        if self.training:
-            self.num_batches_tracked.add_(1)
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, relu)
+                                 self.momentum, self.eps, relu, counter=self.num_batches_tracked if self.training else None)
 
 
 class ReLU(nn.Module):
