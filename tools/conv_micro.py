@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from txt2vid_amd import functional as TF
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'both'

@@ -36,7 +36,7 @@ M, C, T = 262144, 64, 27
 alg = (M * C * 4) * 2 + C * C * T * 4
 print(json.dumps({
     'workload': 'tools/conv_micro.py: grouped stem conv2 (64->64, 3x3x3) over the 4 pyramid levels at B=32 x2 (M=262144 voxels), '
-                'forward+dgrad = conv_igemm_strip_kernel<128,64,2,32>, wgrad = conv_wgrad3_kernel + wgrad_reduce',
+                'forward+dgrad = conv_igemm_strip_kernel<256,64,1,16>, wgrad = conv_wgrad3_kernel + wgrad_reduce',
     'algorithmic_bytes_per_launch': {'igemm (x + y + w)': alg, 'wgrad (x + gy + dw)': alg},
     'notes': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md: TCC slots). Units KB. '
              'WRITE_SIZE calibrates exactly on the known 64 MiB output of the forward; FETCH_SIZE may read low by up to 2x on '
