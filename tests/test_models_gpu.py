@@ -527,12 +527,13 @@ def test_sentence_encoder_matches_packed_nn_lstm(bi):
     np.testing.assert_allclose(hn.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize('channels,batch,frame_sizes,size', [(3, 2, [8, 16, 32, 64], 64), (1, 3, [8, 16, 32, 64], 64), (1, 2, [16, 32, 64, 128], 128)])
+@pytest.mark.parametrize('channels,batch,frame_sizes,size', [(3, 2, [8, 16, 32, 64], 64), (1, 3, [8, 16, 32, 64], 64), (1, 2, [16, 32, 64, 128], 128),
+                                                              (1, 1, [8, 16, 32, 64], 64)])
 def test_iteration_vs_oracle_other_shapes(channels, batch, frame_sizes, size):
     """One full training iteration against the CPU oracle (identical weights / batch / draws) away from the benchmark shape:
     RGB clips (the reference's default `num_channels=3`: Cin = 3 stem, Cout = 3 render convs, 3-channel stem gradient),
-    an odd batch (ragged sub-sampled pyramid: 3 -> 2 -> 1 -> 1 clips), and 128x128 frames (`run_tganv2.sh`'s
-    `--frame_sizes 16 32 64 128`, 2x2 ConvLSTM state)."""
+    an odd batch (ragged sub-sampled pyramid: 3 -> 2 -> 1 -> 1 clips), 128x128 frames (`run_tganv2.sh`'s
+    `--frame_sizes 16 32 64 128`, 2x2 ConvLSTM state), and the smallest batch (one clip on every level)."""
     from txt2vid_amd.models.tganv2.gen import MultiScaleGen
     from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
     from txt2vid_amd.gan.cond_gan import CondGan
