@@ -242,8 +242,9 @@ int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, floa
 /* ---- sentence encoder (txt2vid/models/txt/basic.py:49-70: packed-sequence nn.LSTM, forward only) -----------------
  * One time step of one (layer, direction): pre = xproj_t[b] (row stride xstride; = x_t W_ih^T + b_ih + b_hh from one GEMM
  * over all steps) + h_prev[b] W_hh^T; gates i,f,g,o; samples with t >= lengths[b] keep (h, c) and emit 0 into out_t[b]
- * (row stride ostride). h/c are ping-pong buffers [B,H]. */
-int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, const float* c_prev,
+ * (row stride ostride). h/c are ping-pong buffers [B,H]. w_hh_t is nn.LSTM's weight_hh TRANSPOSED: [H][4H] (one workgroup per
+ * sample reads it with consecutive threads on consecutive addresses; t2v_permute01 makes it once per sequence). 4H <= 1024. */
+int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh_t, const float* h_prev, const float* c_prev,
                       float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B, int H,
                       void* stream);
 
@@ -260,7 +261,7 @@ int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, 
  * t2v_embedding_bwd        dW[tokens[n]] += g[n], n in order, without atomics (fixed summation order); dW zero-filled by the caller.
  * t2v_xent_fwd / _bwd      rows of nn.CrossEntropyLoss: loss[n] = lse[n] - x[n][target[n]];  dx = gloss[n] * (softmax(x[n]) - onehot).
  * t2v_argmax_rows          greedy decoding (basic.py:86): first index of each row's maximum. */
-int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, int64_t hp_stride,
+int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh_t /* [H][4H], as above */, const float* h_prev, int64_t hp_stride,
                         const float* c_prev, int64_t cp_stride, float* h_next, int64_t hn_stride, float* c_next, int64_t cn_stride,
                         float* out_t, int64_t ostride, float* gates_t, int64_t gstride, const int32_t* lengths, int t, int B, int H,
                         void* stream);

@@ -940,42 +940,49 @@ extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const floa
 }
 
 // ---------------------------------------------------------------- sentence encoder (models/txt/basic.py:49-70)
-// One time step of one (layer, direction) of the packed-sequence LSTM: thread (b, u) adds the recurrent product
-// h_prev[b] . W_hh[g*H + u] to the input projection of step t (computed for all steps by one GEMM), applies the gates
-// (order i, f, g, o) and — pack_padded_sequence semantics — only advances samples with t < length[b]; the others keep
-// their state and emit zeros. H <= 256, B*H threads: the whole step is one small launch.
-__global__ __launch_bounds__(256) void lstm_seq_step_k(const float* __restrict__ xproj, long xstride, const float* __restrict__ whh,
-                                                       const float* __restrict__ h_prev, const float* __restrict__ c_prev,
-                                                       float* __restrict__ h_next, float* __restrict__ c_next,
-                                                       float* __restrict__ out, long ostride, const int32_t* __restrict__ lengths,
-                                                       int t, int B, int H) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, u = i - b * H;
-    const float* hp = h_prev + (size_t)b * H;
-    float acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = xproj[(size_t)b * xstride + g * H + u];
-    for (int k = 0; k < H; ++k) {
-        const float hv = hp[k];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] += hv * whh[((size_t)g * H + u) * H + k];
-    }
+// One time step of one (layer, direction) of the packed-sequence LSTM: the recurrent product h_prev[b] . W_hh^T is added to the
+// input projection of step t (computed for all steps by one GEMM), the gates (order i, f, g, o) are applied and — pack_padded_
+// sequence semantics — only samples with t < length[b] advance; the others keep their state and emit zeros. H <= 256.
+// One workgroup per sample, one thread per gate output j = g*H + u: the recurrent product reads the TRANSPOSED weight
+// whh_t[k][j] (consecutive threads -> consecutive addresses; the [4H,H] layout made every thread walk its own row) with h_prev[b]
+// in LDS; the four pre-activations of a unit meet in LDS for the gate math. 4H <= 1024.
+__device__ __forceinline__ float lstm_recurrent_pre(const float* __restrict__ xrow, const float* __restrict__ whh_t,
+                                                    const float* __restrict__ hrow, float* sh, int H) {
+    const int j = threadIdx.x, H4 = 4 * H;
+    for (int k = j; k < H; k += H4) sh[k] = hrow[k];
+    __syncthreads();
+    float acc = xrow[j];
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) acc += sh[k] * whh_t[(size_t)k * H4 + j];
+    sh[H + j] = acc;
+    __syncthreads();
+    return acc;
+}
+__global__ __launch_bounds__(1024) void lstm_seq_step_k(const float* __restrict__ xproj, long xstride, const float* __restrict__ whh_t,
+                                                        const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                        float* __restrict__ h_next, float* __restrict__ c_next,
+                                                        float* __restrict__ out, long ostride, const int32_t* __restrict__ lengths,
+                                                        int t, int B, int H) {
+    extern __shared__ float sh[];                 // H (h_prev[b]) + 4H (pre-activations)
+    const int b = blockIdx.x, u = threadIdx.x;
+    lstm_recurrent_pre(xproj + (size_t)b * xstride, whh_t, h_prev + (size_t)b * H, sh, H);
+    if (u >= H) return;
+    const int i = b * H + u;
     const bool active = t < lengths[b];
-    const float gi = sigm(acc[0]), gf = sigm(acc[1]), gg = tanhf(acc[2]), go = sigm(acc[3]);
+    const float gi = sigm(sh[H + u]), gf = sigm(sh[2 * H + u]), gg = tanhf(sh[3 * H + u]), go = sigm(sh[4 * H + u]);
     const float cc = gf * c_prev[i] + gi * gg;
     const float hh = go * tanhf(cc);
     c_next[i] = active ? cc : c_prev[i];
-    h_next[i] = active ? hh : h_prev[i];
+    h_next[i] = active ? hh : sh[u];
     out[(size_t)b * ostride + u] = active ? hh : 0.f;
 }
-extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, const float* c_prev,
+extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh_t, const float* h_prev, const float* c_prev,
                                  float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B,
                                  int H, void* st) {
-    if (!xproj_t || !w_hh || !h_prev || !c_prev || !h_next || !c_next || !out_t || !lengths || B < 1 || H < 1 || t < 0 ||
-        h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
-    T2V_LAUNCH(lstm_seq_step_k, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, S_(st), xproj_t, (long)xstride, w_hh, h_prev,
-               c_prev, h_next, c_next, out_t, (long)ostride, lengths, t, B, H);
+    if (!xproj_t || !w_hh_t || !h_prev || !c_prev || !h_next || !c_next || !out_t || !lengths || B < 1 || H < 1 || 4 * H > 1024 ||
+        t < 0 || h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_seq_step_k, dim3((unsigned)B), dim3((unsigned)(4 * H)), (size_t)5 * H * sizeof(float), S_(st), xproj_t,
+               (long)xstride, w_hh_t, h_prev, c_prev, h_next, c_next, out_t, (long)ostride, lengths, t, B, H);
     return launch_status();
 }
 
@@ -983,26 +990,18 @@ extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const fl
 // Same step as lstm_seq_step_k with everything the backward needs kept: states live in [B,L,H] buffers indexed by the time
 // step they ENTER (h_prev / c_prev / h_next / c_next are (pointer, row stride) pairs, so the last step can write h_n / c_n
 // directly) and the post-activation gates of the step are stored (row stride gstride, order i,f,g,o).
-__global__ __launch_bounds__(256) void lstm_train_step_k(const float* __restrict__ xproj, long xs, const float* __restrict__ whh,
-                                                         const float* __restrict__ hp, long hps, const float* __restrict__ cp, long cps,
-                                                         float* __restrict__ hn, long hns, float* __restrict__ cn, long cns,
-                                                         float* __restrict__ out, long os, float* __restrict__ gates, long gs,
-                                                         const int32_t* __restrict__ lengths, int t, int B, int H) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, u = i - b * H;
-    const float* hrow = hp + (size_t)b * hps;
-    float acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = xproj[(size_t)b * xs + g * H + u];
-    for (int k = 0; k < H; ++k) {
-        const float hv = hrow[k];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] += hv * whh[((size_t)g * H + u) * H + k];
-    }
+__global__ __launch_bounds__(1024) void lstm_train_step_k(const float* __restrict__ xproj, long xs, const float* __restrict__ whh_t,
+                                                          const float* __restrict__ hp, long hps, const float* __restrict__ cp, long cps,
+                                                          float* __restrict__ hn, long hns, float* __restrict__ cn, long cns,
+                                                          float* __restrict__ out, long os, float* __restrict__ gates, long gs,
+                                                          const int32_t* __restrict__ lengths, int t, int B, int H) {
+    extern __shared__ float sh[];
+    const int b = blockIdx.x, u = threadIdx.x;
+    lstm_recurrent_pre(xproj + (size_t)b * xs, whh_t, hp + (size_t)b * hps, sh, H);
+    if (u >= H) return;
     const bool active = t < lengths[b];
-    const float gi = sigm(acc[0]), gf = sigm(acc[1]), gg = tanhf(acc[2]), go = sigm(acc[3]);
-    const float c0 = cp[(size_t)b * cps + u], h0 = hrow[u];
+    const float gi = sigm(sh[H + u]), gf = sigm(sh[2 * H + u]), gg = tanhf(sh[3 * H + u]), go = sigm(sh[4 * H + u]);
+    const float c0 = cp[(size_t)b * cps + u], h0 = sh[u];
     const float cc = gf * c0 + gi * gg;
     const float hh = go * tanhf(cc);
     float* gr = gates + (size_t)b * gs + u;
@@ -1011,15 +1010,15 @@ __global__ __launch_bounds__(256) void lstm_train_step_k(const float* __restrict
     hn[(size_t)b * hns + u] = active ? hh : h0;
     out[(size_t)b * os + u] = active ? hh : 0.f;
 }
-extern "C" int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh, const float* h_prev, int64_t hp_stride,
+extern "C" int t2v_lstm_train_step(const float* xproj_t, int64_t xstride, const float* w_hh_t, const float* h_prev, int64_t hp_stride,
                                    const float* c_prev, int64_t cp_stride, float* h_next, int64_t hn_stride, float* c_next,
                                    int64_t cn_stride, float* out_t, int64_t ostride, float* gates_t, int64_t gstride,
                                    const int32_t* lengths, int t, int B, int H, void* st) {
-    if (!xproj_t || !w_hh || !h_prev || !c_prev || !h_next || !c_next || !out_t || !gates_t || !lengths || B < 1 || H < 1 || t < 0 ||
-        h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
-    T2V_LAUNCH(lstm_train_step_k, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, S_(st), xproj_t, (long)xstride, w_hh, h_prev,
-               (long)hp_stride, c_prev, (long)cp_stride, h_next, (long)hn_stride, c_next, (long)cn_stride, out_t, (long)ostride, gates_t,
-               (long)gstride, lengths, t, B, H);
+    if (!xproj_t || !w_hh_t || !h_prev || !c_prev || !h_next || !c_next || !out_t || !gates_t || !lengths || B < 1 || H < 1 ||
+        4 * H > 1024 || t < 0 || h_prev == h_next || c_prev == c_next) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_train_step_k, dim3((unsigned)B), dim3((unsigned)(4 * H)), (size_t)5 * H * sizeof(float), S_(st), xproj_t,
+               (long)xstride, w_hh_t, h_prev, (long)hp_stride, c_prev, (long)cp_stride, h_next, (long)hn_stride, c_next,
+               (long)cn_stride, out_t, (long)ostride, gates_t, (long)gstride, lengths, t, B, H);
     return launch_status();
 }
 

@@ -2108,6 +2108,20 @@ def gather_rows(x, perm):
     return GatherRows.apply(x, perm_dev, False)
 
 
+_transposed_cache = {}
+
+
+def transposed_weight(w):
+    """w^T of a 2-D parameter as a dense tensor, cached until the parameter changes (same tags as the packed conv weights)."""
+    tag = _wtag(w)
+    hit = _transposed_cache.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    wt = _permute_01(_c(w.detach()), w.shape[0], w.shape[1], 1).view(w.shape[1], w.shape[0])
+    _transposed_cache[id(w)] = (weakref.ref(w), tag, wt)
+    return wt
+
+
 def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bidirectional):
     """Packed-sequence (Bi-)LSTM forward of the sentence encoder on the HIP kernels (models/txt/basic.py:49-70), no autograd
     (the GAN loop detaches the sentence code unless --end2end). tokens [B,L] int64 (sorted by length, desc), lengths: list.
@@ -2130,9 +2144,10 @@ def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bi
             out = torch.empty((B, L, D * H), device=dev, dtype=torch.float32)
             for d in range(D):
                 sfx = '_l%d%s' % (layer, '_reverse' if d else '')
-                w_ih, w_hh = getattr(lstm, 'weight_ih' + sfx).detach(), getattr(lstm, 'weight_hh' + sfx).detach()
+                w_ih, w_hh = getattr(lstm, 'weight_ih' + sfx), getattr(lstm, 'weight_hh' + sfx)     # parameters: packed / transposed once
                 bsum = _ew(lib().t2v_add, 't2v_add', getattr(lstm, 'bias_ih' + sfx).detach(), getattr(lstm, 'bias_hh' + sfx).detach())
                 xproj = conv_fwd_raw(_as5(inp), _as5(w_ih), bsum).view(B, L, 4 * H)      # all time steps: one GEMM
+                w_hh_t = transposed_weight(w_hh)                                          # [H, 4H]: coalesced reads in the step kernel
                 bufs = [(torch.empty_like(zero), torch.empty_like(zero)) for _ in range(2)]      # ping-pong (h, c)
                 for step in range(L):
                     t = L - 1 - step if d else step
@@ -2140,7 +2155,7 @@ def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bi
                     hn_, cn_ = (h_n[layer * D + d], c_n[layer * D + d]) if step == L - 1 else bufs[step & 1]
                     xp = C.c_void_p(xproj.data_ptr() + 4 * t * 4 * H)
                     op = C.c_void_p(out.data_ptr() + 4 * (t * D * H + d * H))
-                    check(lib().t2v_lstm_seq_step(xp, L * 4 * H, _p(_c(w_hh)), _p(hp), _p(cp), _p(hn_), _p(cn_), op, L * D * H,
+                    check(lib().t2v_lstm_seq_step(xp, L * 4 * H, _p(w_hh_t), _p(hp), _p(cp), _p(hn_), _p(cn_), op, L * D * H,
                                                   _p(len_dev), t, B, H, _stream()), 't2v_lstm_seq_step')
             inp = out.view(B * L, D * H)
         return out, (h_n, c_n)
@@ -2173,12 +2188,14 @@ class LstmDirFn(Function):
         h_n = torch.empty((B, H), device=dev, dtype=torch.float32)
         c_n = torch.empty((B, H), device=dev, dtype=torch.float32)
         order = list(range(L - 1, -1, -1)) if reverse else list(range(L))
+        # [H, 4H] for the step kernel's coalesced reads (cached per parameter: the decoder calls this once per position)
+        w_hh_t = transposed_weight(w_hh) if isinstance(w_hh, torch.nn.Parameter) else _permute_01(w_hh, H4, H, 1)
         _copy2d(h0, 0, H, hprev, order[0] * H, L * H, B, H)
         _copy2d(c0, 0, H, cprev, order[0] * H, L * H, B, H)
         for s_, t in enumerate(order):
             last = s_ == L - 1
             tn = t if last else order[s_ + 1]
-            check(lib().t2v_lstm_train_step(_ptr(xproj, t * H4), L * H4, _p(w_hh), _ptr(hprev, t * H), L * H, _ptr(cprev, t * H), L * H,
+            check(lib().t2v_lstm_train_step(_ptr(xproj, t * H4), L * H4, _p(w_hh_t), _ptr(hprev, t * H), L * H, _ptr(cprev, t * H), L * H,
                                             _p(h_n) if last else _ptr(hprev, tn * H), H if last else L * H,
                                             _p(c_n) if last else _ptr(cprev, tn * H), H if last else L * H,
                                             _ptr(out, t * H), L * H, _ptr(gates, t * H4), L * H4, _p(len_dev), t, B, H, _stream()),
