@@ -186,9 +186,16 @@ def main():
         graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2,
                                    cond_dim=256 if args.cond else 0)
 
-    def sentence_codes():            # part of every iteration (outside the graphs: caption lengths vary in real data)
+    graphed_txt = None
+    if txt is not None and not args.eager:
+        from txt2vid_amd.gan.trainer import GraphedSentenceEncoder
+        graphed_txt = GraphedSentenceEncoder(txt, dev)
+
+    def sentence_codes():            # part of every iteration: its own HIP graph per caption length (lengths vary in real data)
         if txt is None:
             return None
+        if graphed_txt is not None:
+            return graphed_txt.encode(tokens, [8] * args.batch)
         return txt.encode(tokens, [8] * args.batch)[2].detach()
 
     def step(i):
@@ -302,7 +309,7 @@ def main():
         'config': {'workload': workload,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
                    'as_written_tflop_per_step': gf * gb / 1e3 if gf else None},
-        'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (3 graphs/step)',
+        'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (%d graphs/step)' % (4 if txt is not None else 3),
         'as_written_tflops': gf * gb * args.steps / dt / 1e3 if gf else None,
     }
     if grad_sync is not None:

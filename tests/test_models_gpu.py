@@ -593,3 +593,27 @@ def test_iteration_bf16_compute_mode_vs_oracle():
     lDo, lGo = tr.step(x)
     print('bf16 compute: HIP lossD %.6f lossG %.6f | fp32 oracle %.6f %.6f' % (lD, lG, lDo, lGo))
     assert abs(lD - lDo) < 2e-2 and abs(lG - lGo) < 5e-2
+
+
+def test_graphed_sentence_encoder_matches_eager():
+    """`GraphedSentenceEncoder`: first batch of a length eager, second captured, third replayed — all equal to the plain
+    forward for ragged batches of two different longest lengths (the per-sample lengths live on the device)."""
+    from txt2vid_amd.gan.trainer import GraphedSentenceEncoder
+    from txt2vid_amd.models.txt.basic import Seq2Seq
+    from txt2vid_amd.util.torch.init import init
+    torch.manual_seed(3)
+    m = Seq2Seq(vocab_size=41)
+    init(m, 'xavier')
+    m.to(DEV)
+    ge = GraphedSentenceEncoder(m, torch.device(DEV))
+    gen = torch.Generator()
+    gen.manual_seed(8)
+    for round_ in range(3):
+        for lengths in ([9, 7, 7, 4, 2, 1], [6, 6, 5, 3, 3, 2]):
+            tokens = torch.zeros(len(lengths), lengths[0], dtype=torch.long)
+            for b, n in enumerate(lengths):
+                tokens[b, :n] = torch.randint(1, 41, (n,), generator=gen)
+            want = m.encode(tokens.to(DEV), lengths)[2].detach().cpu()
+            got = ge.encode(tokens.to(DEV), lengths).cpu()
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=0)
+    assert all(e[2] is not None for e in ge.entries.values()) and len(ge.entries) == 2

@@ -2124,15 +2124,24 @@ def transposed_weight(w):
 
 def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bidirectional):
     """Packed-sequence (Bi-)LSTM forward of the sentence encoder on the HIP kernels (models/txt/basic.py:49-70), no autograd
-    (the GAN loop detaches the sentence code unless --end2end). tokens [B,L] int64 (sorted by length, desc), lengths: list.
+    (the GAN loop detaches the sentence code unless --end2end). tokens [B,L] int64 (sorted by length, desc), lengths: list —
+    or, for graph capture, int32 device tokens [B,L] and lengths = (L, int32 device tensor [B]).
     `lstm` is the nn.LSTM that holds the parameters (state_dict layout of the reference). Returns
     (out [B,L,D*H] zero beyond each length, (h_n, c_n) [layers*D,B,H]) like nn.LSTM on a packed batch."""
     B, L = int(tokens.shape[0]), int(lengths[0])
     dev = embed_weight.device
     H, D = hidden_size, (2 if bidirectional else 1)
     with torch.no_grad():
-        tok = tokens[:, :L].to(device=dev, dtype=torch.int32).contiguous().view(-1)
-        len_dev = torch.tensor([int(l) for l in lengths], dtype=torch.int32).to(dev)
+        if isinstance(lengths, tuple) and len(lengths) == 2 and isinstance(lengths[1], torch.Tensor):
+            # (L, int32 device tensor of the B lengths) + int32 device tokens [B, L] dense: nothing is uploaded here, so the
+            # whole encoder can be captured in a HIP graph (gan.trainer.GraphedSentenceEncoder)
+            len_dev = lengths[1]
+            tok = tokens.view(-1)
+            if tokens.dtype != torch.int32 or not tokens.is_cuda or tokens.shape[1] != L or not tokens.is_contiguous():
+                raise TypeError('device-resident encoding needs dense int32 device tokens [B, L]')
+        else:
+            tok = tokens[:, :L].to(device=dev, dtype=torch.int32).contiguous().view(-1)
+            len_dev = torch.tensor([int(l) for l in lengths], dtype=torch.int32).to(dev)
         E = embed_weight.shape[1]
         x = torch.empty((B * L, E), device=dev, dtype=torch.float32)
         check(lib().t2v_gather_rows(_p(_c(embed_weight.detach())), _p(tok), _p(x), B * L, E, 0, _stream()), 't2v_gather_rows')

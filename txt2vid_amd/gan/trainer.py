@@ -244,6 +244,39 @@ class GraphedTrainStep(object):
         return self.ts.lD, self.ts.lG
 
 
+class GraphedSentenceEncoder(object):
+    """HIP-graph replay of the sentence encoder's forward (`cond_encoder.encode`, ~90 small launches: embedding gather, one GEMM
+    per layer and direction, one launch per time step): one graph per sequence length — caption batches differ in their longest
+    caption, and the per-sample lengths are read on the device. The first batch of a new length runs eagerly (it also fills the
+    packed / transposed weight caches), the second is captured, later ones replay. Returns the sentence codes [B, encoding] in a
+    buffer that the next call of the same length overwrites."""
+
+    def __init__(self, cond_encoder, device):
+        self.enc, self.device = cond_encoder, device
+        self.entries = {}                # (B, L) -> [tokens int32 [B,L], lengths int32 [B], graph | None, codes | None]
+        self.side = torch.cuda.Stream(device=device)
+
+    def encode(self, tokens, lengths):
+        B, L = int(tokens.shape[0]), int(lengths[0])
+        ent = self.entries.get((B, L))
+        if ent is None:
+            ent = [torch.zeros((B, L), dtype=torch.int32, device=self.device), torch.zeros((B,), dtype=torch.int32, device=self.device),
+                   None, None]
+            self.entries[(B, L)] = ent
+            return self.enc.encode(tokens, lengths)[2].detach()
+        tok, len_dev, graph, codes = ent
+        tok.copy_(tokens[:, :L])                                            # int64 -> int32, device or host source
+        len_dev.copy_(torch.tensor([int(n) for n in lengths], dtype=torch.int32))
+        if graph is None:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=self.side, capture_error_mode='thread_local'):
+                codes = self.enc.encode(tok, (L, len_dev))[2]
+            ent[2], ent[3] = graph, codes
+        graph.replay()
+        return codes
+
+
 def test(gan=None, num_samples=1, dataset=None, device=None, params=None, channel_first=True, vocab=None):
     """Sampling path — trainer.py:44-90: eval-mode generator renders one full [B,C,16,S,S] clip per latent
     (no sub-sampling, last level only); real and generated grids (+ captions) are written per batch."""
@@ -291,7 +324,7 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
     # HIP-graph replay of the iteration (3 graphs, see GraphedTrainStep) unless --no_graph / --end2end: the eager loop is
     # host-bound (~1 000 launches at ~20 us of Python each)
     use_graph = not end2end and not getattr(params, 'no_graph', False) and torch.device(device).type == 'cuda'
-    graphed, graphed_key, pending, loss_ring = None, None, None, None
+    graphed, graphed_key, pending, loss_ring, graphed_encoder = None, None, None, None, None
     for epoch in range(num_epoch):
         if params.log_period > 0:
             status('Epoch %d started' % (epoch + 1))
@@ -309,9 +342,14 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
             x = TF.video_to_channel_first(x)                      # [B,T,C,H,W] -> [B,C,T,H,W] (trainer.py:204)
             cond = None
             if gan.cond_encoder is not None and len(y) >= 2:
-                _, _, cond = gan.cond_encoder.encode(y[0], y[1])
-                if not end2end:
-                    cond = cond.detach()
+                if use_graph:
+                    if graphed_encoder is None:
+                        graphed_encoder = GraphedSentenceEncoder(gan.cond_encoder, device)
+                    cond = graphed_encoder.encode(y[0], y[1])
+                else:
+                    _, _, cond = gan.cond_encoder.encode(y[0], y[1])
+                    if not end2end:
+                        cond = cond.detach()
             if use_graph:
                 key = (tuple(x.shape), None if cond is None else tuple(cond.shape))
                 if graphed is None or key != graphed_key:          # first batch (or a new batch shape): capture again
