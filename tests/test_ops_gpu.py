@@ -537,3 +537,18 @@ def test_pyramid_gather():
         close(y, x[::2, :, bt::2])
     y = TF.pyramid_gather(x.to(dev()), 5, 8, 4, 4, 1, 1, 0)
     close(y, F.interpolate(x, size=(8, 4, 4)))
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (True, False), (False, True), (True, True)])
+def test_bmm_wide_tiles(ta, tb):
+    """The 16 x 64-tile batched GEMM (N >= 64, N % 4 == 0) against torch.bmm on the host for every transposition, with ragged
+    M / K (5, 33 rows; 4, 19, 70 deep) and N = 64, 100, 260; N = 66 keeps the 16 x 16 kernel."""
+    from txt2vid_amd import functional as TF
+    gen = torch.Generator()
+    gen.manual_seed(11)
+    for M, N, K in [(5, 64, 4), (33, 100, 19), (16, 260, 70), (33, 66, 19)]:
+        A = torch.randn((3, K, M) if ta else (3, M, K), generator=gen)
+        B = torch.randn((3, N, K) if tb else (3, K, N), generator=gen)
+        want = torch.bmm(A.transpose(1, 2) if ta else A, B.transpose(1, 2) if tb else B)
+        got = TF.bmm(A.to(dev()), B.to(dev()), ta, tb).cpu()
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)

@@ -877,8 +877,64 @@ __global__ __launch_bounds__(256) void bmm_k(const float* A, const float* B, flo
     }
     if (row < M && col < N) c[(long)row * N + col] = accum ? c[(long)row * N + col] + acc : acc;
 }
+// The same product with a 16 x 64 output tile (four consecutive columns per thread, 16-byte stores) and tile loads that run
+// along whichever dimension is contiguous in memory for the given transposition flags: the non-local block's products move
+// the N x N/4 attention matrix (hundreds of MB at 64 x 64 maps) and are bound by exactly these accesses. N % 4 == 0.
+__global__ __launch_bounds__(256) void bmm_wide_k(const float* A, const float* B, float* C, int M, int N, int K, int ta, int tb, int accum) {
+    __shared__ float As[16][17];                 // [row][k]
+    __shared__ __attribute__((aligned(16))) float Bs[16][68];     // [k][col]
+    const int b = blockIdx.z;
+    const float* a = A + (long)b * M * K;
+    const float* bb = B + (long)b * K * N;
+    float* c = C + (long)b * M * N;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 64;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        if (ta) {                                // a[k][r]: consecutive threads along r
+            const int r = row0 + tx, k = k0 + ty;
+            As[tx][ty] = (r < M && k < K) ? a[(long)k * M + r] : 0.f;
+        } else {                                 // a[r][k]: consecutive threads along k
+            const int r = row0 + ty, k = k0 + tx;
+            As[ty][tx] = (r < M && k < K) ? a[(long)r * K + k] : 0.f;
+        }
+        if (tb) {                                // bb[col][k]: consecutive threads along k
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = ty + 16 * j, cc = col0 + cl, k = k0 + tx;
+                Bs[tx][cl] = (cc < N && k < K) ? bb[(long)cc * K + k] : 0.f;
+            }
+        } else {                                 // bb[k][col]: consecutive threads along col
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = tx + 16 * j, cc = col0 + cl, k = k0 + ty;
+                Bs[ty][cl] = (cc < N && k < K) ? bb[(long)k * N + cc] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float av = As[ty][k];
+            const float4 bv = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+            acc[0] += av * bv.x; acc[1] += av * bv.y; acc[2] += av * bv.z; acc[3] += av * bv.w;
+        }
+        __syncthreads();
+    }
+    const int row = row0 + ty, col = col0 + tx * 4;
+    if (row < M && col < N) {                    // N % 4 == 0: the four columns are in range together
+        float4* dst = reinterpret_cast<float4*>(c + (long)row * N + col);
+        float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (accum) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+    }
+}
 extern "C" int t2v_bmm(const float* A, const float* B, float* C, int batch, int M, int N, int K, int ta, int tb, int accum, void* st) {
     if (!A || !B || !C || batch < 1 || M < 1 || N < 1 || K < 1 || batch > 65535) return T2V_EINVAL;
+    if (N >= 64 && (N & 3) == 0 && ((uintptr_t)C & 15) == 0) {
+        dim3 grid((N + 63) / 64, (M + 15) / 16, batch);
+        T2V_LAUNCH(bmm_wide_k, grid, dim3(256), 0, S_(st), A, B, C, M, N, K, ta, tb, accum);
+        return launch_status();
+    }
     dim3 grid((N + 15) / 16, (M + 15) / 16, batch);
     T2V_LAUNCH(bmm_k, grid, dim3(256), 0, S_(st), A, B, C, M, N, K, ta, tb, accum);
     return launch_status();
