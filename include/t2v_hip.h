@@ -117,6 +117,16 @@ int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* groups, int ngr
                                            int kH, int kW);
 int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                            float* dw, float* slab, int flags, void* stream);
+/* Launch-plan queries (host-side arithmetic only, nothing is launched): which kernel instantiation the two grouped entry
+ * points above select for these members. The tile choice is size-dependent (256x64 strips only for launches of >= 512 such
+ * tiles, K-split wave layouts for small grids, the many-splits reduce for small weights), so the parity tests use these to
+ * assert that every instantiation — the benchmark shapes' in particular — is reached by a checked case.
+ * fwd  out[8]: kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv, 3 thin linear, 4 thin two-pass), BM, BN, K chunk,
+ *              FAST, VECB, KS, split-K S.   (groups[].x / .y may be NULL)
+ * wgrad out[6]: kernel (0 per-tap tiles, 1 (tap,ci) column tiles, 2 three-tap rows), S, chunks per split, slab slots,
+ *              reduce kernel (0 / 1 = many-splits small-weight form), workgroups of the main launch. */
+int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out);
+int t2v_conv_wgrad_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, int32_t* out);
 /* Same, plus the bias gradient dbias[Cout] = sum over all members and voxels of dL/dy (what t2v_channel_sum_grouped
  * computes, layers.py / resnet3d.py conv biases): on the 3-tap-row path the weight-gradient kernel adds up the dL/dy
  * tiles it stages anyway, elsewhere the stand-alone channel sum runs. The slab must hold

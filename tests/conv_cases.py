@@ -1,0 +1,166 @@
+"""Convolution parity cases shared by the GPU op tests (tests/test_ops_gpu.py) and the CPU launch-plan coverage test
+(tests/test_conv_plan.py), plus host-side access to the launch-plan queries of the C ABI (`t2v_conv_fwd_plan`,
+`t2v_conv_wgrad_plan`: pure host arithmetic, no GPU needed).
+
+The kernel instantiation a convolution runs on is size-dependent (conv.hip `build_table` / `conv_variant` /
+`build_wtable`), so "the op is tested" does not imply "the instantiation the benchmark runs is tested". The lists here
+make that explicit: SINGLE_CASES are small single-tensor shapes, GROUPED_CASES include the discriminator's grouped
+launches at the BENCHMARK size (BASELINE configs[1]: per-GPU batch 32, 16x64x64x1 clips)."""
+import ctypes as C
+
+# (x shape, Cout, kernel) — single-tensor cases, checked forward / data gradient / weight + bias gradient vs torch on the CPU
+SINGLE_CASES = [
+    ((2, 16, 4, 6, 6), 32, (3, 3, 3)),
+    ((3, 1, 4, 8, 8), 64, (3, 3, 3)),        # Cin=1: generic-K path
+    ((2, 1, 9, 32, 32), 64, (3, 3, 3)),      # Cin=1, M=18432: its data gradient takes the two-pass thin path
+    ((5, 1, 1, 64, 64), 32, (3, 3, 3)),      # same with D=1 (9 live taps)
+    ((2, 3, 2, 5, 7), 8, (3, 3, 3)),         # Cin=3, odd sizes
+    ((2, 32, 1, 8, 8), 16, (3, 3, 3)),       # D=1: centre plane of taps only
+    ((5, 64, 1, 1, 1), 48, (3, 3, 3)),       # 1x1x1 map: centre tap only
+    ((2, 16, 3, 4, 4), 24, (1, 1, 1)),       # 1x1x1 kernel
+    ((4, 32, 6, 6), 1, (3, 3)),              # 2-D, Cout=1 (render block)
+    ((3, 64, 2, 2), 128, (3, 3)),            # 2-D tiny map
+    ((7, 80), 33, ()),                       # Linear
+    ((2, 64, 4, 32, 32), 64, (3, 3, 3)),     # M=8192: 64x64 strip tiles, split-K
+    ((8, 32, 8, 64, 64), 128, (1, 1, 1)),    # M=262144, Cout=128, 1x1x1: non-strip 256x64 tile
+    ((6, 1024), 1, ()),                      # the discriminator heads: thin linear kernel, one output
+    ((5, 96), 3, ()),                        # thin linear kernel, up to 4 outputs
+    # instantiations the small / model shapes above never select (odd channel counts, mid-size and large launches)
+    ((2, 32, 4, 16, 16), 6, (3, 3, 3)),      # Cout=6: 128x32 strip tile without vector weight loads
+    ((2, 16, 4, 6, 6), 6, (1, 1, 1)),        # 128x32x16 tile, scalar weight loads
+    ((2, 32, 4, 6, 6), 6, (1, 1, 1)),        # 128x32x32 tile, scalar weight loads
+    ((2, 64, 2, 8, 8), 70, (3, 3, 3)),       # Cout=70: 64x64 strip tiles (K-split waves) without vector loads, ragged channel tile
+    ((2, 32, 2, 8, 8), 70, (1, 1, 1)),       # 64x64x32 non-strip tile, scalar weight loads
+    ((4, 32, 8, 32, 32), 66, (3, 3, 3)),     # M=32768 x 2 channel tiles: 64x64 strip tiles, one accumulator chain per wave, scalar loads
+    ((12, 48, 8, 32, 32), 64, (3, 3, 3)),    # Cin=48 (chunks of 16, no strip), M=98304: 128x64x16 tile with 3-D taps
+    ((6, 48, 8, 32, 32), 66, (1, 1, 1)),     # 128x64x16 tile, scalar weight loads
+    ((6, 32, 16, 32, 32), 64, (1, 1, 1)),    # M=98304: non-strip 128x64x32 tile
+    ((6, 32, 8, 32, 32), 66, (1, 1, 1)),     # 128x64x32 tile, scalar weight loads
+    ((6, 64, 8, 32, 32), 128, (3, 3, 3)),    # M=49152, Cout=128: 128x64x32 strip tile
+    ((6, 32, 8, 32, 32), 66, (3, 3, 3)),     # 128x64x32 strip tile, scalar weight loads
+    ((8, 32, 8, 32, 32), 66, (1, 1, 1)),     # M=65536 x 2 channel tiles: non-strip 256x64 tile, scalar weight loads
+    ((8, 16, 8, 32, 32), 66, (3, 3, 3)),     # 256x64 strip tile, scalar weight loads
+    ((6, 3, 16, 32, 32), 64, (3, 3, 3)),     # Cin=3 stem at M=98304 (the configs[4] RGB stem): generic-K 128x64 tile
+    ((2, 40, 4, 8, 8), 64, (3, 3, 3)),       # Cin=40: generic-K path on 64x64 tiles with Cout=64
+    ((16, 128, 4, 4), 256, (3, 3)),          # 2-D, M=256, K=1152: deep split-K
+    ((8, 64, 8, 32, 32), 64, (1, 1, 1)),     # 1x1x1 64->64 at M=65536: per-tap weight gradient with the many-splits reduce
+]
+
+
+def _stage(B, s):
+    """[(N, D, H, W)] of the 4 pyramid levels of a per-GPU batch B after s DownSample / stem poolings
+    (models/resnet3d.py:12-32: every pooling halves each dim of extent > 1, odd extents are padded)."""
+    out = []
+    for lvl in range(4):
+        b, t, sz = -(-B // (1 << lvl)), 16 >> lvl, 8 << lvl
+        for _ in range(s):
+            t, sz = (t + 1) // 2 if t > 1 else 1, sz // 2
+        out.append((b, t, sz, sz))
+    return out
+
+
+def d_step_members(B, s):
+    """The 8 members of a discriminator-step forward launch: real||fake per level (batch 2*b) and the gradient-penalty
+    interpolates x-hat per level (batch b) — gan/cond_gan.py all_discrim_forward + losses.gradient_penalty."""
+    lv = _stage(B, s)
+    return [(2 * n, d, h, w) for n, d, h, w in lv] + lv
+
+
+def gp_members(B, s):
+    """The 4 x-hat members alone (the gradient penalty's first-order sweep and its double backward)."""
+    return _stage(B, s)
+
+
+# name, Cin, Cout, kernel, members [(N, D, H, W)], relu_in — grouped launches of the discriminator at the benchmark size
+GROUPED_CASES = [
+    ('stem_conv2_B32_8members', 64, 64, (3, 3, 3), d_step_members(32, 0), True),     # M=393216: 256x64 strip tile, wgrad S=171
+    ('stem_conv2_B32_gp', 64, 64, (3, 3, 3), gp_members(32, 0), True),               # M=131072
+    ('down0_conv1_B32_8members', 64, 64, (3, 3, 3), d_step_members(32, 1), True),    # M=49152
+    ('down0_conv2_B32_8members', 64, 128, (3, 3, 3), d_step_members(32, 1), True),   # M=49152, 64->128
+    ('down1_conv2_B32_8members', 128, 256, (3, 3, 3), d_step_members(32, 2), True),  # M=7680 (ragged T), 128->256
+    ('small_ragged_group', 64, 64, (3, 3, 3), [(4, 2, 16, 16), (2, 4, 8, 8), (1, 1, 5, 3)], False),
+]
+
+
+def _group_array(members, cin, cout, k):
+    from txt2vid_amd.functional import conv_geom
+    from txt2vid_amd._lib import ConvGroup
+    geoms = [conv_geom(n, cin, d, h, w, cout, k[0], k[1], k[2]) for n, d, h, w in members]
+    mask = 0
+    for g in geoms:
+        mask |= g.mask
+    taps = [t for t in range(geoms[0].T) if (mask >> t) & 1]
+    slot_of = {t: j for j, t in enumerate(taps)}
+    arr = (ConvGroup * len(members))()
+    for a, g in zip(arr, geoms):
+        a.x = a.y = a.mask = None
+        a.N, a.D, a.H, a.W, a.ntaps = g.cg.N, g.cg.D, g.cg.H, g.cg.W, g.cg.ntaps
+        for j, t in enumerate(g.taps):
+            a.dz[j], a.dy[j], a.dx[j] = g.cg.dz[j], g.cg.dy[j], g.cg.dx[j]
+            a.widx[j] = slot_of[t]
+    return arr
+
+
+def k3(k):
+    k = tuple(k)
+    return (1,) * (3 - len(k)) + k
+
+
+def fwd_plan(members, cin, cout, k, flags=0):
+    """('igemm'|'strip'|'thin'|'linear'|'thin2', BM, BN, BK, fast, vecb, KS, S) for a forward (or, with cin/cout swapped,
+    data-gradient) launch over `members`."""
+    from txt2vid_amd._lib import lib
+    out = (C.c_int32 * 8)()
+    rc = lib().t2v_conv_fwd_plan(_group_array(members, cin, cout, k3(k)), len(members), cin, cout, flags, out)
+    assert rc == 0, rc
+    v = list(out)
+    return (('igemm', 'strip', 'thin', 'linear', 'thin2')[v[0]],) + tuple(v[1:])
+
+
+def wgrad_plan(members, cin, cout, k):
+    """('taps'|'cols'|'rows3', S, chunks per split, slab slots, 'reduce'|'reduce_small', workgroups)."""
+    from txt2vid_amd._lib import lib
+    out = (C.c_int32 * 6)()
+    kk = k3(k)
+    rc = lib().t2v_conv_wgrad_plan(_group_array(members, cin, cout, kk), len(members), cin, cout, kk[0], kk[1], kk[2], out)
+    assert rc == 0, rc
+    v = list(out)
+    return (('taps', 'cols', 'rows3')[v[0]], v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
+
+
+def members_of_single(xs):
+    """(N, D, H, W) of a single-tensor case given as [N,C] / [N,C,H,W] / [N,C,D,H,W]."""
+    if len(xs) == 2:
+        return (xs[0], 1, 1, 1)
+    if len(xs) == 4:
+        return (xs[0], 1, xs[2], xs[3])
+    return (xs[0], xs[2], xs[3], xs[4])
+
+
+def variant_key(plan):
+    """The part of a forward plan that names a kernel instantiation (the split count is a launch parameter)."""
+    return plan[:7]
+
+
+def all_checked_fwd_variants():
+    """Every forward / data-gradient instantiation reached by SINGLE_CASES and GROUPED_CASES."""
+    seen = {}
+    for xs, cout, k in SINGLE_CASES:
+        m = [members_of_single(xs)]
+        seen.setdefault(variant_key(fwd_plan(m, xs[1], cout, k)), 'single %s->%d fwd' % (xs, cout))
+        seen.setdefault(variant_key(fwd_plan(m, cout, xs[1], k)), 'single %s->%d dgrad' % (xs, cout))
+    for name, cin, cout, k, members, _ in GROUPED_CASES:
+        seen.setdefault(variant_key(fwd_plan(members, cin, cout, k)), name + ' fwd')
+        seen.setdefault(variant_key(fwd_plan(members, cout, cin, k)), name + ' dgrad')
+    return seen
+
+
+def all_checked_wgrad_variants():
+    seen = {}
+    for xs, cout, k in SINGLE_CASES:
+        p = wgrad_plan([members_of_single(xs)], xs[1], cout, k)
+        seen.setdefault((p[0], p[4]), 'single %s->%d' % (xs, cout))
+    for name, cin, cout, k, members, _ in GROUPED_CASES:
+        p = wgrad_plan(members, cin, cout, k)
+        seen.setdefault((p[0], p[4]), name)
+    return seen

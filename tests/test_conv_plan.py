@@ -1,0 +1,65 @@
+"""CPU: the launch-plan queries of the C ABI (host arithmetic, no GPU) say which kernel instantiation a convolution runs
+on. This file pins (1) what the BENCHMARK shapes select — the 256x64 strip GEMM and the 171-way split weight gradient that
+the round-1 review found in no parity test — and (2) that EVERY instantiation compiled into libt2v_hip.so is reached by at
+least one case of tests/conv_cases.py, which tests/test_ops_gpu.py checks against torch on the GPU box."""
+import itertools
+
+import conv_cases as cc
+
+
+def test_benchmark_shapes_select_the_big_tile_paths():
+    """BASELINE configs[1] at per-GPU batch 32 (what bench.py times): stem conv2 over the 8 discriminator-step members."""
+    name, cin, cout, k, members, _ = cc.GROUPED_CASES[0]
+    assert name == 'stem_conv2_B32_8members'
+    assert sum(n * d * h * w for n, d, h, w in members) == 393216
+    assert cc.fwd_plan(members, cin, cout, k) == ('strip', 256, 64, 16, 1, 1, 1, 1)          # conv_igemm_strip_kernel<256,64,1,16,true,1>
+    assert cc.fwd_plan(members, cout, cin, k) == ('strip', 256, 64, 16, 1, 1, 1, 1)          # its data gradient
+    w = cc.wgrad_plan(members, cin, cout, k)
+    assert w[0] == 'rows3' and w[4] == 'reduce_small' and w[1] >= 16                          # conv_wgrad3_kernel, many-splits reduce
+    # the gradient-penalty members alone (M = 131072) still fill 512 tiles of 256 voxels
+    _, cin, cout, k, members, _ = cc.GROUPED_CASES[1]
+    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 256, 64, 16)
+    # 64 -> 128 at M = 49152: 128x64 strip tiles forward, 64x64 K-split strip tiles for the data gradient
+    _, cin, cout, k, members, _ = cc.GROUPED_CASES[3]
+    assert sum(n * d * h * w for n, d, h, w in members) == 49152
+    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 128, 64, 32)
+    assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip', 64, 64, 32, 1, 1, 2)
+
+
+# every instantiation the launchers in conv.hip can select (launch_conv_t + the thin kernels)
+_TILES = [(128, 32, 32), (128, 32, 16), (256, 64, 16), (128, 64, 32), (128, 64, 16), (64, 64, 32), (64, 64, 16)]
+ALL_FWD = set()
+for bm, bn, bk in _TILES:
+    for vecb in (1, 0):
+        ALL_FWD.add(('igemm', bm, bn, bk, 1, vecb, 1))                       # conv_igemm_kernel<BM,BN,*,BK,true,VECB>
+        if bk == 32 or bm == 256:
+            ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>
+            if (bm, bn, bk) == (64, 64, 32):
+                ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 2))               # K-split wave layout
+for bm, bn in ((128, 32), (128, 64), (64, 64)):
+    ALL_FWD.add(('igemm', bm, bn, 16, 0, 0, 1))                              # generic-K: conv_igemm_kernel<BM,BN,*,16,false,false>
+ALL_FWD |= {('thin', 256, 1, 0, 0, 0, 0), ('thin', 256, 4, 0, 0, 0, 0), ('thin2', 256, 1, 0, 0, 0, 0),
+            ('linear', 0, 1, 0, 0, 0, 0), ('linear', 0, 4, 0, 0, 0, 0)}
+ALL_WGRAD = set(itertools.product(('taps', 'cols', 'rows3'), ('reduce', 'reduce_small')))
+
+
+def test_every_forward_instantiation_is_reached_by_a_parity_case():
+    seen = cc.all_checked_fwd_variants()
+    assert not (set(seen) - ALL_FWD), 'plan query reports an instantiation this list does not know: %s' % (set(seen) - ALL_FWD)
+    missing = ALL_FWD - set(seen)
+    assert not missing, 'no parity case runs on %s' % sorted(missing)
+
+
+def test_every_weight_gradient_instantiation_is_reached_by_a_parity_case():
+    seen = cc.all_checked_wgrad_variants()
+    assert set(seen) == ALL_WGRAD, sorted(ALL_WGRAD - set(seen))
+
+
+def test_plan_queries_reject_bad_geometry():
+    import ctypes as C
+    from txt2vid_amd._lib import lib, ConvGroup
+    arr = (ConvGroup * 1)()
+    out = (C.c_int32 * 8)()
+    assert lib().t2v_conv_fwd_plan(arr, 1, 64, 64, 0, out) < 0             # all-zero member
+    assert lib().t2v_conv_wgrad_plan(arr, 1, 64, 64, 3, 3, 3, out) < 0
+    assert lib().t2v_conv_fwd_plan(arr, 0, 64, 64, 0, out) < 0

@@ -570,6 +570,79 @@ def test_iteration_vs_oracle_other_shapes(channels, batch, frame_sizes, size):
     assert abs(float(lD) - lDo) < 1e-3 and abs(float(lG) - lGo) < 1e-3
 
 
+def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
+    """BASELINE configs[1] AS BENCHMARKED — unconditional TGANv2, 16x64x64x1, per-GPU batch 32, fp32, RSGAN + GP 0.5 — one full
+    iteration against the CPU oracle on identical weights / batch / draws: both losses and the per-parameter gradient norms of
+    the D step (incl. the gradient-penalty double backward) and of the G step. This is the only place besides bench.py where
+    the kernels run at the size the headline is measured at (256x64 strip GEMM, 171-way split weight gradient, ...); the
+    launch plans of every convolution launch of the iteration are recorded (T2V_PROF_DUMP) and each instantiation must also
+    be one that the op-level cases of tests/conv_cases.py check against torch."""
+    import ctypes as C
+    import conv_cases as cc
+    from txt2vid_amd._lib import lib
+    from txt2vid_amd.gan.trainer import train_iteration
+    B = 32
+    gan, optD, optG, losses, prm = _make_uncond()
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1)), O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0)))
+    random.seed(11)
+    np.random.seed(11)
+    torch.manual_seed(11)
+    x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+    st = torch.get_rng_state()
+    dump = tmp_path / 'launches.csv'
+    monkeypatch.setenv('T2V_PROF_DUMP', str(dump))
+    assert lib().t2v_prof_begin(8192) == 0
+    lD, lG, _, _ = train_iteration(gan, x.to(DEV), None, optD, optG, losses, prm, DEV)
+    torch.cuda.synchronize()
+    out = (C.c_double * 18)()
+    assert lib().t2v_prof_end(out, 6) == 0                       # 0: every launch recorded (pool not exhausted)
+    monkeypatch.delenv('T2V_PROF_DUMP')
+    d_norms = {k: float(p.grad.norm()) for k, p in gan.discrims[0].named_parameters() if p.grad is not None}
+    g_norms = {k: float(p.grad.norm()) for k, p in gan.gen.named_parameters() if p.grad is not None}
+    # ---- oracle, same draws; D gradients are snapshotted before its optimiser step (the reference's G step adds the
+    # discriminator's wasted weight gradients on top afterwards, cond_gan.py:157-158)
+    torch.set_rng_state(st)
+    d_ref = {}
+    step_d = tr.optD.step
+
+    def snap(*a, **kw):
+        d_ref.update({k: float(tr.PD[k].grad.norm()) for k in tr.d_params if tr.PD[k].grad is not None})
+        return step_d(*a, **kw)
+    tr.optD.step = snap
+    lDo, lGo = tr.step(x)
+    g_ref = {k: float(tr.PG[k].grad.norm()) for k in tr.g_params if tr.PG[k].grad is not None}
+    print('B=32: HIP lossD %.7f lossG %.7f | oracle %.7f %.7f' % (float(lD), float(lG), lDo, lGo))
+    assert abs(float(lD) - lDo) < 2e-4 and abs(float(lG) - lGo) < 2e-4
+    worst = 0.0
+    for got, ref, what in ((d_norms, d_ref, 'D'), (g_norms, g_ref, 'G')):
+        floor = 1e-7 * max(ref.values()) + 1e-6
+        for k, v in ref.items():
+            e = abs(got.get(k, 0.0) - v)
+            assert e <= 3e-3 * abs(v) + floor, (what, k, got.get(k), v)
+            worst = max(worst, e / (abs(v) + floor))
+    print('B=32: worst per-parameter gradient-norm deviation %.2e over %d + %d parameters' % (worst, len(d_ref), len(g_ref)))
+    # ---- every convolution instantiation this iteration launched is one an op-level parity case covers
+    checked_fwd = set(cc.all_checked_fwd_variants())
+    checked_wgrad = set(cc.all_checked_wgrad_variants())
+    kinds = ('igemm', 'strip', 'thin', 'linear', 'thin2')
+    launched = set()
+    rows = dump.read_text().strip().splitlines()[1:]
+    assert len(rows) > 150
+    for line in rows:
+        f = line.split(',')
+        kind, plan = int(f[0]), [int(v) for v in f[9].split(':')]
+        if kind in (0, 3):                                         # implicit GEMM / thin kernels (forward or data gradient)
+            key = (kinds[plan[0]],) + tuple(plan[1:7])
+            launched.add(key)
+            assert key in checked_fwd, ('launched at B=32 but in no op-level parity case', key, line)
+        elif kind == 1:
+            key = (('taps', 'cols', 'rows3')[plan[0]], ('reduce', 'reduce_small')[plan[4]])
+            launched.add(key)
+            assert key in checked_wgrad, key
+    assert ('strip', 256, 64, 16, 1, 1, 1) in launched and ('rows3', 'reduce_small') in launched
+    print('B=32: %d convolution launches on %d instantiations, all covered by op-level parity cases' % (len(rows), len(launched)))
+
+
 def test_iteration_bf16_compute_mode_vs_oracle():
     """bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA; BASELINE configs 2-4 "bf16 compute / fp32 master"): one
     full iteration against the fp32 CPU oracle. bf16 operands carry 8 mantissa bits, so this is a LOOSER, separately stated

@@ -33,22 +33,7 @@ def ref_conv(x, w, b):
     return F.linear(x, w, b)
 
 
-CONV_CASES = [
-    # (x shape, Cout, kernel)
-    ((2, 16, 4, 6, 6), 32, (3, 3, 3)),
-    ((3, 1, 4, 8, 8), 64, (3, 3, 3)),        # Cin=1: generic-K path
-    ((2, 1, 9, 32, 32), 64, (3, 3, 3)),      # Cin=1, M=18432: its data gradient takes the two-pass thin path
-    ((5, 1, 1, 64, 64), 32, (3, 3, 3)),      # same with D=1 (9 live taps)
-    ((2, 3, 2, 5, 7), 8, (3, 3, 3)),         # Cin=3, odd sizes
-    ((2, 32, 1, 8, 8), 16, (3, 3, 3)),       # D=1: centre plane of taps only
-    ((5, 64, 1, 1, 1), 48, (3, 3, 3)),       # 1x1x1 map: centre tap only
-    ((2, 16, 3, 4, 4), 24, (1, 1, 1)),       # 1x1x1 kernel
-    ((4, 32, 6, 6), 1, (3, 3)),              # 2-D, Cout=1 (render block)
-    ((3, 64, 2, 2), 128, (3, 3)),            # 2-D tiny map
-    ((7, 80), 33, ()),                       # Linear
-    ((2, 64, 4, 32, 32), 64, (3, 3, 3)),     # bigger: 128x64 / 64x64 tiles
-    ((8, 32, 8, 64, 64), 128, (1, 1, 1)),    # M=262144, Cout=128 -> 128x128 tile
-]
+from conv_cases import SINGLE_CASES as CONV_CASES, GROUPED_CASES      # shared with the CPU launch-plan coverage test
 
 
 @pytest.mark.parametrize('xs,cout,k', CONV_CASES)
@@ -70,6 +55,42 @@ def test_conv_fwd_bwd(xs, cout, k):
     close(xd.grad, xr.grad)
     close(wd.grad, wr.grad, rtol=2e-4, atol=2e-4)
     close(bd.grad, br.grad, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('case', GROUPED_CASES, ids=[c[0] for c in GROUPED_CASES])
+def test_conv_grouped_at_benchmark_size(case):
+    """The discriminator's grouped launches at the size bench.py runs them (BASELINE configs[1], per-GPU batch 32: the 8
+    members of a D-step pass, M = 393 216 voxels for the 64->64 stem convolution): forward (+ fused input ReLU, bias), the
+    data gradient with the ReLU adjoint in its epilogue, and the weight + bias gradient summed over all members — the
+    256x64 strip GEMM and the 171-way split weight gradient with its many-splits reduce — against torch on the CPU.
+    Per-member references in fp32; the weight gradient (a sum over up to 393 216 voxels) against an fp64 accumulation of
+    the per-member fp32 references."""
+    from txt2vid_amd import functional as TF
+    name, cin, cout, k, members, relu_in = case
+    w = rnd(2, cout, cin, *k) * (1.0 / np.sqrt(cin * 27.0))
+    b = rnd(3, cout) * 0.1
+    xs = [rnd(10 + i, n, cin, d, h, wd) for i, (n, d, h, wd) in enumerate(members)]
+    gys = [rnd(40 + i, n, cout, d, h, wd) for i, (n, d, h, wd) in enumerate(members)]
+    wd_, bd_ = w.to(dev()), b.to(dev())
+    xd, gyd = [x.to(dev()) for x in xs], [g.to(dev()) for g in gys]
+    ys = TF.conv_group_raw(xd, wd_, bd_, relu_in, 0)
+    gxs = TF.conv_group_raw(gyd, wd_, None, False, 1, masks=xd if relu_in else None)
+    dbias = torch.empty(cout, device=dev())
+    dw = TF.conv_group_wgrad_raw(xd, gyd, tuple(w.shape), relu_in, dbias=dbias)
+    torch.cuda.synchronize()
+    dw_ref = torch.zeros(w.shape, dtype=torch.float64)
+    db_ref = torch.zeros(cout, dtype=torch.float64)
+    for i, (x, gy) in enumerate(zip(xs, gys)):
+        xr = x.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv3d(F.relu(xr) if relu_in else xr, wr, br, padding=1)
+        close(ys[i], yr)
+        (yr * gy).sum().backward()
+        close(gxs[i], xr.grad)
+        dw_ref += wr.grad.double()
+        db_ref += br.grad.double()
+    close(dw, dw_ref, rtol=2e-4, atol=2e-4)
+    close(dbias, db_ref, rtol=2e-4, atol=2e-4)
 
 
 def test_conv_double_backward():

@@ -53,7 +53,7 @@ static inline int launch_status() {
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
-struct ProfRec { hipEvent_t e0, e1; double flops; int kind; long M; int Cin, Cout, taps, groups, S; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int kind; long M; int Cin, Cout, taps, groups, S; int32_t plan[8]; };
 static struct {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -72,10 +72,15 @@ struct ProfScope {
             r->kind = kind;
             r->flops = flops;
             r->M = M; r->Cin = Cin; r->Cout = Cout; r->taps = taps; r->groups = groups; r->S = S;
+            for (int i = 0; i < 8; ++i) r->plan[i] = -1;
             g_prof_cur = r;
         }
     }
     ~ProfScope() { g_prof_cur = nullptr; }
+    // the launch plan (t2v_conv_fwd_plan / t2v_conv_wgrad_plan layout) of the launch this scope brackets, for the dump
+    static void set_plan(const int32_t* plan, int n) {
+        if (g_prof_cur) for (int i = 0; i < n && i < 8; ++i) g_prof_cur->plan[i] = plan[i];
+    }
 };
 #define T2V_LAUNCH_PROF(kernel, grid, block, shm, stream, ...) do {                                                      \
         (void)hipGetLastError();                                                                                          \
@@ -105,14 +110,15 @@ extern "C" int t2v_prof_end(double* out, int nkinds) {
     for (int i = 0; i < nkinds * 3; ++i) out[i] = 0.0;
     FILE* dump = nullptr;
     if (const char* path = getenv("T2V_PROF_DUMP")) dump = fopen(path, "w");   // developer aid: one line per launch
-    if (dump) fprintf(dump, "kind,flops,ms,M,Cin,Cout,taps,groups,S\n");
+    if (dump) fprintf(dump, "kind,flops,ms,M,Cin,Cout,taps,groups,S,plan\n");
     for (size_t i = 0; i < g_prof.used; ++i) {
         ProfRec& r = g_prof.recs[i];
         if (hipEventSynchronize(r.e1) != hipSuccess) return T2V_ELAUNCH;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return T2V_ELAUNCH;
         if (r.kind >= 0 && r.kind < nkinds) { out[r.kind * 3] += ms; out[r.kind * 3 + 1] += r.flops; out[r.kind * 3 + 2] += 1.0; }
-        if (dump) fprintf(dump, "%d,%.0f,%.6f,%ld,%d,%d,%d,%d,%d\n", r.kind, r.flops, ms, r.M, r.Cin, r.Cout, r.taps, r.groups, r.S);
+        if (dump) fprintf(dump, "%d,%.0f,%.6f,%ld,%d,%d,%d,%d,%d,%d:%d:%d:%d:%d:%d:%d:%d\n", r.kind, r.flops, ms, r.M, r.Cin, r.Cout, r.taps,
+                          r.groups, r.S, r.plan[0], r.plan[1], r.plan[2], r.plan[3], r.plan[4], r.plan[5], r.plan[6], r.plan[7]);
     }
     if (dump) fclose(dump);
     int dropped = (g_prof.used >= g_prof.recs.size()) ? 1 : 0;
@@ -1477,16 +1483,29 @@ static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
 static bool g_ksplit_waves = getenv("T2V_NO_KSPLIT_WAVES") == nullptr;
 static long g_ksplit_max_blocks = getenv("T2V_KSPLIT_MAX_BLOCKS") ? atol(getenv("T2V_KSPLIT_MAX_BLOCKS")) : 768;
 
+// Which instantiation a (tile, chunk) choice ends up in: the strip variant (three dx taps from one staged strip) when the
+// members carry their taps in (row, dx) order, and for the 64x64x32 strip tile the K-split wave layout (KS = 2: two
+// accumulator chains per wave cost a VGPR occupancy step, 3 instead of 4 waves per SIMD: worth it only for launches that
+// cannot put 4 workgroups on every CU anyway). Shared by the launcher and by t2v_conv_fwd_plan.
+struct ConvVariant { bool strip; int ks; };
+static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
+    ConvVariant v{false, 1};
+    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
+        v.strip = true;
+        const long nblocks = (long)tab.tile_start[tab.n] * ((Cout + BN - 1) / BN) * p.S;
+        if (BM == 64 && BN == 64 && BKT == 32 && g_ksplit_waves && nblocks <= g_ksplit_max_blocks) v.ks = 2;
+    }
+    return v;
+}
+
 template <int BM, int BN, int WAVES_CO, int BKT>
 static void launch_conv_t(const GroupTable& tab, const float* wp, const float* bias, float* slab, int Cin, int Cout, int flags,
                           const ConvPlan& p, hipStream_t s) {
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
-    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
+    const ConvVariant v = conv_variant(tab, p, BM, BN, BKT, Cin, Cout, flags);
+    if (v.strip) {
         constexpr int KS = (BM == 64 && BN == 64 && BKT == 32) ? 2 : 1;
-        // two accumulator chains per wave cost a VGPR occupancy step (3 instead of 4 waves per SIMD): worth it only for
-        // launches that cannot put 4 workgroups on every CU anyway
-        const long nblocks_ = (long)grid.x * grid.y * grid.z;
-        if (KS == 2 && (!g_ksplit_waves || nblocks_ > g_ksplit_max_blocks)) {
+        if (KS == 2 && v.ks != 2) {
             if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
             return;
@@ -1501,6 +1520,38 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
     } else {
         T2V_LAUNCH_PROF((conv_igemm_kernel<BM, BN, WAVES_CO, 16, false, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
     }
+}
+
+// Launch-plan query (no launch): the kernel instantiation t2v_conv_fwd_grouped would run for these members.
+// out[0] kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv (Cout <= 4), 3 thin linear, 4 thin two-pass),
+// out[1..3] tile BM, BN and K chunk, out[4] FAST (Cin % 16 == 0), out[5] VECB (Cout % 4 == 0), out[6] KS, out[7] split-K S.
+// Used by the parity tests to assert that every instantiation — in particular the ones the benchmark shapes select —
+// is reached by at least one checked case.
+static void fill_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, const GroupTable& tab,
+                          const ConvPlan& p, int32_t* out) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    int nslots;
+    bool pure_linear = Cout <= 4;
+    for (int i = 0; i < ngroups; ++i)
+        pure_linear = pure_linear && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1 && groups[i].ntaps == 1 && groups[i].widx[0] == 0;
+    if (pure_linear) { out[0] = 3; out[2] = Cout == 1 ? 1 : 4; out[7] = 1; return; }
+    if (thin_ok(groups, ngroups, Cin, Cout, nslots)) {
+        out[0] = thin_two_pass(groups, ngroups, Cin, Cout, nslots) ? 4 : 2;
+        out[1] = 256; out[2] = Cout == 1 ? 1 : 4; out[7] = 1;
+        return;
+    }
+    const int bk = (p.bm == 256 && p.bn == 64) ? 16 : (p.bk == 32 ? 32 : 16);
+    const ConvVariant v = conv_variant(tab, p, p.bm, p.bn, bk, Cin, Cout, flags);
+    out[0] = v.strip ? 1 : 0;
+    out[1] = p.bm; out[2] = p.bn; out[3] = p.fast ? bk : 16;
+    out[4] = p.fast ? 1 : 0; out[5] = (p.fast && p.vecb) ? 1 : 0; out[6] = v.ks; out[7] = p.S;
+}
+extern "C" int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out) {
+    GroupTable tab;
+    ConvPlan p;
+    if (!out || !build_table(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    fill_fwd_plan(groups, ngroups, Cin, Cout, flags, tab, p, out);
+    return T2V_OK;
 }
 
 extern "C" int64_t t2v_conv_fwd_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout) {
@@ -1544,6 +1595,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         Mtot_ += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
         if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
     }
+    int32_t plan_[8];
+    fill_fwd_plan(groups, ngroups, Cin, Cout, flags, tab, p, plan_);
     bool pure_linear = Cout <= 4;
     for (int i = 0; i < ngroups; ++i)
         pure_linear = pure_linear && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1 && groups[i].ntaps == 1 && groups[i].widx[0] == 0;
@@ -1552,6 +1605,7 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         for (int i = 0; i < ngroups; ++i) { tab.tile_start[i] = (int32_t)rows; rows += groups[i].N; }
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)rows;
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, 1, ngroups, 1);
+        ProfScope::set_plan(plan_, 8);
         if (Cout == 1) T2V_LAUNCH_PROF(linear_thin_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
         else T2V_LAUNCH_PROF(linear_thin_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tab, wp, bias, Cin, Cout, flags);
         return launch_status();
@@ -1567,6 +1621,7 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         if (ws && thin_two_pass(groups, ngroups, Cin, Cout, nslots)) {
             {
                 ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
+                ProfScope::set_plan(plan_, 8);
                 T2V_LAUNCH_PROF(thin_taps_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, Cin, nslots, flags);
             }
             ProfScope prof2(3, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, 2);
@@ -1574,11 +1629,13 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
             return launch_status();
         }
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
+        ProfScope::set_plan(plan_, 8);
         if (Cout == 1) T2V_LAUNCH_PROF(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
         else T2V_LAUNCH_PROF(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
         return launch_status();
     }
     ProfScope prof(0, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);      // executed (non-padding-tap) MACs x 2
+    ProfScope::set_plan(plan_, 8);
     const int bk = p.bk;
     if (p.bn == 32) {
         if (bk == 32) launch_conv_t<128, 32, 1, 32>(tab, wp, bias, ws, Cin, Cout, flags, p, s);
@@ -2585,6 +2642,28 @@ extern "C" int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* grou
     return (int64_t)p.S * p.nlive * Cout * Cin;
 }
 
+// Launch-plan query (no launch) for t2v_conv_wgrad_grouped[_bias]: out[0] kernel (0 per-tap 64x64 tiles, 1 (tap, ci) column
+// tiles for Cin < 64, 2 three-tap kernel rows), out[1] k-splits S, out[2] 32-voxel chunks per split, out[3] slab slots,
+// out[4] reduce kernel (0 per-64-pairs, 1 the many-splits small-weight form), out[5] workgroups of the main launch.
+static void fill_wgrad_plan(int Cin, int Cout, const WgradPlan& p, int32_t* out) {
+    const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
+    out[0] = p.rows3 ? 2 : (Cin < 64 ? 1 : 0);
+    out[1] = p.S;
+    out[2] = p.cps;
+    out[3] = p.nlive;
+    out[4] = ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0;
+    out[5] = (int32_t)((p.rows3 ? tiles * p.nrows : Cin < 64 ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
+                                                              : tiles * p.nlive) * p.S);
+}
+extern "C" int t2v_conv_wgrad_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                                   int32_t* out) {
+    WGroupTable tab;
+    WgradPlan p;
+    if (!out || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
+    fill_wgrad_plan(Cin, Cout, p, out);
+    return T2V_OK;
+}
+
 extern "C" int64_t t2v_channel_sum_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int C);
 extern "C" int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups, int C, float* out, float* ws, int accum, void* stream);
 
@@ -2669,6 +2748,9 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     // grid.y runs over the taps at least one member can touch; the others are written as zeros by the reduce
     {
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
+        int32_t plan_[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        fill_wgrad_plan(Cin, Cout, p, plan_);
+        ProfScope::set_plan(plan_, 8);
         if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
             if (flags & T2V_CONV_BF16)
