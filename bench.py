@@ -1,6 +1,7 @@
 """bench.py — TGANv2 training throughput on MI355X (see the driver contract in DESIGN.md §Measurement).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: under torch.distributed.run, or bare — then it starts its
+                                                               own N ranks as a child torch.distributed.run before touching a GPU)
 
 Workload (BASELINE.json configs[1]): unconditional TGANv2, 16x64x64x1 clips, per-GPU batch 32, fp32,
 RSGAN + zero-centred GP (lambda 0.5), Adam(2e-4, (0.5, 0.999)), 1 D step + 1 G step per iteration,
@@ -120,6 +121,23 @@ def cpu_baseline(threads, budget_s=45.0):
             'steps_per_sec': 1.0 / dt}
 
 
+def self_launch(n):
+    """One process per GPU over RCCL, as the driver's own N>1 command line does it:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL's intra-node transport needs it on this host driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('[bench] launching %d ranks: %s\n' % (n, ' '.join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,6 +156,12 @@ def main():
                                                                           '= the per-GPU share of BASELINE configs[4] (MSRVDC shape)')
     ap.add_argument('--channels', type=int, default=1, choices=(1, 3))
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` (no launcher): start the N ranks as a CHILD torch.distributed.run — nothing in this
+        # process has touched the GPU yet (importing torch does not), and it never does: it only relays the ranks' output
+        # (rank 0 prints the JSON line) and exits with their return code.
+        raise SystemExit(self_launch(args.gpus))
 
     from txt2vid_amd import dist as tdist
     from txt2vid_amd import functional as TF

@@ -127,3 +127,44 @@ def test_dp_semantics_equal_global_batch_with_oracle():
     for k in keys:
         avg = 0.5 * (g0[k] + g1[k])
         assert torch.allclose(avg, g_global[k], rtol=2e-3, atol=1e-5 * max(1.0, float(g_global[k].abs().max()))), k
+
+
+def _replica_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import random
+    from txt2vid_amd import dist as tdist
+    tdist.init_from_env('gloo')
+    random.seed(1000 + 17 * rank)                        # no --seed: every rank would draw its own (train/setup.py:8)
+    seed = tdist.broadcast_seed(random.randint(1, 100000))
+    torch.manual_seed(12345 + rank)                      # ... and even with differently seeded constructors / init:
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(4, 2))
+    with torch.no_grad():
+        net[1].running_mean.add_(float(rank))            # buffers travel too
+    strided = torch.nn.Parameter(torch.randn(3, 3, 4, 5).permute(2, 3, 0, 1))        # a non-contiguous master copy
+    holder = torch.nn.Module()
+    holder.w = strided
+    n = tdist.sync_replicas([net, None, holder])
+    flat = torch.cat([t.detach().reshape(-1).double() for t in list(net.parameters()) + list(net.buffers()) + [strided]])
+    q.put((rank, seed, n, flat, tdist.rank_world()))
+    dist.destroy_process_group()
+
+
+def test_replicas_identical_without_seed_world2():
+    """no parameter broadcast existed and each rank drew its own seed. `broadcast_seed` + `sync_replicas`
+    (train/gan.py) make the replicas bit-identical before the first step; rank 0 is the source."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, n0, f0, rw0), (r1, s1, n1, f1, rw1) = res
+    assert s0 == s1 and n0 == n1 == 6 + 3 + 1        # conv / bn / linear weight + bias, 3 BatchNorm buffers, the strided tensor
+    assert torch.equal(f0, f1)
+    assert rw0 == (0, 2) and rw1 == (1, 2)
+    random_state = __import__('random').Random(1000)
+    assert s0 == random_state.randint(1, 100000)                   # rank 0's draw won

@@ -619,8 +619,9 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
         for k, v in ref.items():
             e = abs(got.get(k, 0.0) - v)
             assert e <= 3e-3 * abs(v) + floor, (what, k, got.get(k), v)
-            worst = max(worst, e / (abs(v) + floor))
-    print('B=32: worst per-parameter gradient-norm deviation %.2e over %d + %d parameters' % (worst, len(d_ref), len(g_ref)))
+            if abs(v) > 1e-4 * max(ref.values()):                 # (biases in front of a BatchNorm have a true gradient of zero)
+                worst = max(worst, e / abs(v))
+    print('B=32: worst relative per-parameter gradient-norm deviation %.2e over %d + %d parameters' % (worst, len(d_ref), len(g_ref)))
     # ---- every convolution instantiation this iteration launched is one an op-level parity case covers
     checked_fwd = set(cc.all_checked_fwd_variants())
     checked_wgrad = set(cc.all_checked_wgrad_variants())
@@ -631,6 +632,8 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
     for line in rows:
         f = line.split(',')
         kind, plan = int(f[0]), [int(v) for v in f[9].split(':')]
+        if plan[0] < 0:
+            continue                                              # second pass of the two-pass thin kernel: no plan of its own
         if kind in (0, 3):                                         # implicit GEMM / thin kernels (forward or data gradient)
             key = (kinds[plan[0]],) + tuple(plan[1:7])
             launched.add(key)

@@ -37,6 +37,45 @@ def local_device_index():
     return int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
 
 
+def rank_world():
+    """(rank, world) of this process; (0, 1) outside a process group."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def broadcast_seed(seed):
+    """Every rank adopts rank 0's seed (the reference draws one with `random.randint` when --seed is absent,
+    train/setup.py:8: under one process per GPU each rank would otherwise build a different model)."""
+    if rank_world()[1] == 1:
+        return seed
+    box = [seed]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def sync_replicas(modules, src=0):
+    """Broadcast every parameter and buffer of `modules` from rank `src`: the replicas start bit-identical whatever each rank's
+    generator state was (random init, a checkpoint only rank 0 could read, ...). Gradient averaging keeps them identical
+    afterwards. Returns the number of tensors sent."""
+    if rank_world()[1] == 1:
+        return 0
+    n = 0
+    with torch.no_grad():
+        for m in modules:
+            if m is None:
+                continue
+            for t in list(m.parameters()) + list(m.buffers()):
+                if t.is_contiguous():
+                    dist.broadcast(t, src=src)
+                else:                                       # (tap-major master copies and the like)
+                    c = t.contiguous()
+                    dist.broadcast(c, src=src)
+                    t.copy_(c)
+                n += 1
+    return n
+
+
 class GradArena(object):
     """Flat gradient buffer of one model + the per-step exchange.
 

@@ -122,7 +122,9 @@ def _gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xb
         per = (torch.sqrt(sq) - 1) ** 2
     if combine is torch.sum:
         return TF.vec_sum(per, scale)
-    return combine(per) * scale
+    # a batch MEAN: the average of the ranks' local means already is the global mean — `scale` (world_size under data
+    # parallelism) only applies to the sum-combined form above
+    return combine(per)
 
 
 def gradient_penalty(discrim, real_x=None, real_xbar=None, fake_x=None, fake_xbar=None, real_cond=None, fake_cond=None,

@@ -335,6 +335,8 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
     avg_load = RollingAvg(window_size=max(1, params.log_period))
     load_watch, iter_watch = Stopwatch(), Stopwatch()
     from ..data import DevicePrefetcher
+    from ..dist import rank_world
+    writer = rank_world()[0] == 0            # data-parallel replicas are identical: rank 0 alone writes checkpoints and samples
     iteration = 0
     # HIP-graph replay of the iteration (3 graphs, see GraphedTrainStep) unless --no_graph / --end2end: the eager loop is
     # host-bound (~1 000 launches at ~20 us of Python each)
@@ -397,8 +399,8 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
                 gen_loss.update(float(lG))
             # checkpoint: the reference tests `save_example_period` here (trainer.py:269) and never reads
             # --save_model_period; the intended flag is used (SURVEY §8a defect 3).
-            if (iteration == 1 and params.save_initial) or (params.save_model_period > 0 and
-                                                            iteration % params.save_model_period == 0):
+            if writer and ((iteration == 1 and params.save_initial) or (params.save_model_period > 0 and
+                                                                        iteration % params.save_model_period == 0)):
                 to_save = {'optG': optG.state_dict(), 'optD': optD.state_dict(), 'iteration': iteration}
                 to_save.update(gan.save_dict())
                 torch.save(to_save, '%s/iter_%d_lossG_%.4f_lossD_%.4f' % (params.out, iteration, gen_loss.get(),
@@ -410,8 +412,8 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
                                                 gen_loss.get(), torch.cuda.max_memory_allocated() / 1e9,
                                                 torch.cuda.max_memory_reserved() / 1e9, avg_iter.get(), avg_load.get()))
                 torch.cuda.reset_peak_memory_stats()
-            if params.save_example_period > 0 and ((iteration == 1 and params.save_initial_examples) or
-                                                   iteration % params.save_example_period == 0):
+            if writer and params.save_example_period > 0 and ((iteration == 1 and params.save_initial_examples) or
+                                                              iteration % params.save_example_period == 0):
                 from .samples import save_frames, save_sentences
                 status('saving to %s (iteration %d)' % (params.out_samples, iteration))
                 save_frames(xs[0], '%s/real_samples.png' % params.out_samples)

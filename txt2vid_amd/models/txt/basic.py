@@ -12,6 +12,10 @@ import torch.nn as nn
 
 
 class RecurrentModel(nn.Module):
+    # Class-level default: a Seq2Seq pickled by the reference (train/txt.py:185 saves the whole module) is rebuilt without
+    # running this __init__, so the instance has no `with_grad` of its own; it then encodes on the forward-only kernels.
+    with_grad = False
+
     def __init__(self, vocab_size=None, embed_size=256, hidden_size=256, encoding_size=256, num_layers=4, bi=True,
                  is_decoder=False):
         super().__init__()
@@ -46,7 +50,10 @@ class RecurrentModel(nn.Module):
         from ... import functional as TF
         self._check_device()
         D = 2 if self.bi else 1
-        if self.with_grad and torch.is_grad_enabled():
+        # lengths as (L, int32 device tensor) is the graph-capturable form `GraphedSentenceEncoder` passes: forward-only kernels
+        # whatever the flag says (the differentiable path reads the lengths on the host)
+        device_lengths = isinstance(lengths, tuple) and len(lengths) == 2 and isinstance(lengths[1], torch.Tensor)
+        if self.with_grad and torch.is_grad_enabled() and not device_lengths:
             out, (hs, cs) = self._run_lstm(x, lengths, initial_state)
             hidden = (hs, cs)                       # lists of [B,H], index layer * D + direction (differentiable)
             hn = TF.cat_features(hs[-2], hs[-1]) if self.bi else hs[-1].unsqueeze(0)

@@ -19,7 +19,15 @@ class Adam(torch.optim.Optimizer):
         steps = [int(self.state[p]['step']) for g in self.param_groups for p in g['params'] if p in self.state and self.state[p]]
         if len({tuple(g['betas']) for g in self.param_groups}) != 1:
             raise NotImplementedError('graph capture: one (beta1, beta2) per optimiser')
-        self.step_dev = torch.tensor([float(max(steps) if steps else 0), 0.0, 0.0], device=device, dtype=torch.float32)
+        n = max(steps) if steps else 0
+        if self.step_dev is not None:
+            # a second capture (new batch shape): the host-side `step` entries only advance on eager / capture calls, the
+            # replays in between advanced the device counter alone — carry on from whichever is further
+            n = max(n, int(self.step_dev[0].item()))
+            for st in self.state.values():
+                if st:
+                    st['step'] = n
+        self.step_dev = torch.tensor([float(n), 0.0, 0.0], device=device, dtype=torch.float32)
 
     def state_dict(self):
         """Same layout as torch.optim.Adam. Under graph replay the step counter advances on the device only: fold it back

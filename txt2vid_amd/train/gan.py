@@ -38,6 +38,9 @@ def main(args):
     rank, world = tdist.init_from_env('nccl')
     from ..util.misc import limit_host_threads
     limit_host_threads()                 # an oversubscribed CPU thread pool starves the HIP runtime's submission thread
+    if world > 1 and args.seed is None:
+        import random
+        args.seed = tdist.broadcast_seed(random.randint(1, 100000))      # one seed for all ranks: identical replicas
     seed, device = setup(args)
     status('%d cuda devices available; rank %d of %d' % (torch.cuda.device_count(), rank, world))
     vocab = load(args.vocab) if args.vocab else data.Vocab()
@@ -50,6 +53,9 @@ def main(args):
             if isinstance(txt_encoder, dict) and 'txt' in txt_encoder:
                 txt_encoder = txt_encoder['txt']
             txt_encoder = txt_encoder.to(device)
+            if hasattr(txt_encoder, 'differentiable'):
+                txt_encoder.differentiable(False)      # a pre-training checkpoint may carry the autograd-path flag: the GAN loop
+                #                                        detaches the sentence code (trainer.py:211-215), forward-only kernels
         else:
             txt_encoder = create_object(args.sent, vocab_size=len(vocab)).to(device)
             init(txt_encoder, init_method=args.sent_init_method or args.init_method)
@@ -88,6 +94,16 @@ def main(args):
         if 'optG' in to_load:
             optG.load_state_dict(to_load['optG'])
         del to_load
+    if world > 1:
+        # replicas bit-identical before the first step (whatever each rank's init / checkpoint read produced), then per-rank
+        # generators for everything drawn per iteration (z, sub-sample phases, GP alphas, caption permutations)
+        from .. import functional as TF
+        tdist.sync_replicas([gen] + list(discrims) + [txt_encoder])
+        TF.bump_weight_epoch()
+        import random
+        import numpy as np
+        for seeder in (random.seed, np.random.seed, torch.manual_seed):
+            seeder(seed + rank)
     transform = data.default_transform(frame_size=[args.frame_sizes[-1]], num_channels=args.num_channels)
     dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=transform, size=args.frame_sizes[-1],
                          channels=args.num_channels, seed=(args.seed or 0) + rank)

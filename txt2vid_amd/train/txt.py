@@ -155,7 +155,13 @@ class Pretrainer(object):
         self._scalar('data/val_loss', self.val_loss)
         path = '%s/iter_%d_loss_%.4f_val_%.4f' % (self.args.out, self.iteration, self.rolling.get(), self.val_loss)
         print('saving to: %s' % path)
-        torch.save({'optim': self.opt, 'txt': self.net}, path)
+        # the whole module is pickled (reference layout, train/txt.py:185); it is saved in forward-only mode so that
+        # `train/gan.py --sent_weights` gets an encoder on the capturable kernels, and switched back for the next iteration
+        self.net.differentiable(False)
+        try:
+            torch.save({'optim': self.opt, 'txt': self.net}, path)
+        finally:
+            self.net.differentiable(True)
 
     def report(self, epoch, i, n_batches, sent, symbols):
         print('real words=', self.vocab.to_words(sent[0]))
