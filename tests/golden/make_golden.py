@@ -441,6 +441,239 @@ def golden_txt_pretrain():
     save('txt_pretrain', **out)
 
 
+# ---------------------------------------------------------------------------------------------
+def golden_host():
+    """Which ATen CPU kernels produced the fixtures: torch version, CPU ISA level and thread count. tests/test_oracle_golden.py
+    asserts the tight (<= 1e-6) oracle-vs-reference bound when the host runs the same kernels and the looser cross-platform
+    bound otherwise (a different ISA changes oneDNN's summation order)."""
+    import json
+    info = {'torch': torch.__version__, 'cpu_capability': torch.backends.cpu.get_cpu_capability(), 'threads': torch.get_num_threads()}
+    with open(os.path.join(HERE, 'host.json'), 'w') as f:
+        json.dump(info, f)
+    print('wrote host.json', info)
+
+
+def _compact(obj):
+    """Same nested structure with every tensor replaced by a stride-0 view of ONE element (its mean): shape, dtype and key
+    layout survive `torch.save`, the bytes do not (the generator alone is 345 MB; fixtures must stay small)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.numel() == 0 or not obj.dtype.is_floating_point:
+            return obj.detach().clone()
+        v = obj.detach().double().mean().to(obj.dtype).reshape(1)
+        return v.expand(obj.numel()).view(obj.shape) if obj.dim() else v.reshape(())
+    if isinstance(obj, dict):
+        return type(obj)((k, _compact(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_compact(v) for v in obj)
+    return obj
+
+
+def golden_checkpoint():
+    """The dict `trainer.train()` hands to `torch.save` (trainer.py:269-279): `{'optG', 'optD'}` + `CondGan.save_dict()`
+    (cond_gan.py:186-196), built by the REFERENCE's classes after one real optimiser step each (so both Adam states
+    exist), for the text-conditioned model (`single_discrim.module.*` keys from its nn.DataParallel wrapper, 'cond' entry) and the
+    unconditional one (`single_discrim.*`). Tensor VALUES are compacted to one element per tensor (`_compact`): what is pinned
+    is the file format — key names, nesting, shapes, dtypes, optimiser param-group layout."""
+    for tag, G, D, cond_dim in (('uncond', GenU, DisU, 0), ('cond', GenC, DisC, 256)):
+        g = pour(G(width=64, height=64, num_channels=1, **({'cond_dim': cond_dim} if cond_dim else {})))
+        d = pour(D(num_channels=1, **({'cond_dim': cond_dim} if cond_dim else {})))
+        txt = None
+        if cond_dim:
+            txt = Seq2Seq(vocab_size=21)
+            txt.load_state_dict({k: recipe_tensor('encoder.' + k.split('.', 1)[1], v.shape) for k, v in txt.state_dict().items()})
+        gan = CondGan(gen=g, discrims=[d], cond_encoder=txt, discrim_names=['video'])
+        optD = torch.optim.Adam([{'params': d.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+        optG = torch.optim.Adam([{'params': g.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+        for m, opt in ((g, optG), (d, optD)):                     # one step on synthetic gradients: populates the Adam state
+            for i, p in enumerate(m.parameters()):
+                p.grad = torch.full_like(p, 1e-3 * (1 + i % 7))
+            opt.step()
+        to_save = {'optG': optG.state_dict(), 'optD': optD.state_dict()}
+        to_save.update(gan.save_dict())
+        path = os.path.join(HERE, 'ref_checkpoint_%s.pt' % tag)
+        torch.save(_compact(to_save), path)
+        print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024.0), sorted(to_save.keys()))
+
+
+def golden_seq2seq_pickle():
+    """`train/txt.py:185` pickles the WHOLE module: `torch.save({'optim': optimizer, 'txt': seq2seq}, path)`; `train/gan.py
+    --sent_weights` unpickles it (train/gan.py:36-43). Written here by the reference's own classes (class path
+    `txt2vid.models.txt.basic.Seq2Seq`; its instances have no attribute this build adds in __init__), parameters compacted."""
+    txt = Seq2Seq(vocab_size=21)
+    opt = torch.optim.Adam(txt.parameters(), lr=1e-3)
+    for p in txt.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    for p in txt.parameters():
+        p.grad = None
+    with torch.no_grad():
+        for mod in txt.modules():
+            for name, p in list(mod._parameters.items()):
+                if p is not None:
+                    p.data = _compact(p.data)
+            if hasattr(mod, '_flat_weights'):
+                mod._flat_weights = [getattr(mod, n) for n in mod._flat_weights_names]
+    for st in opt.state.values():
+        for k, v in list(st.items()):
+            st[k] = _compact(v)
+    path = os.path.join(HERE, 'ref_seq2seq.pt')
+    torch.save({'optim': opt, 'txt': txt}, path)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024.0))
+
+
+def golden_data():
+    """The input-pipeline contract (txt2vid/data/__init__.py): `Vocab` / `build_vocab` / `tokenize` / `to_words`, `pick_frames`,
+    `collate_fn`, and `Dataset.__getitem__` on two tiny frame folders (JPEG bytes stored in the fixture). The reference module
+    hard-imports cv2, torchvision and nvidia.dali at the top (data/__init__.py:6,9-10,16-18), none of which exist here and none of
+    which the functions above touch: EMPTY placeholder modules are registered for those names so that the import statement
+    succeeds (runtime shims like SURVEY §8c's two; nothing of those libraries is emulated). The per-frame transform is passed in
+    by the caller (the reference's own `default_transform` is torchvision code)."""
+    import io
+    import pickle
+    import tempfile
+    import types
+    from PIL import Image
+    for name in ('cv2', 'torchvision', 'torchvision.transforms', 'torchvision.transforms.functional', 'nvidia', 'nvidia.dali',
+                 'nvidia.dali.pipeline', 'nvidia.dali.ops', 'nvidia.dali.types'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision.transforms'].functional = sys.modules['torchvision.transforms.functional']
+    sys.modules['nvidia'].dali = sys.modules['nvidia.dali']
+    sys.modules['nvidia.dali'].ops = sys.modules['nvidia.dali.ops']
+    sys.modules['nvidia.dali'].types = sys.modules['nvidia.dali.types']
+    sys.modules['nvidia.dali.pipeline'].Pipeline = object
+    import txt2vid.data as RD
+    out = {}
+    sentences = ['digit 3 is left and right.', 'A man is playing a guitar', 'the cat. sat on The mat', 'digit 7 is top and bottom.',
+                 'someone slices an onion. quickly']
+    vocab = RD.build_vocab(sentences)
+    words = [vocab.idx2word[i] for i in range(len(vocab))]
+    out['vocab_words'] = np.array(words)
+    out['sentences'] = np.array(sentences)
+    probes = sentences + ['an unseen word appears. here', 'digit 3 is']
+    out['probes'] = np.array(probes)
+    toks = [[vocab(t) for t in vocab.tokenize(s)] for s in probes]
+    out['probe_lens'] = np.array([len(t) for t in toks])
+    out['probe_tokens'] = np.array(sum(toks, []))
+    out['probe_words'] = np.array([vocab.to_words(t) for t in toks])
+    # pick_frames, deterministic branch
+    for n in (16, 17, 40, 64):
+        out['pick_%d' % n] = np.array(RD.pick_frames(list(range(100, 100 + n)), random=False, num_frames=16))
+    # Dataset on two frame folders (+ one listed video that is missing on disk)
+    rs = np.random.RandomState(7)
+
+    def transform(img):                                           # caller-supplied: float32 [C,h,w] in [-1,1]
+        a = np.asarray(img.convert('L'), dtype=np.float32) / 255.0
+        return torch.from_numpy((a[None] - 0.5) / 0.5)
+    with tempfile.TemporaryDirectory() as tmp:
+        captions = {'vidA': ['digit 3 is left and right.', 'the cat. sat on The mat'], 'vidB': ['A man is playing a guitar'],
+                    'vidMissing': ['never read']}
+        nframes = {'vidA': 20, 'vidB': 33}
+        for vid, n in nframes.items():
+            os.makedirs(os.path.join(tmp, vid))
+            for i in range(n):
+                img = Image.fromarray(rs.randint(0, 256, size=(12, 12, 3)).astype(np.uint8))
+                buf = io.BytesIO()
+                img.save(buf, format='JPEG', quality=90)
+                data = buf.getvalue()
+                with open(os.path.join(tmp, vid, '%d.jpg' % (i * 3)), 'wb') as f:      # frame ids 0, 3, 6, ...: sorted numerically
+                    f.write(data)
+                out['jpeg_%s_%d' % (vid, i * 3)] = np.frombuffer(data, dtype=np.uint8)
+            with open(os.path.join(tmp, vid, 'notes.txt'), 'w') as f:                   # non-frame files are skipped
+                f.write('x')
+        cap_path = os.path.join(tmp, 'captions.pkl')
+        with open(cap_path, 'wb') as f:
+            pickle.dump(captions, f)
+        out['captions_pickle'] = np.frombuffer(pickle.dumps(captions, protocol=2), dtype=np.uint8)
+        ds = RD.Dataset(video_dir=tmp, vocab=vocab, captions=cap_path, transform=transform)
+        out['ds_len'] = np.int64(len(ds))
+        out['ds_missing'] = np.int64(ds.missing)
+        out['ds_video_ids'] = np.array([str(v) for v in ds.video_ids])
+        items = [ds[i] for i in range(len(ds))]
+        for i, (frames, cap) in enumerate(items):
+            out['ds_frames_%d' % i] = npy(frames)
+            out['ds_caption_%d' % i] = npy(cap)
+            out['ds_caption_dtype_%d' % i] = np.array(str(cap.dtype))
+        vids, targets, lengths = RD.collate_fn(list(items))
+        out['collate_vids'], out['collate_targets'], out['collate_lengths'] = npy(vids), targets.numpy(), np.array(lengths)
+        out['collate_targets_dtype'] = np.array(str(targets.dtype))
+    save('data_contract', **out)
+
+
+def golden_trajectory(n_steps=100):
+    """the CPU oracle and the imported reference side by side for `n_steps` FREE-RUNNING iterations in this
+    container (uncond TGANv2 64x64x1, B=4, recipe weights, seeds 100): per-step |delta lossD|, |delta lossG| (expected exactly 0:
+    same ATen kernels in the same order) and the reference's own loss curve. Only these numbers are committed
+    (tests/golden/trajectory_%d.json); the per-step states are 345 MB each."""
+    import json
+    import time
+    from oracle import tganv2_oracle as O
+    B = 4
+    g = pour(GenU(width=64, height=64, num_channels=1))
+    d = pour(DisU(num_channels=1))
+    g.train()
+    d.train()
+    gan = CondGan(gen=g, discrims=[d], discrim_names=['video'])
+    losses = MixedGanLoss(g_loss=RSGANLoss(), d_loss=RSGANLoss())
+    optD = torch.optim.Adam([{'params': d.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = torch.optim.Adam([{'params': g.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1)), O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0)))
+    ss = Subsample()
+    fs = [8, 16, 32, 64]
+    rec = {'lossD_ref': [], 'lossG_ref': [], 'dD': [], 'dG': [], 'max_param_delta': []}
+    seed = 100
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    t0 = time.time()
+    for it in range(n_steps):
+        x0 = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
+        state = (torch.get_rng_state(), np.random.get_state(), random.getstate())
+        x = x0
+        xs = []
+        for i in range(4):
+            xs.append(F.interpolate(x, size=(x.size(2), fs[i], fs[i])) if i != 3 else x)
+            x, _ = ss(x)
+        z = torch.randn(B, g.latent_size)
+        fake = gan(z, cond=None)
+        lD = gan.discrim_step(real=xs, fake=[f.detach() for f in fake], cond=None, loss=losses.discrim_loss, gp_lambda=0.5)
+        lD.backward()
+        optD.step()
+        _, _, real_pred = gan.all_discrim_forward(real=xs, cond=None, fake=None, loss=None)
+        g.zero_grad()
+        fc = d(x=fake, cond=None, xbar=None)
+        lG = torch.stack([losses.gen_loss(fake=ff[0], real=rr) for ff, rr in zip(fc, real_pred[0])]).mean()
+        lG.backward()
+        optG.step()
+        after = (torch.get_rng_state(), np.random.get_state(), random.getstate())
+        torch.set_rng_state(state[0])
+        np.random.set_state(state[1])
+        random.setstate(state[2])
+        lDo, lGo = tr.step(x0)
+        torch.set_rng_state(after[0])
+        np.random.set_state(after[1])
+        random.setstate(after[2])
+        pd = 0.0
+        if it % 10 == 9 or it == n_steps - 1:                      # parameters of both models, every 10th step
+            sd_g, sd_d = g.state_dict(), d.state_dict()
+            pd = max(max(float((sd_g[k] - tr.PG[k].detach()).abs().max()) for k in tr.g_params),
+                     max(float((sd_d[k] - tr.PD[k].detach()).abs().max()) for k in tr.d_params))
+        rec['lossD_ref'].append(float(lD))
+        rec['lossG_ref'].append(float(lG))
+        rec['dD'].append(abs(float(lD) - lDo))
+        rec['dG'].append(abs(float(lG) - lGo))
+        rec['max_param_delta'].append(pd)
+        print('it %3d  ref lossD %.7f lossG %.7f | oracle delta %.1e %.1e | param delta %.1e | %.0f s' %
+              (it, float(lD), float(lG), rec['dD'][-1], rec['dG'][-1], pd, time.time() - t0), flush=True)
+    rec['summary'] = {'steps': n_steps, 'max_dD': max(rec['dD']), 'max_dG': max(rec['dG']), 'max_param_delta': max(rec['max_param_delta']),
+                      'torch': torch.__version__, 'threads': torch.get_num_threads(), 'batch': B,
+                      'protocol': 'free-running, both consume identical x / z / subsample phases / GP alphas'}
+    with open(os.path.join(HERE, 'trajectory_%d.json' % n_steps), 'w') as f:
+        json.dump(rec, f)
+    print('summary', rec['summary'])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['layers', 'resnet3d', 'gen', 'steps', 'init', 'steps_cond', 'losses', 'txt_pretrain']
     if 'losses' in which:
@@ -459,3 +692,14 @@ if __name__ == '__main__':
         golden_steps()
     if 'steps_cond' in which:
         golden_steps_cond()
+    if 'host' in which:
+        golden_host()
+    if 'checkpoint' in which:
+        golden_checkpoint()
+    if 'seq2seq_pickle' in which:
+        golden_seq2seq_pickle()
+    if 'data' in which:
+        golden_data()
+    if 'trajectory' in which:                                       # python make_golden.py trajectory [N]   (~15 s per step)
+        n = [int(a) for a in which if a.isdigit()]
+        golden_trajectory(n[0] if n else 100)

@@ -57,3 +57,64 @@ def test_cond_cli_train(tmp_path):
                         '--out_samples', smp, '--max_iters', '2', '--save_model_period', '1000', '--save_example_period', '2'], tmp_path)
     assert 'Iter 2, Loss_D' in log
     assert glob.glob(os.path.join(smp, 'sentences_epoch000_iter_000002.txt'))
+
+
+def test_pretrained_sentence_encoder_feeds_the_graph_replayed_gan_loop(tmp_path):
+    """a checkpoint written by `train/txt.py` (the whole Seq2Seq pickled, reference layout) loaded through
+    `train/gan.py --sent_weights` and used under HIP-graph replay — the encoder must run on the forward-only, capturable
+    kernels whatever mode it was pickled in."""
+    import pickle
+    import random
+    import torch
+    from txt2vid_amd.data import Vocab
+    vocab = Vocab()
+    words = [w for w in vocab.word2idx if not w.startswith('<')] if hasattr(vocab, 'word2idx') else ['digit', '0', 'is', 'left']
+    rng = random.Random(3)
+    sents = {'v%d' % i: [' '.join(rng.choice(words) for _ in range(rng.randint(3, 6)))] for i in range(24)}
+    with open(tmp_path / 'sents.pkl', 'wb') as f:
+        pickle.dump(sents, f)
+    with open(tmp_path / 'vocab.pkl', 'wb') as f:
+        pickle.dump(vocab, f)
+    out_txt = tmp_path / 'txt_out'
+    cmd = [sys.executable, '-m', 'txt2vid_amd.train.txt', '--data', str(tmp_path / 'sents.pkl'), '--vocab', str(tmp_path / 'vocab.pkl'),
+           '--out', str(out_txt), '--cuda', '--seed', '5', '--batch_size', '8', '--epoch', '4', '--workers', '0', '--max_iters', '4',
+           '--save_model_period', '4', '--log_period', '2']
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors='replace')[-3000:]
+    ck = sorted(glob.glob(os.path.join(str(out_txt), 'iter_4_*')))
+    assert len(ck) == 1
+    saved = torch.load(ck[0], weights_only=False, map_location='cpu')
+    assert saved['txt'].encoder.with_grad is False                   # pickled in forward-only mode
+    # ... and a pickle that DOES carry the autograd-path flag (what round 1 wrote) must still work
+    saved['txt'].differentiable(True)
+    legacy = str(tmp_path / 'legacy_ckpt')
+    torch.save(saved, legacy)
+    out_dir, smp = str(tmp_path / 'out'), str(tmp_path / 'samples')
+    for weights in (ck[0], legacy):
+        log = run(COMMON + ['--G', 'txt2vid.models.tganv2_cond.gen.MultiScaleGen', '--D', 'txt2vid.models.tganv2_cond.discrim.MultiScaleDiscrim',
+                            '--sent_weights', weights, '--vocab', str(tmp_path / 'vocab.pkl'), '--batch_size', '8', '--epochs', '1',
+                            '--out', out_dir, '--out_samples', smp, '--max_iters', '5', '--save_model_period', '1000',
+                            '--save_example_period', '0'], tmp_path)
+        assert 'Iter 5, Loss_D' in log and 'HIP-graph replay' in log
+
+
+def test_cli_resumes_from_checkpoints_written_by_the_real_reference(tmp_path):
+    """`--weights` on tests/golden/ref_checkpoint_uncond.pt and `--weights` + `--sent_weights` on the text-conditioned pair
+    (ref_checkpoint_cond.pt, ref_seq2seq.pt): files produced by the reference's own CondGan.save_dict / Adam.state_dict /
+    whole-module Seq2Seq pickle (make_golden.py; one element per tensor kept), resumed through this build's CLI with the
+    iteration under HIP-graph replay (closes SURVEY §8 f3 "load reference-produced checkpoints")."""
+    import re
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    out_dir, smp = str(tmp_path / 'out'), str(tmp_path / 'samples')
+    tail = ['--batch_size', '8', '--epochs', '1', '--out', out_dir, '--out_samples', smp, '--max_iters', '4',
+            '--save_model_period', '1000', '--save_example_period', '0']
+    log = run(COMMON + ['--G', 'txt2vid.models.tganv2.gen.MultiScaleGen', '--D', 'txt2vid.models.tganv2.discrim.MultiScaleDiscrim',
+                        '--dont_use_sent', '--weights', os.path.join(gold, 'ref_checkpoint_uncond.pt')] + tail, tmp_path)
+    m = re.search(r'Iter 4, Loss_D: ([-0-9.naninf]+) Loss_G: ([-0-9.naninf]+)', log)
+    assert m and all(abs(float(v)) < 1e3 for v in m.groups()), log[-1500:]
+    log = run(COMMON + ['--G', 'txt2vid.models.tganv2_cond.gen.MultiScaleGen', '--D', 'txt2vid.models.tganv2_cond.discrim.MultiScaleDiscrim',
+                        '--sent_weights', os.path.join(gold, 'ref_seq2seq.pt'),
+                        '--weights', os.path.join(gold, 'ref_checkpoint_cond.pt')] + tail, tmp_path)
+    m = re.search(r'Iter 4, Loss_D: ([-0-9.naninf]+) Loss_G: ([-0-9.naninf]+)', log)
+    assert m and all(abs(float(v)) < 1e3 for v in m.groups()), log[-1500:]
+    assert 'HIP-graph replay' in log

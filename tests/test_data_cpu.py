@@ -116,3 +116,53 @@ def test_vocab_pickles_written_by_the_reference_resolve(tmp_path):
     p.write_bytes(blob)
     w = load(str(p))
     assert isinstance(w, data.Vocab) and w('left') == v('left') and len(w) == len(v)
+
+
+def test_input_pipeline_vs_reference_fixture(golden, tmp_path):
+    """tests/golden/data_contract.npz holds what the REAL reference's `txt2vid.data` produced (make_golden.py `data`: Vocab /
+    build_vocab / tokenize / to_words, pick_frames, Dataset.__getitem__ on two frame folders whose JPEG bytes are in the
+    fixture, collate_fn). This build's data module must reproduce all of it exactly (closes SURVEY §8 f1's pin)."""
+    import pickle
+    import numpy as np
+    import torch
+    from txt2vid_amd import data as D
+    g = golden('data_contract')
+    sentences = [str(s) for s in g['sentences']]
+    vocab = D.build_vocab(sentences)
+    assert [vocab.idx2word[i] for i in range(len(vocab))] == [str(w) for w in g['vocab_words']]
+    probes = [str(s) for s in g['probes']]
+    toks = [[vocab(t) for t in vocab.tokenize(s)] for s in probes]
+    assert [len(t) for t in toks] == list(g['probe_lens'])
+    assert sum(toks, []) == list(g['probe_tokens'])
+    assert [vocab.to_words(t) for t in toks] == [str(w) for w in g['probe_words']]
+    for n in (16, 17, 40, 64):
+        assert D.pick_frames(list(range(100, 100 + n)), num_frames=16, random=False) == list(g['pick_%d' % n])
+    # the two frame folders, byte for byte
+    for key in g.files:
+        if key.startswith('jpeg_'):
+            _, vid, idx = key.split('_')
+            (tmp_path / vid).mkdir(exist_ok=True)
+            (tmp_path / vid / ('%s.jpg' % idx)).write_bytes(g[key].tobytes())
+    for vid in ('vidA', 'vidB'):
+        (tmp_path / vid / 'notes.txt').write_text('x')
+    captions = pickle.loads(g['captions_pickle'].tobytes())
+    cap_path = tmp_path / 'captions.pkl'
+    cap_path.write_bytes(pickle.dumps(captions))
+
+    def transform(img):
+        a = np.asarray(img.convert('L'), dtype=np.float32) / 255.0
+        return torch.from_numpy((a[None] - 0.5) / 0.5)
+    ds = D.Dataset(video_dir=str(tmp_path), vocab=vocab, captions=str(cap_path), transform=transform)
+    assert len(ds) == int(g['ds_len']) and ds.missing == int(g['ds_missing'])
+    assert [str(v) for v in ds.video_ids] == [str(v) for v in g['ds_video_ids']]
+    items = [ds[i] for i in range(len(ds))]
+    for i, (frames, cap) in enumerate(items):
+        assert np.array_equal(frames.numpy(), g['ds_frames_%d' % i]), i
+        assert np.array_equal(cap.numpy(), g['ds_caption_%d' % i]) and str(cap.dtype) == str(g['ds_caption_dtype_%d' % i])
+    vids, targets, lengths = D.collate_fn(list(items))
+    assert np.array_equal(vids.numpy(), g['collate_vids'])
+    assert np.array_equal(targets.numpy(), g['collate_targets']) and str(targets.dtype) == str(g['collate_targets_dtype'])
+    assert list(lengths) == list(g['collate_lengths'])
+    # the same through the config factory (config/*.json: "class": "txt2vid.data.my_dataset")
+    ds2 = D.my_dataset(data=str(tmp_path), vocab=vocab, anno=str(cap_path), transform=transform)
+    assert np.array_equal(ds2[1][0].numpy(), g['ds_frames_1'])

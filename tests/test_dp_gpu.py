@@ -19,3 +19,43 @@ def test_two_rank_replicas_stay_identical():
     assert p.returncode == 0, out[-3000:]
     line = [l for l in out.splitlines() if l.startswith('DP_CHECK')]
     assert line and 'identical after 5 iterations: True' in line[0], out[-2000:]
+
+
+def test_two_rank_nccl_replicas_stay_identical():
+    """The same check over RCCL, one rank per GPU — only where the box has two GPUs (the builder's lease has one; the
+    driver's multi-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('T2V_DIST_BACKEND', None)
+    env.pop('T2V_SINGLE_DEVICE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'tools', 'dp_check.py')]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode(errors='replace')
+    assert p.returncode == 0, out[-3000:]
+    line = [l for l in out.splitlines() if l.startswith('DP_CHECK')]
+    assert line and 'identical after 5 iterations: True' in line[0], out[-2000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls the N=1 case): bench.py starts the two
+    ranks itself as a child torch.distributed.run before touching the GPU, relays rank 0's JSON line and exit code.
+    Rehearsed here with gloo and both ranks on device 0 (one GPU per lease); over RCCL when the box has two GPUs."""
+    import json
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if torch.cuda.device_count() < 2:
+        env.update(T2V_DIST_BACKEND='gloo', T2V_SINGLE_DEVICE='1')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--batch', '8',
+           '--no_cpu_baseline', '--no_roofline']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors='replace')[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 16 and res['scaling'] == 'weak'
+    assert res['config']['grad_exchange_mb_per_step'] > 100          # D 116 MB + G's live 76 MB
+    assert res['value'] > 0 and res['steps'] == 2

@@ -155,3 +155,88 @@ def test_reference_pickled_sentence_encoder_resolves(tmp_path):
     got = pickle.loads(blob)['txt']
     assert isinstance(got, Seq2Seq) and got.encoder.lstm.weight_hh_l0.shape == m.encoder.lstm.weight_hh_l0.shape
     assert torch.equal(got.encoder.embed.weight, m.encoder.embed.weight)
+
+
+def _purge_reference_modules():
+    import sys
+    for k in [k for k in sys.modules if k == 'txt2vid' or k.startswith('txt2vid.')]:
+        del sys.modules[k]
+
+
+def test_sentence_encoder_pickled_by_the_real_reference(golden):
+    """tests/golden/ref_seq2seq.pt was written by the REFERENCE's own classes (`torch.save({'optim': Adam, 'txt': Seq2Seq})`,
+    train/txt.py:185; make_golden.py `seq2seq_pickle`; parameter values compacted). Unpickling never runs this build's
+    __init__, so the instance lacks every attribute only this build sets: it must still resolve to the drop-in class and be
+    in forward-only mode (`with_grad` was an instance attribute)."""
+    import os
+    from conftest import GOLDEN
+    from txt2vid_amd.models.txt.basic import Seq2Seq, RecurrentModel
+    from txt2vid_amd.util.reflection import alias_reference_modules
+    _purge_reference_modules()
+    alias_reference_modules()
+    ck = torch.load(os.path.join(GOLDEN, 'ref_seq2seq.pt'), weights_only=False, map_location='cpu')
+    assert set(ck) == {'optim', 'txt'}
+    txt = ck['txt']
+    assert isinstance(txt, Seq2Seq) and isinstance(txt.encoder, RecurrentModel) and txt.decoder is txt.encoder
+    assert 'with_grad' not in txt.encoder.__dict__ and txt.encoder.with_grad is False
+    assert txt.encoder.encoding_size == 256 and txt.encoder.hidden_size == 128 and txt.encoder.bi and txt.encoder.num_layers == 4
+    want = Seq2Seq(vocab_size=21).state_dict()
+    got = txt.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        assert got[k].shape == want[k].shape and got[k].dtype == want[k].dtype, k
+    txt.differentiable(False)                                    # what train/gan.py does after loading
+    assert txt.encoder.__dict__['with_grad'] is False
+    assert isinstance(ck['optim'], torch.optim.Adam)
+
+
+@pytest.mark.parametrize('which', ['uncond', 'cond'])
+def test_checkpoint_written_by_the_real_reference_loads(which):
+    """tests/golden/ref_checkpoint_{uncond,cond}.pt: the dict `trainer.train()` saves (trainer.py:269-279), built by the
+    reference's CondGan.save_dict + torch.optim.Adam.state_dict after one optimiser step (make_golden.py `checkpoint`; one
+    element per tensor kept). `CondGan.load_from_dict` + both optimisers' `load_state_dict` must take it as is — the
+    reference's own resume sequence, train/gan.py:113-127 — and every tensor must arrive (closes SURVEY §8 f3)."""
+    import os
+    from conftest import GOLDEN
+    from txt2vid_amd.gan.cond_gan import CondGan
+    from txt2vid_amd.optim import Adam
+    if which == 'uncond':
+        from txt2vid_amd.models.tganv2.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2.discrim import MultiScaleDiscrim
+        gen, dis, txt = MultiScaleGen(width=64, height=64, num_channels=1), MultiScaleDiscrim(num_channels=1), None
+    else:
+        from txt2vid_amd.models.tganv2_cond.gen import MultiScaleGen
+        from txt2vid_amd.models.tganv2_cond.discrim import MultiScaleDiscrim
+        from txt2vid_amd.models.txt.basic import Seq2Seq
+        gen = MultiScaleGen(width=64, height=64, num_channels=1, cond_dim=256)
+        dis = MultiScaleDiscrim(num_channels=1, cond_dim=256)
+        txt = Seq2Seq(vocab_size=21)
+    ck = torch.load(os.path.join(GOLDEN, 'ref_checkpoint_%s.pt' % which), weights_only=False, map_location='cpu')
+    assert set(ck) == {'optG', 'optD', 'gen', 'video'} | ({'cond'} if txt is not None else set())
+    style = 'single_discrim.module.' if which == 'cond' else 'single_discrim.'
+    assert all(k.startswith(style) for k in ck['video'])
+    gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'])
+    for m in (gen, dis):
+        for p in m.parameters():
+            p.data.fill_(123.0)
+    gan.load_from_dict(ck)
+    for name, mod in (('gen', gen), ('video', dis)) + ((('cond', txt),) if txt is not None else ()):
+        sd = mod.state_dict()
+        assert set(sd.keys()) == set(ck[name].keys()), (name, set(sd) ^ set(ck[name]))
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(ck[name][k].shape), k
+            if v.dtype.is_floating_point:
+                assert torch.equal(v, ck[name][k].contiguous()), (name, k)        # every tensor arrived
+    optD = Adam([{'params': dis.parameters()}], lr=1e-4, betas=(0.5, 0.9))
+    optG = Adam([{'params': gen.parameters()}], lr=1e-4, betas=(0.5, 0.9))
+    optD.load_state_dict(ck['optD'])
+    optG.load_state_dict(ck['optG'])
+    for opt, mod, key in ((optD, dis, 'optD'), (optG, gen, 'optG')):
+        grp = opt.param_groups[0]
+        assert grp['lr'] == 2e-4 and tuple(grp['betas']) == (0.5, 0.999)       # the checkpoint's hyper-parameters win, as in torch
+        params = list(mod.parameters())
+        assert len(opt.state) == len(params) == len(ck[key]['state'])
+        for i, p in enumerate(params):
+            st, ref = opt.state[p], ck[key]['state'][i]
+            assert int(st['step']) == 1 and st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape
+            assert torch.equal(st['exp_avg'], ref['exp_avg'].contiguous()), (key, i)

@@ -186,6 +186,25 @@ def test_resnet3d_and_gp(golden, tag, cond_dim):
     close(net.fc_uncond.weight.grad, g[tag + '_gp_g_fc_uncond.weight'], rtol=3e-3, atol=3e-4)
 
 
+def test_gp_world_scale_applies_to_the_sum_combined_form_only(golden):
+    """Data parallelism scales the local gradient penalty by world_size so that gradient AVERAGING reproduces the global batch
+    SUM of the multi-scale form (losses.py:203); the single-discriminator form is a batch MEAN (losses.py:185,209), whose
+    rank average already is the global mean: there the scale must not apply."""
+    from txt2vid_amd.models.resnet3d import Resnet3D
+    from txt2vid_amd.gan.losses import _gradient_penalty
+    g = golden('resnet3d')
+    net = pour(Resnet3D(num_channels=1, cond_dim=0))
+    xr, xf = T(g['u_gp_xr']).to(DEV), T(g['u_gp_xf']).to(DEV)
+    alpha = torch.rand(2, 1, 1, 1, 1)
+    vals = {}
+    for combine, zc in ((torch.sum, True), (torch.mean, False)):
+        for scale in (1.0, 4.0):
+            vals[(combine, scale)] = float(_gradient_penalty(net, real_x=xr, fake_x=xf, zero_center=zc, combine=combine,
+                                                             alpha=alpha, scale=scale))
+    assert abs(vals[(torch.sum, 4.0)] - 4.0 * vals[(torch.sum, 1.0)]) < 1e-4 * abs(vals[(torch.sum, 4.0)])
+    assert vals[(torch.mean, 4.0)] == vals[(torch.mean, 1.0)]
+
+
 @pytest.mark.parametrize('tag,cond_dim', [('u', 0), ('c', 16)])
 def test_gen(golden, tag, cond_dim):
     if tag == 'u':
@@ -383,6 +402,35 @@ def test_graph_replay_matches_eager():
         tol = 5e-6 if i < 2 else 5e-4                              # the dynamics amplify ~x5-30 per iteration
         assert abs(got[0] - eager[i][0]) < tol and abs(got[1] - eager[i][1]) < tol, (i, got, eager[i])
     assert gs.graphs is not None
+
+
+def test_adam_step_counter_survives_a_second_capture():
+    """`GraphedTrainStep` is rebuilt when the batch shape changes (trainer.py). Replays advance Adam's step counter on the device
+    only; the second capture must carry on from it instead of falling back to the host-side count: after
+    2 eager + 1 capture/replay + 3 replays, then a new GraphedTrainStep with 2 eager + 1 capture/replay + 1 replay, both
+    optimisers have taken 10 steps."""
+    from txt2vid_amd.gan.trainer import GraphedTrainStep
+    gan, optD, optG, losses, prm = _make_uncond()
+    g = torch.Generator()
+    g.manual_seed(3)
+    xs = [(torch.rand(2, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(2)]
+    random.seed(5)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    gs = GraphedTrainStep(gan, optD, optG, losses, prm, DEV, (2, 1, 16, 64, 64), warmup=2)
+    for i in range(6):
+        gs.step(xs[i % 2])
+    torch.cuda.synchronize()
+    assert int(optD.step_dev[0].item()) == 6 and int(optG.step_dev[0].item()) == 6
+    gs2 = GraphedTrainStep(gan, optD, optG, losses, prm, DEV, (2, 1, 16, 64, 64), warmup=2)
+    for i in range(4):
+        gs2.step(xs[i % 2])
+    torch.cuda.synchronize()
+    assert gs2.graphs is not None
+    for opt in (optD, optG):
+        assert int(opt.step_dev[0].item()) == 10
+        steps = {int(st['step']) for st in opt.state_dict()['state'].values()}
+        assert steps == {10}, steps
 
 
 def _make_cond(V=21):

@@ -1,11 +1,23 @@
 """CPU: the oracle (oracle/tganv2_oracle.py) against the golden vectors produced by the REAL
-reference (tests/golden/make_golden.py). This is what pins the oracle."""
+reference (tests/golden/make_golden.py). This is what pins the oracle.
+
+The oracle issues the same ATen CPU operators in the same order as the reference, so on a host that runs the SAME kernels
+as the one that recorded the fixtures (tests/golden/host.json: torch version, CPU ISA level, thread count) the two agree to
+the last bit, and the bound asserted is 1e-6. On any other host oneDNN picks different code paths /
+summation orders: there the per-call bounds written at the call sites apply (cross-platform, <= 1e-3)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import tganv2_oracle as O
 
+HOST = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'host.json')))
+SAME_KERNELS = (torch.__version__ == HOST['torch'] and torch.backends.cpu.get_cpu_capability() == HOST['cpu_capability']
+                and torch.get_num_threads() == HOST['threads'])
+PIN = 1e-6                 # bound on |oracle - reference| relative to the tensor's scale when SAME_KERNELS
 TOL = dict(rtol=2e-4, atol=2e-5)
 
 
@@ -13,9 +25,30 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def close(a, b, rtol=2e-4, atol=2e-5):
+def close(a, b, rtol=2e-4, atol=2e-5, pinned=True):
+    """`pinned=False`: the oracle restates this piece with different operators than the reference (explicit time loops instead of
+    nn.LSTM), so bit-level agreement is not expected on any host."""
     a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+    b = np.asarray(b)
+    if SAME_KERNELS and pinned:
+        scale = max(float(np.abs(b).max()) if b.size else 0.0, 1e-30)
+        np.testing.assert_allclose(a, b, rtol=0, atol=PIN * scale)
+        return
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def scalar_close(got, want, tol):
+    """|got - want| < tol across platforms; < 1e-6 * max(1, |want|) on the recording host's kernels."""
+    if SAME_KERNELS:
+        tol = min(tol, PIN * max(1.0, abs(float(want))))
+    assert abs(float(got) - float(want)) < tol, (float(got), float(want), tol)
+
+
+def test_fixture_host_is_recorded():
+    assert set(HOST) == {'torch', 'cpu_capability', 'threads'}
+    print('oracle pin: %s (this host: torch %s, %s, %d threads; fixtures: %s)' %
+          ('bit-level, 1e-6 asserted' if SAME_KERNELS else 'cross-platform bounds', torch.__version__,
+           torch.backends.cpu.get_cpu_capability(), torch.get_num_threads(), HOST))
 
 
 def recipe_params(shapes, **kw):
@@ -26,12 +59,13 @@ def recipe_params(shapes, **kw):
     return P
 
 
-def norms_close(P, g, prefix, strip='', rtol=1e-3):
+def norms_close(P, g, prefix, strip='', rtol=1e-3, pinned=True):
     keys = [str(k) for k in g[prefix + '_keys']]
     vals = g[prefix + '_vals']
     for k, v in zip(keys, vals):
         got = float(P[strip + k].grad.norm()) if P[strip + k].grad is not None else -1.0
-        assert abs(got - v) <= rtol * max(abs(v), 1e-6) + 1e-7, (k, got, v)
+        r = min(rtol, PIN) if (SAME_KERNELS and pinned) else rtol
+        assert abs(got - v) <= r * max(abs(v), 1e-6) + 1e-7, (k, got, v)
 
 
 def test_downsample(golden):
@@ -74,7 +108,7 @@ def test_nonlocal3d_double_backward(golden):
     close(gx, g['at3_gx'])
     r = (gx ** 2).sum()
     r.backward()
-    assert abs(r.item() - float(g['at3_r'])) < 1e-3 * abs(float(g['at3_r']))
+    scalar_close(r.item(), float(g['at3_r']), 1e-3 * abs(float(g['at3_r'])))
     close(x.grad, g['at3_ggx'], rtol=1e-3, atol=1e-4)
     for k in shapes:
         close(P[k].grad, g['at3_gg_' + k], rtol=1e-3, atol=1e-4)
@@ -175,7 +209,7 @@ def test_resnet3d_and_gp(golden, tag, cond_dim):
     gp = O.gp_level(P, '', T(g[tag + '_gp_xr']), T(g[tag + '_gp_xf']),
                     T(g[tag + '_gp_cr']) if cond_dim else None, T(g[tag + '_gp_cf']) if cond_dim else None,
                     alpha=alpha)
-    assert abs(gp.item() - float(g[tag + '_gp'])) < 1e-3 * abs(float(g[tag + '_gp']))
+    scalar_close(gp.item(), float(g[tag + '_gp']), 1e-3 * abs(float(g[tag + '_gp'])))
     gp.backward()
     norms_close(P, g, tag + '_gp_gn')
     close(P['down.1.gamma'].grad, g[tag + '_gp_g_down.1.gamma'], rtol=1e-3, atol=1e-4)
@@ -228,8 +262,8 @@ def test_train_steps_uncond(golden):
             # probe grad norms of iteration 0 through hooks on the optimisers
             pass
         lD, lG = tr.step(x)
-        assert abs(lD - g['lossD'][it]) < 1e-3, (it, lD, g['lossD'][it])
-        assert abs(lG - g['lossG'][it]) < 1e-3, (it, lG, g['lossG'][it])
+        scalar_close(lD, g['lossD'][it], 1e-3)
+        scalar_close(lG, g['lossG'][it], 1e-3)
 
 
 def test_train_steps_cond(golden):
@@ -253,8 +287,8 @@ def test_train_steps_cond(golden):
         if it == 0:
             close(cond, g['cond0'], rtol=1e-4, atol=1e-5)
         lD, lG = tr.step(x, cond=cond)
-        assert abs(lD - g['lossD'][it]) < 1e-3, (it, lD, g['lossD'][it])
-        assert abs(lG - g['lossG'][it]) < 1e-3, (it, lG, g['lossG'][it])
+        scalar_close(lD, g['lossD'][it], 1e-3)
+        scalar_close(lG, g['lossG'][it], 1e-3)
 
 
 ZOO = ['vanilla', 'hinge', 'hinge3', 'wasserstein', 'rasgan', 'ralsgan']
@@ -290,21 +324,24 @@ def test_txt_pretrain(golden, tag, teacher):
     (train/txt.py:160-178, models/txt/basic.py:49-101) on a ragged batch: loss, logits, greedy symbols, sentence code, per-key
     gradient norms and five full gradients."""
     from oracle import txt_oracle as TO
+
+    def close_(a, b, **kw):               # time loops vs nn.LSTM: different operators, no bit-level pin (measured 6e-6 of scale)
+        close(a, b, pinned=False, **kw)
     g = golden('txt_pretrain')
     P = txt_params()
     tokens, lengths = T(g['tokens']), [int(v) for v in g['lengths']]
     out, (h_n, c_n), hn = TO.encode(P, tokens, lengths)
-    close(out, g[tag + '_enc_out'])
-    close(h_n, g[tag + '_h_n'])
-    close(c_n, g[tag + '_c_n'])
+    close_(out, g[tag + '_enc_out'])
+    close_(h_n, g[tag + '_h_n'])
+    close_(c_n, g[tag + '_c_n'])
     loss, decoded, symbols, hn = TO.pretrain_loss(P, tokens, lengths, teacher)
-    close(hn, g[tag + '_hn'])
-    close(decoded, g[tag + '_decoded'], rtol=2e-4, atol=2e-5)
+    close_(hn, g[tag + '_hn'])
+    close_(decoded, g[tag + '_decoded'], rtol=2e-4, atol=2e-5)
     assert (symbols.numpy() == g[tag + '_symbols']).all()
-    close(loss, g[tag + '_loss'], rtol=1e-5, atol=1e-6)
-    close(TO.pretrain_loss(P, tokens, lengths, teacher, reduction='sum')[0], g[tag + '_sum_loss'], rtol=1e-5, atol=1e-5)
+    close_(loss, g[tag + '_loss'], rtol=1e-5, atol=1e-6)
+    close_(TO.pretrain_loss(P, tokens, lengths, teacher, reduction='sum')[0], g[tag + '_sum_loss'], rtol=1e-5, atol=1e-5)
     loss.backward()
-    norms_close(P, g, tag + '_gn')
+    norms_close(P, g, tag + '_gn', pinned=False)
     for k in ('encoder.embed.weight', 'encoder.to_vocab.bias', 'encoder.lstm.bias_hh_l0', 'encoder.lstm.bias_ih_l3_reverse',
               'encoder.lstm.weight_hh_l1_reverse'):
-        close(P[k].grad, g[tag + '_g_' + k], rtol=1e-3, atol=1e-5)
+        close_(P[k].grad, g[tag + '_g_' + k], rtol=1e-3, atol=1e-5)
