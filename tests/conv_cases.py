@@ -54,7 +54,7 @@ def _stage(B, s):
     for lvl in range(4):
         b, t, sz = -(-B // (1 << lvl)), 16 >> lvl, 8 << lvl
         for _ in range(s):
-            t, sz = (t + 1) // 2 if t > 1 else 1, sz // 2
+            t, sz = (t + 1) // 2 if t > 1 else 1, max(1, sz // 2)
         out.append((b, t, sz, sz))
     return out
 

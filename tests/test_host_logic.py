@@ -240,3 +240,5 @@ def test_checkpoint_written_by_the_real_reference_loads(which):
             st, ref = opt.state[p], ck[key]['state'][i]
             assert int(st['step']) == 1 and st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape
             assert torch.equal(st['exp_avg'], ref['exp_avg'].contiguous()), (key, i)
+            for k in ('exp_avg', 'exp_avg_sq'):        # dense memory of their own: the kernels walk them through raw pointers
+                assert st[k].is_contiguous() and st[k].untyped_storage().nbytes() >= st[k].numel() * 4, (key, i, k)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libt2v_hip.so')
+LIB_PATH = os.environ.get('T2V_LIB') or os.path.join(_HERE, 'csrc', 'libt2v_hip.so')     # T2V_LIB: developer A/B builds only
 
 MAX_TAPS = 27
 

@@ -2157,12 +2157,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
 #define W3_BP (WG_BK + 3)      // x strip pitch: 34 columns + 1 pad (odd)
 struct LiveRows { int8_t r[9]; int32_t n; };    // slab row slot -> original kernel row (dz,dy) index a*kH + b
 
+#define W3_XP (WG_BK + 3)      // x copies: columns -1 .. 32 (two dummy columns take the out-of-tile writes), odd pitch
+
+// Per-chunk work outside the MFMA loop is what bounds this kernel (a chunk is only 32 voxels = 48 MFMAs per wave): the
+// voxel decode and the 17 gather addresses used to cost ~400 vector instructions per chunk (three reciprocal divisions,
+// 64-bit multiply-adds per load, the member's descriptor re-read from the kernel arguments), the staging another ~230
+// (exec-masked edge writes). Now: the member's descriptor is cached in scalar registers and re-read only when the chunk
+// range moves on to the next member; power-of-two extents (every shape of the model) decode with shifts; all offsets are
+// 32-bit element offsets from the member's base pointers (build_wtable guarantees M * C < 2^31) and the 8 rows a thread
+// gathers are a constant stride apart; the three shifted copies of x are written unconditionally (the two writes that
+// fall outside the tile land in dummy columns).
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                           const int Cout, const int kD, const int kH, const int flags,
                                                           const int chunks_per_split, const LiveRows live,
                                                           float* __restrict__ bias_slab) {
-    __shared__ float As[64 * W3_AP];   // gy^T tile [co][m]
-    __shared__ float Bs[3 * 64 * W3_AP];   // three shifted + masked copies of the x tile: [dx][ci][m]
+    __shared__ float As[64 * W3_AP];          // gy^T tile [co][m]
+    __shared__ float Bs[3 * 64 * W3_XP];      // three shifted + masked copies of the x tile: [dx][ci][1 + m]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave & 1, wci = wave >> 1;
@@ -2173,8 +2183,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
     const int split = lin / (int)gridDim.y;
     const int krow = live.r[rslot];
     const int dz = krow / kH - kD / 2, dy = krow % kH - kH / 2;
-    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
     const int ml = tid & 31, rl = tid >> 5;
+    const bool full = co0 + 64 <= Cout && ci0 + 64 <= Cin;       // (block-uniform) no channel clamping needed
 
     f32x16 acc0, acc1, acc2;
 #pragma unroll
@@ -2187,115 +2198,143 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
 
     float ra[8], rb[8], rh = 0.f;
     uint32_t pm0 = 0, pm1 = 0, pm2 = 0;       // pending chunk: validity of (voxel, dx) as 32-bit masks
-    int pend_DHW = 1;
+    bool pend_mv = false;
     // bias gradient on the side: the workgroups of the first channel tile and first kernel row also add up the dL/dy
     // values they stage anyway (bias_slab[split][co], summed over the splits by one workgroup of the reduce kernel)
     const bool do_bias = bias_slab != nullptr && ci0 == 0 && rslot == 0;
-    bool pend_mv = false;
     float bsum[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
-#ifdef T2V_ABLATION
-    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
-#endif
-    auto load_chunk = [&](int q) {
-#ifdef T2V_ABLATION
-        if (dbg_noload && q != q0) return;
-#endif
+
+    // ---- the member the current chunk range lies in (scalar state, reloaded when q passes g_end)
+    int g_i = -1, g_begin = 0, g_end = 0;
+    int gD = 1, gH = 1, gW = 1, gHW = 1, gDHW = 1, gM = 0, g_lw = 0, g_lhw = 0, g_shift = 0;
+    bool g_pow2 = false;
+    // buffer descriptors of the member's x and dL/dy: 32-bit byte offsets in the gathers (one add, no 64-bit address
+    // arithmetic), out-of-range offsets read 0. Built from kernel-argument scalars only (provably wave-uniform).
+    __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_y = g_x;
+    auto enter_group = [&](int q) {
         int gi = 0;
 #pragma unroll
         for (int k = 1; k < T2V_MAX_GROUPS; ++k)
             if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
         const t2v_conv_group& gd = tab.g[gi];
-        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
-        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
-        const bool mv = m < M;
-        bool vc = false;
-        int w_ = 0;
-        size_t gbase = 0;
-        ptrdiff_t xb = 0;              // element index of x[n, 0, voxel + (dz,dy,0)] (0 when not loadable)
-        if (mv) {
-            const bool small = M < (1 << 24);
+        g_i = gi;
+        g_begin = tab.chunk_start[gi];
+        g_end = tab.chunk_start[gi + 1];
+        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW; gM = gd.N * gDHW;
+        g_pow2 = ((gD & (gD - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
+        g_lw = __builtin_ctz(gW);
+        g_lhw = g_lw + __builtin_ctz(gH);
+        g_shift = dz * gHW + dy * gW;
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)gM * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
+        g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
+    };
+
+    auto load_chunk = [&](int q) {
+        if (q >= g_end || g_i < 0) enter_group(q);                  // (uniform)
+        const int D = gD, H = gH, W = gW, HW = gHW, DHW = gDHW;
+        const int m = (q - g_begin) * WG_BK + ml;
+        const bool mv = m < gM;
+        int sp, d, h, w_;
+        if (g_pow2) {                                               // (uniform) every extent a power of two: shifts
+            sp = m & (DHW - 1);
+            d = sp >> g_lhw;
+            h = (sp >> g_lw) & (H - 1);
+            w_ = sp & (W - 1);
+        } else {
+            const bool small = gM < (1 << 24);
             const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
-            const int sp = m - n * DHW;
-            const int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            sp = m - n * DHW;
+            d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
             const int r = sp - d * HW;
-            const int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
             w_ = r - h * W;
-            gbase = (size_t)n * Cout * DHW + sp;
-            vc = (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H;
-            xb = vc ? (ptrdiff_t)((size_t)n * Cin * DHW + sp) + (ptrdiff_t)(dz * HW + dy * W) : 0;
         }
+        const bool vc = mv && (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H;
+        // element offsets of (n, channel 0, voxel): n*DHW = m - sp
+        const uint32_t gbase = mv ? (uint32_t)(m - sp) * (uint32_t)Cout + (uint32_t)sp : 0u;
+        const uint32_t xb = vc ? (uint32_t)(m - sp) * (uint32_t)Cin + (uint32_t)(sp + g_shift) : 0u;
         // wave-uniform validity masks (every wave sees the same 32 voxels in lanes 0-31)
         pm0 = (uint32_t)__ballot(vc && w_ >= 1);
         pm1 = (uint32_t)__ballot(vc);
         pm2 = (uint32_t)__ballot(vc && w_ + 1 < W);
-        pend_DHW = DHW;
         pend_mv = mv;
-        const float* __restrict__ gy = gd.y;
-        const float* __restrict__ x = gd.x;
+        const uint32_t uDHW = (uint32_t)DHW;
+        if (full) {                                                 // rows rl, rl+8, ...: a constant (scalar) stride apart
+            const uint32_t oa = (gbase + (uint32_t)(co0 + rl) * uDHW) * 4u, ob = (xb + (uint32_t)(ci0 + rl) * uDHW) * 4u;
+            const int st = 32 * DHW;                                // 8 rows, in bytes
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {           // unconditional loads from clamped addresses
-            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
-            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
-            rb[p] = x[xb + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
+            for (int p = 0; p < 8; ++p) {
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, oa, p * st, 0));
+                rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, ob, p * st, 0));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {                           // clamped rows (zeroed when staged)
+                const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uDHW) * 4u, 0, 0));
+                rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    g_x, (xb + (uint32_t)(ci < Cin ? ci : Cin - 1) * uDHW) * 4u, 0, 0));
+            }
         }
         // the two extra strip columns: linear neighbours of voxel 0 (left) and voxel 31 (right) of the chunk
-        const ptrdiff_t xb_l = __shfl(xb, 0, 64), xb_r = __shfl(xb, 31, 64);
-        const bool use_l = (pm0 & 1u) != 0, use_r = (pm2 >> 31) != 0;
+        const uint32_t xb_l = __shfl(xb, 0, 64), xb_r = __shfl(xb, 31, 64);
         if (tid < 128) {
             const int row = tid >> 1, side = tid & 1;
             const int ci = ci0 + row;
-            const ptrdiff_t base = side ? (use_r ? xb_r + 1 : 0) : (use_l ? xb_l - 1 : 0);
-            rh = x[base + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
+            const uint32_t base = side ? (((pm2 >> 31) & 1u) ? xb_r + 1u : 0u) : ((pm0 & 1u) ? xb_l - 1u : 0u);
+            rh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                g_x, (base + (uint32_t)(ci < Cin ? ci : Cin - 1) * uDHW) * 4u, 0, 0));
         }
     };
 
-    // Staging writes THREE shifted + masked copies of the x strip (dx = -1, 0, +1), so the MFMA loop is four plain
-    // LDS reads per three MFMAs with no per-step mask arithmetic on the vector ALU.
-    const bool m_c = true;
-    (void)m_c;
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
-#ifdef T2V_ABLATION
-        if (!(dbg_nostage && q != q0))
-#endif
         {
-            const bool v0 = ml + 1 < WG_BK && ((pm0 >> (ml + 1)) & 1u);   // my voxel is the LEFT neighbour of voxel ml+1
-            const bool v1 = (pm1 >> ml) & 1u;
-            const bool v2 = ml >= 1 && ((pm2 >> (ml - 1)) & 1u);          // ... the RIGHT neighbour of voxel ml-1
+            // my voxel ml is the LEFT neighbour of voxel ml+1 (copy dx=-1, column ml+1), itself (column ml), and the RIGHT
+            // neighbour of voxel ml-1 (copy dx=+1, column ml-1); columns -1 and 32 are dummies
+            const bool v0 = (((uint64_t)pm0 >> (ml + 1)) & 1u) != 0;
+            const bool v1 = ((pm1 >> ml) & 1u) != 0;
+            const bool v2 = ((((uint64_t)pm2 << 1) >> ml) & 1u) != 0;
             if (do_bias) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
             }
+            float* pa = &As[rl * W3_AP + ml];
+            float* pb = &Bs[rl * W3_XP + 1 + ml];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const int row = rl + p * 8;
-                const int co = co0 + row, ci = ci0 + row;
-                As[row * W3_AP + ml] = (co < Cout) ? ra[p] : 0.f;
-                float v = (ci < Cin) ? rb[p] : 0.f;
-                v = relu_in ? fmaxf(v, 0.f) : v;
-                Bs[(1 * 64 + row) * W3_AP + ml] = v1 ? v : 0.f;
-                if (ml + 1 < WG_BK) Bs[(0 * 64 + row) * W3_AP + ml + 1] = v0 ? v : 0.f;
-                if (ml >= 1) Bs[(2 * 64 + row) * W3_AP + ml - 1] = v2 ? v : 0.f;
+                float a = ra[p], v = fmaxf(rb[p], relu_floor);
+                if (!full) {
+                    const int row = rl + p * 8;
+                    a = (co0 + row < Cout) ? a : 0.f;
+                    v = (ci0 + row < Cin) ? v : 0.f;
+                }
+                pa[p * 8 * W3_AP] = a;
+                pb[(0 * 64 + p * 8) * W3_XP + 1] = v0 ? v : 0.f;
+                pb[(1 * 64 + p * 8) * W3_XP] = v1 ? v : 0.f;
+                pb[(2 * 64 + p * 8) * W3_XP - 1] = v2 ? v : 0.f;
             }
             if (tid < 128) {
                 const int row = tid >> 1, side = tid & 1;
-                float v = (ci0 + row < Cin) ? rh : 0.f;
-                v = relu_in ? fmaxf(v, 0.f) : v;
-                if (side) Bs[(2 * 64 + row) * W3_AP + WG_BK - 1] = ((pm2 >> 31) & 1u) ? v : 0.f;
-                else Bs[(0 * 64 + row) * W3_AP + 0] = (pm0 & 1u) ? v : 0.f;
+                float v = (ci0 + row < Cin) ? fmaxf(rh, relu_floor) : 0.f;
+                if (side) Bs[(2 * 64 + row) * W3_XP + 1 + WG_BK - 1] = ((pm2 >> 31) & 1u) ? v : 0.f;
+                else Bs[(0 * 64 + row) * W3_XP + 1 + 0] = (pm0 & 1u) ? v : 0.f;
             }
         }
         __syncthreads();
         if (q + 1 < q1) load_chunk(q + 1);
+        const float* qa = &As[(wco * 32 + l31) * W3_AP + hi];
+        const float* qb = &Bs[(wci * 32 + l31) * W3_XP + 1 + hi];
 #pragma unroll
         for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
-            const int kc = k2 * 2 + hi;
-            const float a = As[(wco * 32 + l31) * W3_AP + kc];
-            const float b0 = Bs[(0 * 64 + wci * 32 + l31) * W3_AP + kc];
-            const float b1 = Bs[(1 * 64 + wci * 32 + l31) * W3_AP + kc];
-            const float b2 = Bs[(2 * 64 + wci * 32 + l31) * W3_AP + kc];
+            const float a = qa[k2 * 2];
+            const float b0 = qb[0 * 64 * W3_XP + k2 * 2];
+            const float b1 = qb[1 * 64 * W3_XP + k2 * 2];
+            const float b2 = qb[2 * 64 * W3_XP + k2 * 2];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc2, 0, 0, 0);
@@ -2591,7 +2630,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
                          WGroupTable& tab, WgradPlan& p) {
     if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
     if ((kD != 1 && kD != 3) || (kH != 1 && kH != 3) || (kW != 1 && kW != 3)) return false;
-    long nch = 0;
+    long nch = 0, maxMC = 0;
     p.live = 0;
     tab.n = ngroups;
     for (int i = 0; i < ngroups; ++i) {
@@ -2600,6 +2639,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
         if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1) return false;
         const long M = (long)g.N * g.D * g.H * g.W;
         if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;
+        if (M * (long)(Cin > Cout ? Cin : Cout) > maxMC) maxMC = M * (long)(Cin > Cout ? Cin : Cout);
         tab.g[i] = g;
         tab.chunk_start[i] = (int32_t)nch;
         nch += (M + WG_BK - 1) / WG_BK;
@@ -2614,7 +2654,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     // kW == 3 with at least one member wider than one voxel: the three dx taps of a kernel row share a workgroup
     bool anyw = false;
     for (int i = 0; i < ngroups; ++i) anyw = anyw || groups[i].W > 1;
-    p.rows3 = (kW == 3) && anyw && Cin >= 64;
+    p.rows3 = (kW == 3) && anyw && Cin >= 64 && maxMC < (1L << 30);   // the 3-tap kernel gathers through 32-bit byte offsets
     p.liverows = 0;
     for (int r = 0; r < kD * kH; ++r)
         if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;

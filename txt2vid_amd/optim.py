@@ -5,6 +5,18 @@ import torch
 from . import functional as TF
 
 
+def _densify_state(opt):
+    """Every per-parameter state tensor contiguous, with the parameter's shape and dtype, in memory of its own."""
+    for p, st in opt.state.items():
+        for k, v in list(st.items()):
+            if isinstance(v, torch.Tensor) and v.dim() > 0:
+                if tuple(v.shape) != tuple(p.shape):
+                    raise ValueError('optimiser state %r has shape %s for a parameter of shape %s' % (k, tuple(v.shape), tuple(p.shape)))
+                dense = v.is_contiguous() and v.untyped_storage().nbytes() >= v.numel() * v.element_size()
+                if not dense or v.dtype != p.dtype or v.device != p.device:
+                    st[k] = v.to(device=p.device, dtype=p.dtype).contiguous().clone()
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if weight_decay != 0:
@@ -28,6 +40,12 @@ class Adam(torch.optim.Optimizer):
                 if st:
                     st['step'] = n
         self.step_dev = torch.tensor([float(n), 0.0, 0.0], device=device, dtype=torch.float32)
+
+    def load_state_dict(self, state_dict):
+        """torch's loader keeps whatever strides the checkpoint's tensors had (`.to(device)` preserves them); the kernels walk the
+        moments as dense arrays through raw pointers, so anything that is not a dense tensor of its own is re-materialised."""
+        super().load_state_dict(state_dict)
+        _densify_state(self)
 
     def state_dict(self):
         """Same layout as torch.optim.Adam. Under graph replay the step counter advances on the device only: fold it back
@@ -79,6 +97,10 @@ class SGD(torch.optim.Optimizer):
 
     def make_capturable(self, device):
         """Nothing step-dependent lives on the host once the momentum buffers exist (they do after the eager warm-up)."""
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        _densify_state(self)
 
     @torch.no_grad()
     def step(self, closure=None):
