@@ -566,8 +566,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
 
     __shared__ __attribute__((aligned(16))) float As[2 * BKT * AP];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BKT * BN];
-    __shared__ int s_roff[T2V_MAX_TAPS];
-    __shared__ int s_widx[T2V_MAX_TAPS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -590,22 +588,29 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     const int ndx = gd.dx[0] < 0 ? 3 : 1;           // taps r*ndx + {0,1,2} = dx -1, 0, +1 of row tap r
     const int nrow = ntaps / ndx;
 
-    if (tid < nrow) s_roff[tid] = gd.dz[tid * ndx] * HW + gd.dy[tid * ndx] * W;
-    if (tid < ntaps) s_widx[tid] = gd.widx[tid];
+    // per-tap tables held one entry per LANE (read back with v_readlane at the wave-uniform tap index: no LDS round trip
+    // and no wait in the chunk loop): byte offset of row tap r inside x, packed-weight slot of tap t
+    const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
+    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    const int tab_widx = gd.widx[lane_t];
+    // buffer descriptors (wave-uniform: kernel arguments only). All gathers use 32-bit byte offsets — the host only selects
+    // this kernel when every member's M * Cin * 4 fits 32 bits — with the channel stride in the scalar offset.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)M * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
 
     // ---- staging coordinates: this thread's voxel of the strip body, and (threads < 2 BKT) one halo element
     const int ma_l = tid % BM, ka_l = tid / BM;
     const int he = tid / BKT, hk = tid % BKT;        // halo: he = 0 left (voxel m0 - 1), 1 right (voxel m0 + BM)
     const bool halo_thread = tid < 2 * BKT;
     uint32_t rowmask = 0, rowmask_h = 0;
-    size_t xbase = 0, xbase_h = 0;
+    uint32_t xbase = 0, xbase_h = 0;         // element offsets of (n, channel 0, voxel)
     {
         const int m_a = m0 + ma_l;
         if (m_a < M) {
             const int n = m_a / DHW, sp = m_a - n * DHW;
             const int d = sp / HW, r = sp - d * HW;
             const int h = r / W;
-            xbase = (size_t)n * Cin * DHW + sp;
+            xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
                 const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
             const int n = m_h / DHW, sp = m_h - n * DHW;
             const int d = sp / HW, r = sp - d * HW;
             const int h = r / W;
-            xbase_h = (size_t)n * Cin * DHW + sp;
+            xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
                 const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
@@ -636,7 +641,10 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4);
     const bool vact = (NV >= 256) || (tid < NV);
     const bool co_ok = VECB ? (vact && (co0 + cv_l) < Cout) : (co0 + cob_l) < Cout;
-    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
+    // this thread's fixed byte offsets: strip body (channel ka_l), halo element (channel hk), weight element
+    const uint32_t xoff = (xbase + (uint32_t)ka_l * (uint32_t)DHW) * 4u, xoff_h = (xbase_h + (uint32_t)hk * (uint32_t)DHW) * 4u;
+    const uint32_t woff = co_ok ? (uint32_t)((VECB ? kv_l : kb_l) * Cout + co0 + (VECB ? cv_l : cob_l)) * 4u : 0u;
 
     f32x16 acc[NCO][NM];
 #pragma unroll
@@ -655,7 +663,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     const int q0 = blockIdx.z * cps;
     int q1 = q0 + cps;
     if (q1 > nchunks) q1 = nchunks;
-    __syncthreads();   // s_roff / s_widx visible
 
     // chunk q = (r * ncb + cb) * ndx + d
     int r_cur = q0 / (ncb * ndx);
@@ -672,24 +679,28 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
         pend_has_a = force_a || d_cur == 0;
         pend_dx = ndx == 3 ? d_cur - 1 : 0;
         if (pend_has_a) {
+            const int roff = __builtin_amdgcn_readlane(tab_roff, r_cur);
+            const int sx = c0 * DHW * 4;                       // (scalar) first channel of the block
             pend_av = (rowmask >> r_cur) & 1u;
-            const float* px = x + xbase + (pend_av ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + ka_l) * DHW;
+            const uint32_t vo = xoff + (pend_av ? (uint32_t)roff : 0u);
 #pragma unroll
-            for (int j = 0; j < LA; ++j) ra[j] = px[(size_t)j * KSA * DHW];
+            for (int j = 0; j < LA; ++j)
+                ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, sx + j * (KSA * 4) * DHW, 0));
             if (halo_thread) {
                 pend_hv = (rowmask_h >> r_cur) & 1u;
-                rah = x[xbase_h + (pend_hv ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + hk) * DHW];
+                rah = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff_h + (pend_hv ? (uint32_t)roff : 0u), sx, 0));
             }
         }
         const int t = r_cur * ndx + d_cur;
+        const int sw = (__builtin_amdgcn_readlane(tab_widx, t) * Cin + c0) * Cout * 4;     // (scalar) first row of the chunk's weights
         if (VECB) {
-            const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kv_l) * Cout + co0 + cv_l : wp;
 #pragma unroll
-            for (int j = 0; j < LBV; ++j) rbv[j] = *reinterpret_cast<const float4*>(pw + (size_t)j * KSBV * Cout);
+            for (int j = 0; j < LBV; ++j)
+                rbv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, sw + j * (KSBV * 4) * Cout, 0));
         } else {
-            const float* pw = co_ok ? wp + ((size_t)s_widx[t] * Cin + c0 + kb_l) * Cout + co0 + cob_l : wp;
 #pragma unroll
-            for (int j = 0; j < LB; ++j) rb[j] = pw[(size_t)j * KSB * Cout];
+            for (int j = 0; j < LB; ++j)
+                rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, sw + j * (KSB * 4) * Cout, 0));
         }
     };
     auto stage = [&](int ab, int bb) {
@@ -697,12 +708,10 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
             float* as = As + ab * (BKT * AP);
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                const float val = pend_av ? ra[j] : 0.f;
-                as[(ka_l + j * KSA) * AP + 1 + ma_l] = relu_in ? fmaxf(val, 0.f) : val;
+                as[(ka_l + j * KSA) * AP + 1 + ma_l] = pend_av ? fmaxf(ra[j], relu_floor) : 0.f;
             }
             if (halo_thread) {
-                const float val = pend_hv ? rah : 0.f;
-                as[hk * AP + (he ? BM + 1 : 0)] = relu_in ? fmaxf(val, 0.f) : val;
+                as[hk * AP + (he ? BM + 1 : 0)] = pend_hv ? fmaxf(rah, relu_floor) : 0.f;
             }
         }
         float* bs = Bs + bb * (BKT * BN);
@@ -1479,6 +1488,14 @@ static bool strip_ok(const GroupTable& tab) {
     }
     return any3;
 }
+// the fp32 strip kernel gathers x through 32-bit byte offsets (buffer loads)
+static bool strip_fits32(const GroupTable& tab, int Cin) {
+    for (int i = 0; i < tab.n; ++i) {
+        const t2v_conv_group& g = tab.g[i];
+        if ((long)g.N * g.D * g.H * g.W * (long)Cin >= (1L << 30)) return false;
+    }
+    return true;
+}
 static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
 static bool g_ksplit_waves = getenv("T2V_NO_KSPLIT_WAVES") == nullptr;
 static long g_ksplit_max_blocks = getenv("T2V_KSPLIT_MAX_BLOCKS") ? atol(getenv("T2V_KSPLIT_MAX_BLOCKS")) : 768;
@@ -1490,7 +1507,7 @@ static long g_ksplit_max_blocks = getenv("T2V_KSPLIT_MAX_BLOCKS") ? atol(getenv(
 struct ConvVariant { bool strip; int ks; };
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
     ConvVariant v{false, 1};
-    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab)) {
+    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
         v.strip = true;
         const long nblocks = (long)tab.tile_start[tab.n] * ((Cout + BN - 1) / BN) * p.S;
         if (BM == 64 && BN == 64 && BKT == 32 && g_ksplit_waves && nblocks <= g_ksplit_max_blocks) v.ks = 2;
