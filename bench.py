@@ -76,13 +76,21 @@ def synthetic_batches(batch, n, seed, dev, size=64, channels=1):
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate `--pmc` runs of tools/conv_micro.py; a PMC pass cannot run inside this
-    process). Returns (bytes, note) or (None, None)."""
+    process). The profile names the commit whose conv.hip it measured; when the kernel source has changed since, the
+    figure is dropped (None) rather than reported stale. Returns (bytes, note) or (None, None)."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        if not os.path.exists(path):
+            return None, None
+        d = json.load(open(path))
+        import hashlib
+        src = open(os.path.join(ROOT, 'txt2vid_amd', 'csrc', 'conv.hip'), 'rb').read()
+        if d.get('conv_hip_sha1') != hashlib.sha1(src).hexdigest():
+            return None, 'profiles/r02_pmc_traffic.json was measured on an older conv.hip (sha1 %s): dropped' % d.get('conv_hip_sha1', '?')[:10]
         for k, v in d['kernels'].items():
             if 'conv_igemm' in k and v.get('FETCH_SIZE_KB_per_launch') and v.get('WRITE_SIZE_KB_per_launch'):
                 b = (v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
-                return b, ('profiles/r01_pmc_traffic.json: %s, per launch; algorithmic %.0f MB; FETCH_SIZE may under-count '
+                return b, ('profiles/r02_pmc_traffic.json: %s, per launch; algorithmic %.0f MB; FETCH_SIZE may under-count '
                            'streaming reads by up to 2x on gfx950' % (d['workload'].split(':')[1].split(',')[0].strip(),
                                                                       d['algorithmic_bytes_per_launch']['igemm (x + y + w)'] / 1e6))
     except Exception:
@@ -121,6 +129,22 @@ def cpu_baseline(threads, budget_s=45.0):
             'steps_per_sec': 1.0 / dt}
 
 
+def extra_record(flags):
+    """Run `python bench.py <flags>` as a child (no CPU baseline, no roofline passes) and return the fields of its JSON line that
+    identify and size the measurement; an error string if it failed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_roofline', '--no_d_roofline', '--no_extra']
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        line = [l for l in p.stdout.decode(errors='replace').splitlines() if l.startswith('{')]
+        if p.returncode != 0 or not line:
+            return {'error': 'child exited %d: %s' % (p.returncode, p.stderr.decode(errors='replace')[-300:])}
+        r = json.loads(line[-1])
+        return {k: r.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_losses', 'launch_mode')}
+    except Exception as e:                                    # never let the extra record take the headline down
+        return {'error': repr(e)[:300]}
+
+
 def self_launch(n):
     """One process per GPU over RCCL, as the driver's own N>1 command line does it:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>."""
@@ -155,6 +179,7 @@ def main():
     ap.add_argument('--size', type=int, default=64, choices=(64, 128), help='frame side; 128 with --channels 3 --cond --bf16 --batch 16 '
                                                                           '= the per-GPU share of BASELINE configs[4] (MSRVDC shape)')
     ap.add_argument('--channels', type=int, default=1, choices=(1, 3))
+    ap.add_argument('--no_extra', action='store_true', help='skip the extra BASELINE configs[2] record (text-conditioned, bf16 compute) of the default run')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -284,6 +309,7 @@ def main():
     if prof:
         out = (C.c_double * 18)()
         over = lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
+        conv_flops = out[1] + out[4] + out[10] + out[16]      # fp32 implicit GEMM + weight gradients + thin kernels + bf16 GEMM
         if bf16:                                   # bf16-compute mode: the dominant kernel is the bf16 GEMM, priced against the bf16 peak
             out[0], out[1], out[2] = out[15], out[16], out[17]
         ms, fl, cnt = out[0] + out[12], out[1], out[2]
@@ -304,6 +330,11 @@ def main():
                                       '%d eager iterations right after the timed region (graph replay has no launch calls to '
                                       'bracket)' % prof_steps),
                     'gpu_ms_per_step': ms / prof_steps, 'pool_overflow': bool(over),
+                    # every convolution FLOP the iteration executes (forward / data / weight gradients, thin kernels) over the
+                    # WHOLE step time: what the step as a whole achieves against the matrix peak (kernel fraction above: the
+                    # implicit-GEMM launches alone over their own time)
+                    'all_in_frac': conv_flops / prof_steps / (dt / args.steps) / 1e12 / peak,
+                    'executed_conv_tflop_per_step': conv_flops / prof_steps / 1e12,
                     'wgrad': {'achieved': (out[4] / (out[3] * 1e-3) / 1e12) if out[3] > 0 else None,
                               'launches_per_step': out[5] / prof_steps, 'gpu_ms_per_step': out[3] / prof_steps,
                               'reduce_gpu_ms_per_step': out[6] / prof_steps}}
@@ -348,6 +379,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond and default_shape:
         log('timing the CPU oracle on %d host threads' % host_threads())
         res['cpu_baseline'] = cpu_baseline(host_threads())
+    if rank == 0 and world == 1 and not args.no_extra and not args.cond and not bf16 and default_shape and not args.eager:
+        # BASELINE configs[2] (text-conditioned, Bi-LSTM sentence codes, non-local blocks on, bf16 compute) as an EXTRA record of the
+        # same line: measured by a child process after this one's timed region, never part of `value`
+        log('extra record: BASELINE configs[2] (child process)')
+        res['extra_records'] = {'configs[2]': extra_record(['--cond', '--bf16', '--batch', str(args.batch), '--steps', '10', '--warmup', '3'])}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

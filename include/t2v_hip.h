@@ -63,6 +63,7 @@ typedef struct {
 /* w[Cout][Cin][T] (PyTorch layout, T = kD*kH*kW) -> wp[ntaps][Cin][Cout] for the forward GEMM
  * (mode 0: wp[j][ci][co] = w[co][ci][taps[j]]) or wp[ntaps][Cout][Cin] for the data-gradient GEMM
  * (mode 1: wp[j][co][ci] = w[co][ci][T-1-taps[j]], i.e. the spatially mirrored kernel).
+ * mode | 8: the source is stored tap-major, w[T][Cout][Cin] (the ConvLSTM's master weights, whose live taps are then contiguous).
  * `taps` is a HOST array of the ntaps original tap indices. */
 int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
                     int mode, void* stream);
@@ -117,11 +118,47 @@ int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* groups, int ngr
                                            int kH, int kW);
 int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                            float* dw, float* slab, int flags, void* stream);
+/* Deferred, batched reduction of the weight-gradient partial sums (one reduce launch per backward pass instead of one per
+ * layer). t2v_conv_wgrad_grouped_partial = t2v_conv_wgrad_grouped[_bias] without its second (reduce) kernel: the k-split
+ * partial sums stay in `slab` (same size query as the full call; `want_bias` != 0 also keeps the dL/dy side-sums behind
+ * it — MFMA kernels only, i.e. Cin >= 64) and *out_src describes them. t2v_wgrad_reduce_multi then sums, for every
+ * destination of a DEVICE table, its sources in order: dw (+)= sum_src sum_splits slab, dbias likewise.
+ * Replaces the per-parameter accumulation autograd does for conv weights (AccumulateGrad of the call sites above). */
+#define T2V_WGRAD_MAX_SRC 6
+typedef struct {
+    const float* slab;        /* [S][ntaps][Cout*Cin] partial sums                                   */
+    const float* bias_slab;   /* [S][Cout] partial dL/dy sums, or NULL                                */
+    int32_t ntaps, S;         /* slab slots, k-splits                                                */
+    int8_t map[T2V_MAX_TAPS]; /* original tap t -> slab slot, -1: tap never touched (contributes 0)  */
+    int8_t pad_[5];
+    int64_t tap_stride;       /* floats between the planes of two slots (Cout*Cin of the LAUNCH; a destination that is a
+                                 row block of a fused weight — one gate of the ConvLSTM's 4-gate GEMM — points `slab` at its
+                                 first row and keeps the launch's strides)                            */
+    int64_t split_stride;     /* floats between two k-splits (ntaps * tap_stride)                    */
+} t2v_wgrad_src;
+typedef struct {
+    float* dw;                /* [Cout][Cin][T] (PyTorch layout)                                      */
+    float* dbias;             /* [Cout] or NULL                                                       */
+    int64_t CoCi;             /* Cout * Cin                                                           */
+    int32_t T, Cout, nsrc;
+    int32_t accum, accum_bias; /* add to what dw / dbias hold instead of overwriting                  */
+    int32_t kind;             /* 0: one workgroup per 64 (co,ci) pairs; 1: per (64 pairs, tap), for small weights with many splits */
+    int32_t block_begin, nblocks;
+    int32_t tap_major;        /* dw is stored [T][Cout][Cin] (tap-major master weights); taps no source touches stay untouched */
+    int32_t pad_;
+    t2v_wgrad_src src[T2V_WGRAD_MAX_SRC];
+} t2v_wgrad_dest;
+int t2v_conv_wgrad_grouped_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
+                                   float* slab, int want_bias, int flags, t2v_wgrad_src* out_src, void* stream);
+int t2v_wgrad_dest_bytes(void);
+int t2v_wgrad_reduce_multi(const void* table /* device t2v_wgrad_dest[ndest] */, int ndest, int total_blocks, void* stream);
+
 /* Launch-plan queries (host-side arithmetic only, nothing is launched): which kernel instantiation the two grouped entry
  * points above select for these members. The tile choice is size-dependent (256x64 strips only for launches of >= 512 such
  * tiles, K-split wave layouts for small grids, the many-splits reduce for small weights), so the parity tests use these to
  * assert that every instantiation — the benchmark shapes' in particular — is reached by a checked case.
- * fwd  out[8]: kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv, 3 thin linear, 4 thin two-pass), BM, BN, K chunk,
+ * fwd  out[8]: kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv, 3 thin linear, 4 thin two-pass, 5 strip GEMM with
+ *              all three dx taps per barrier round), BM, BN, K chunk,
  *              FAST, VECB, KS, split-K S.   (groups[].x / .y may be NULL)
  * wgrad out[6]: kernel (0 per-tap tiles, 1 (tap,ci) column tiles, 2 three-tap rows), S, chunks per split, slab slots,
  *              reduce kernel (0 / 1 = many-splits small-weight form), workgroups of the main launch. */
@@ -376,6 +413,18 @@ int t2v_prof_begin(int max_records);
 int t2v_prof_end(double* out, int nkinds);
 
 const char* t2v_version(void);
+
+/* Fused non-local attention of the generator's 2-D block (txt2vid/models/layers.py:23-36: theta^T phi -> softmax over the
+ * pooled positions -> weighted sum of g) without materialising beta [b, N, Nk]: o[b][c][i] = sum_j softmax_j(theta[:, i] .
+ * phi[:, j]) g[c][j]; theta [b,C8,N], phi [b,C8,Nk], g [b,C2,Nk], o [b,C2,N], lse [b,N] (row log-sum-exp, kept for the
+ * adjoint). t2v_nonlocal_bwd: dtheta, dphi, dg from dL/do with beta recomputed from lse; ws: b*N floats.
+ * Built for the head sizes of the generator's block (C8 = 4, C2 = 16: t2v_nonlocal_ok); other sizes and the
+ * discriminator's 3-D block (which needs a second-order adjoint) stay on t2v_bmm / t2v_softmax. */
+int t2v_nonlocal_ok(int C8, int C2);
+int t2v_nonlocal_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int b, int C8, int C2, int N,
+                     int Nk, void* stream);
+int t2v_nonlocal_bwd(const float* theta, const float* phi, const float* g, const float* o, const float* lse, const float* go,
+                     float* dtheta, float* dphi, float* dg, float* ws, int b, int C8, int C2, int N, int Nk, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,14 +107,14 @@ def k3(k):
 
 
 def fwd_plan(members, cin, cout, k, flags=0):
-    """('igemm'|'strip'|'thin'|'linear'|'thin2', BM, BN, BK, fast, vecb, KS, S) for a forward (or, with cin/cout swapped,
+    """('igemm'|'strip'|'thin'|'linear'|'thin2'|'strip3', BM, BN, BK, fast, vecb, KS, S) for a forward (or, with cin/cout swapped,
     data-gradient) launch over `members`."""
     from txt2vid_amd._lib import lib
     out = (C.c_int32 * 8)()
     rc = lib().t2v_conv_fwd_plan(_group_array(members, cin, cout, k3(k)), len(members), cin, cout, flags, out)
     assert rc == 0, rc
     v = list(out)
-    return (('igemm', 'strip', 'thin', 'linear', 'thin2')[v[0]],) + tuple(v[1:])
+    return (('igemm', 'strip', 'thin', 'linear', 'thin2', 'strip3')[v[0]],) + tuple(v[1:])
 
 
 def wgrad_plan(members, cin, cout, k):

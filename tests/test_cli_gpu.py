@@ -47,7 +47,8 @@ def test_uncond_cli_train_checkpoint_resume_and_sample(tmp_path):
     # sampling path (trainer.test): eval-mode generator renders full 16x64x64 clips
     smp2 = str(tmp_path / 'samples_test')
     run(base[:-2] + ['--out_samples', smp2, '--test', '--weights', ck[0], '--num_samples', '1', '--max_iters', '1'], tmp_path)
-    assert glob.glob(os.path.join(smp2, 'fake_0_0.png'))
+    assert os.path.exists(os.path.join(smp2, 'real_0.png')) and os.path.exists(os.path.join(smp2, '64x64_0_0.jpg'))      # trainer.py:76,88
+    assert len(os.listdir(smp2)) == 2                                     # one batch per sample, last level only in eval mode
 
 
 def test_cond_cli_train(tmp_path):

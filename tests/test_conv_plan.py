@@ -19,11 +19,11 @@ def test_benchmark_shapes_select_the_big_tile_paths():
     # the gradient-penalty members alone (M = 131072) still fill 512 tiles of 256 voxels
     _, cin, cout, k, members, _ = cc.GROUPED_CASES[1]
     assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 256, 64, 16)
-    # 64 -> 128 at M = 49152: 128x64 strip tiles forward, 64x64 K-split strip tiles for the data gradient
+    # 64 -> 128 at M = 49152: 128x64 strip tiles forward, 64x64 tiles with three dx taps per round for the data gradient
     _, cin, cout, k, members, _ = cc.GROUPED_CASES[3]
     assert sum(n * d * h * w for n, d, h, w in members) == 49152
     assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 128, 64, 32)
-    assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip', 64, 64, 32, 1, 1, 2)
+    assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip3', 64, 64, 32, 1, 1, 1)
 
 
 # every instantiation the launchers in conv.hip can select (launch_conv_t + the thin kernels)
@@ -32,10 +32,10 @@ ALL_FWD = set()
 for bm, bn, bk in _TILES:
     for vecb in (1, 0):
         ALL_FWD.add(('igemm', bm, bn, bk, 1, vecb, 1))                       # conv_igemm_kernel<BM,BN,*,BK,true,VECB>
-        if bk == 32 or bm == 256:
+        if (bm, bn, bk) == (64, 64, 32):
+            ALL_FWD.add(('strip3', bm, bn, bk, 1, vecb, 1))                  # conv_igemm_strip3_kernel<BM,VECB>: 3 dx taps per round
+        elif bk == 32 or bm == 256:
             ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>
-            if (bm, bn, bk) == (64, 64, 32):
-                ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 2))               # K-split wave layout
 for bm, bn in ((128, 32), (128, 64), (64, 64)):
     ALL_FWD.add(('igemm', bm, bn, 16, 0, 0, 1))                              # generic-K: conv_igemm_kernel<BM,BN,*,16,false,false>
 ALL_FWD |= {('thin', 256, 1, 0, 0, 0, 0), ('thin', 256, 4, 0, 0, 0, 0), ('thin2', 256, 1, 0, 0, 0, 0),

@@ -240,5 +240,65 @@ def test_checkpoint_written_by_the_real_reference_loads(which):
             st, ref = opt.state[p], ck[key]['state'][i]
             assert int(st['step']) == 1 and st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape
             assert torch.equal(st['exp_avg'], ref['exp_avg'].contiguous()), (key, i)
-            for k in ('exp_avg', 'exp_avg_sq'):        # dense memory of their own: the kernels walk them through raw pointers
-                assert st[k].is_contiguous() and st[k].untyped_storage().nbytes() >= st[k].numel() * 4, (key, i, k)
+            for k in ('exp_avg', 'exp_avg_sq'):        # dense memory of their own IN THE PARAMETER'S LAYOUT: the kernels walk p, g, m, v with one index
+                assert st[k].stride() == p.stride() and st[k].untyped_storage().nbytes() >= st[k].numel() * 4, (key, i, k)
+
+
+def test_tap_major_master_weights_keep_values_draw_order_and_state_dict():
+    """The ConvLSTM's eight [1024,1024,3,3] weights are stored tap-major in memory (models/conv_lstm.py) while shape, values,
+    `init()` draw order and state_dict stay those of the reference's dense weights."""
+    import torch.nn as nn
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.models.conv_lstm import ConvLSTMCell
+    from txt2vid_amd.util.torch.init import init
+    torch.manual_seed(7)
+    cell = ConvLSTMCell(8, 8, 3)
+    torch.manual_seed(7)
+    plain = [nn.Conv2d(8, 8, 3, 1, 1, bias=b) for b in (True, False) * 4]          # same constructor order: Wxi Whi Wxf Whf ...
+    names = ('Wxi', 'Whi', 'Wxf', 'Whf', 'Wxc', 'Whc', 'Wxo', 'Who')
+    for n, ref in zip(names, plain):
+        w = getattr(cell, n).weight
+        assert TF.is_tap_major(w) and tuple(w.shape) == (8, 8, 3, 3) and torch.equal(w, ref.weight)
+    torch.manual_seed(11)
+    init(cell, 'xavier')
+    torch.manual_seed(11)
+    for ref in plain:                                   # children-first, left to right = the order above
+        nn.init.xavier_normal_(ref.weight)
+    for n, ref in zip(names, plain):
+        assert torch.equal(getattr(cell, n).weight, ref.weight), n
+    sd = cell.state_dict()
+    assert list(sd)[:3] == ['Wxi.weight', 'Wxi.bias', 'Whi.weight']
+    dense = {k: v.contiguous() for k, v in sd.items()}  # what a reference checkpoint holds
+    cell2 = ConvLSTMCell(8, 8, 3)
+    cell2.load_state_dict(dense)
+    assert all(torch.equal(a, b) for a, b in zip(cell.state_dict().values(), cell2.state_dict().values()))
+    assert TF.is_tap_major(cell2.Wxi.weight)
+    rows = TF.tap_rows(cell.Wxi.weight)
+    assert rows.shape == (9, 64) and torch.equal(rows[4].view(8, 8), cell.Wxi.weight[:, :, 1, 1])
+
+
+def test_sample_grid_writer_pixel_level(tmp_path):
+    """`samples.save_frames` = torchvision.utils.save_image(frames, normalize=True, nrow=T) of trainer.py:92-101: min/max
+    normalisation over the whole tensor, one clip per row, 2-pixel zero padding, round-half-up to uint8 — decoded back
+    from the PNG and compared pixel by pixel with the layout computed independently here; grey clips become 3 equal channels."""
+    from PIL import Image
+    from txt2vid_amd.gan.samples import save_frames
+    g = torch.Generator()
+    g.manual_seed(5)
+    for C_ in (1, 3):
+        x = torch.randn(3, C_, 4, 6, 5, generator=g) * 2.0 - 0.3                # [b,C,T,H,W]
+        path = tmp_path / ('grid%d.png' % C_)
+        save_frames(x, str(path))
+        img = np.asarray(Image.open(path).convert('RGB')).astype(np.int64)       # [gh, gw, 3]
+        b, _, T, H, W = x.shape
+        assert img.shape == (b * (H + 2) + 2, T * (W + 2) + 2, 3)
+        lo, hi = float(x.min()), float(x.max())
+        want = np.zeros(img.shape, dtype=np.int64)
+        for n in range(b):
+            for t in range(T):
+                tile = ((x[n, :, t] - lo) / (hi - lo)).clamp(0, 1).mul(255).add(0.5).floor().numpy().astype(np.int64)
+                tile = np.repeat(tile, 3, axis=0) if C_ == 1 else tile
+                want[n * (H + 2) + 2:n * (H + 2) + 2 + H, t * (W + 2) + 2:t * (W + 2) + 2 + W, :] = tile.transpose(1, 2, 0)
+        assert np.array_equal(img, want)
+    save_frames(x, str(tmp_path / 'grid.jpg'))                                   # the sampling path's extension: PIL writes JPEG
+    assert Image.open(tmp_path / 'grid.jpg').format == 'JPEG'

@@ -93,6 +93,88 @@ def test_conv_grouped_at_benchmark_size(case):
     close(dbias, db_ref, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize('cin,cout,k,members', [
+    (64, 64, (3, 3, 3), [(4, 4, 16, 16), (2, 2, 32, 32)]),          # 3-tap rows, many splits of a small weight (kind 1)
+    (128, 256, (3, 3, 3), [(4, 2, 4, 4), (2, 1, 8, 8)]),             # 3-tap rows, one workgroup per 64 pairs (kind 0)
+    (64, 96, (1, 1, 1), [(3, 4, 8, 8)]),                             # per-tap kernel
+    (16, 32, (3, 3, 3), [(2, 4, 6, 6)]),                             # Cin < 64: (tap, ci) column tiles, no fused bias
+])
+def test_deferred_weight_gradient_reduce(cin, cout, k, members):
+    """`GradSink` leaves each weight-gradient launch's k-split slab pending and sums all of them in ONE
+    `t2v_wgrad_reduce_multi` launch: same numbers as the per-launch reduce — bit for bit for a single source; three
+    sources of one parameter (first-order + gradient-penalty terms) summed in order; an immediate producer in between
+    flushes first (ordering)."""
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.dist import GradArena
+    w = torch.nn.Parameter(rnd(2, cout, cin, *k).to(dev()) * 0.1)
+    b = torch.nn.Parameter(rnd(3, cout).to(dev()))
+    sets = []
+    for r in range(3):
+        xs = [rnd(10 + 7 * r + i, n, cin, d, h, wd).to(dev()) for i, (n, d, h, wd) in enumerate(members)]
+        gys = [rnd(40 + 7 * r + i, n, cout, d, h, wd).to(dev()) for i, (n, d, h, wd) in enumerate(members)]
+        sets.append((xs, gys))
+    # reference: immediate reduces, accumulated launch by launch
+    dw_ref, db_ref = torch.empty_like(w), torch.empty_like(b)
+    for r, (xs, gys) in enumerate(sets):
+        TF.conv_group_wgrad_raw(xs, gys, tuple(w.shape), True, out=dw_ref, accum=r > 0, dbias=db_ref, accum_bias=r > 0)
+    dw1 = TF.conv_group_wgrad_raw(sets[0][0], sets[0][1], tuple(w.shape), True)
+    arena = GradArena([w, b])
+    sink = TF.GradSink([arena])
+    assert sink.defer
+    old = TF.set_grad_sink(sink)
+    try:
+        with torch.no_grad():
+            # one source: bit-identical to the immediate path
+            TF.grad_sink_reset()
+            done, gw = TF._to_sink_w(w, sets[0][0], sets[0][1], True)
+            assert done and gw is not None and sink.pending
+            TF.grad_sink_flush()
+            assert not sink.pending
+            assert torch.equal(gw, dw1)
+            # three sources of the same weight (+ bias through the fused side sums when Cin >= 64)
+            TF.grad_sink_reset()
+            for r, (xs, gys) in enumerate(sets):
+                done, gw_r, gb_r = TF._to_sink_wb(w, b, xs, gys, True)
+                assert done and (gw_r is None) == (r > 0)
+            TF.grad_sink_flush()
+            views = arena.views()
+            close(views[0], dw_ref, rtol=1e-5, atol=1e-5)
+            close(views[1], db_ref, rtol=1e-5, atol=1e-5)
+            # an immediate producer of the same parameter while a slab is pending: the pending part lands first
+            TF.grad_sink_reset()
+            TF._to_sink_w(w, sets[0][0], sets[0][1], True)
+            extra = rnd(99, *w.shape).to(dev())
+            done, _ = TF._to_sink(w, lambda out, acc: TF.copy_into(out + extra, out) if acc else TF.copy_into(extra, out))
+            assert done and not sink.pending
+            TF._to_sink_w(w, sets[1][0], sets[1][1], True)
+            TF.grad_sink_flush()
+            want = dw1 + extra + TF.conv_group_wgrad_raw(sets[1][0], sets[1][1], tuple(w.shape), True)
+            close(arena.views()[0], want, rtol=1e-5, atol=1e-5)
+    finally:
+        TF.set_grad_sink(old)
+
+
+@pytest.mark.parametrize('b,N,Nk', [(3, 1024, 256), (2, 900, 225), (1, 64, 16), (2, 4096, 1024)])
+def test_fused_nonlocal_attend(b, N, Nk):
+    """`t2v_nonlocal_fwd/_bwd` (scores -> softmax -> weighted sum with beta kept in registers) against torch on the CPU:
+    o = g . softmax(theta^T phi)^T and the three input gradients, at the generator's head sizes (4 / 16), for map sizes
+    with partial key / query tiles and the 64x64 map of BASELINE configs[4] (beta would be 4096 x 1024 per frame)."""
+    from txt2vid_amd import functional as TF
+    th, ph, g = rnd(1, b, 4, N), rnd(2, b, 4, Nk), rnd(3, b, 16, Nk)
+    go = rnd(4, b, 16, N)
+    ref = [t.clone().double().requires_grad_(True) for t in (th, ph, g)]
+    beta = torch.softmax(torch.bmm(ref[0].transpose(1, 2), ref[1]), dim=-1)
+    o_ref = torch.bmm(ref[2], beta.transpose(1, 2))
+    (o_ref * go.double()).sum().backward()
+    dv = [t.to(dev()).requires_grad_(True) for t in (th, ph, g)]
+    assert TF.nonlocal_attend_ok(4, 16) and not TF.nonlocal_attend_ok(16, 64)
+    o = TF.nonlocal_attend(*dv)
+    close(o, o_ref, rtol=1e-5, atol=1e-5)
+    (o * go.to(dev())).sum().backward()
+    for got, want in zip(dv, ref):
+        close(got.grad, want.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_conv_double_backward():
     """R = || d(sum y*gy)/dx ||^2 differentiated w.r.t. w and gy-side input — the GP pattern."""
     from txt2vid_amd import functional as TF

@@ -345,3 +345,27 @@ def test_txt_pretrain(golden, tag, teacher):
     for k in ('encoder.embed.weight', 'encoder.to_vocab.bias', 'encoder.lstm.bias_hh_l0', 'encoder.lstm.bias_ih_l3_reverse',
               'encoder.lstm.weight_hh_l1_reverse'):
         close_(P[k].grad, g[tag + '_g_' + k], rtol=1e-3, atol=1e-5)
+
+
+def test_trajectory_100_steps_side_by_side_record():
+    """tests/golden/trajectory_100.json (make_golden.py `trajectory 100`): the oracle and the imported reference ran side by side
+    for 100 FREE-RUNNING iterations in the build container, consuming identical draws. Committed: per-step |delta loss| (all
+    exactly 0 — same ATen kernels in the same order), the max parameter difference every 10th step (0), and the reference's
+    own loss curve. Here: the record says what it must, and the oracle re-run on this host reproduces the first two points
+    of the reference's curve (1e-6 on the recording host's kernels, 1e-3 elsewhere)."""
+    import random
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trajectory_100.json')))
+    sm = rec['summary']
+    assert sm['steps'] == 100 and len(rec['lossD_ref']) == 100 and len(rec['dD']) == 100
+    assert sm['max_dD'] <= 1e-6 and sm['max_dG'] <= 1e-6 and sm['max_param_delta'] <= 1e-6
+    assert max(rec['dD']) == sm['max_dD'] and max(rec['dG']) == sm['max_dG']
+    assert 0.05 < min(rec['lossD_ref']) and max(rec['lossG_ref']) < 10.0            # a live GAN trajectory, not a constant
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1)), O.recipe_state(O.resnet3d_shapes('single_discrim.', 1, 64, 0)))
+    random.seed(100)
+    np.random.seed(100)
+    torch.manual_seed(100)
+    for it in range(2):
+        x = (torch.rand(4, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4)
+        lD, lG = tr.step(x)
+        scalar_close(lD, rec['lossD_ref'][it], 1e-3)
+        scalar_close(lG, rec['lossG_ref'][it], 1e-3)

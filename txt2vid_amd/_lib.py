@@ -54,6 +54,23 @@ class PackJob(C.Structure):
                 ('taps', C.c_int8 * MAX_TAPS), ('pad_', C.c_int8 * 5)]
 
 
+WGRAD_MAX_SRC = 6
+
+
+class WgradSrc(C.Structure):
+    """Mirror of `t2v_wgrad_src` (include/t2v_hip.h)."""
+    _fields_ = [('slab', C.c_void_p), ('bias_slab', C.c_void_p), ('ntaps', C.c_int32), ('S', C.c_int32),
+                ('map', C.c_int8 * MAX_TAPS), ('pad_', C.c_int8 * 5), ('tap_stride', C.c_int64), ('split_stride', C.c_int64)]
+
+
+class WgradDest(C.Structure):
+    """Mirror of `t2v_wgrad_dest` (include/t2v_hip.h)."""
+    _fields_ = [('dw', C.c_void_p), ('dbias', C.c_void_p), ('CoCi', C.c_int64), ('T', C.c_int32), ('Cout', C.c_int32),
+                ('nsrc', C.c_int32), ('accum', C.c_int32), ('accum_bias', C.c_int32), ('kind', C.c_int32),
+                ('block_begin', C.c_int32), ('nblocks', C.c_int32), ('tap_major', C.c_int32), ('pad_', C.c_int32),
+                ('src', WgradSrc * WGRAD_MAX_SRC)]
+
+
 MAX_GROUPS = 8
 _P = C.c_void_p
 _I = C.c_int
@@ -75,6 +92,12 @@ SIGNATURES = {
     't2v_conv_fwd_grouped': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_conv_wgrad_grouped_slab_floats': [_P, _I, _I, _I, _I, _I, _I],
     't2v_conv_fwd_plan': [_P, _I, _I, _I, _I, _I3],
+    't2v_nonlocal_ok': [_I, _I],
+    't2v_nonlocal_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    't2v_nonlocal_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    't2v_conv_wgrad_grouped_partial': [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    't2v_wgrad_dest_bytes': [],
+    't2v_wgrad_reduce_multi': [_P, _I, _I, _P],
     't2v_conv_wgrad_plan': [_P, _I, _I, _I, _I, _I, _I, _I3],
     't2v_pack_weight_bf16': [_P, _P, _I, _I, _I, _P, _I, _I, _P],
     't2v_conv_fwd_grouped_bf16_ok': [_P, _I, _I, _I],

@@ -140,13 +140,17 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     // ConvLSTM gates become one GEMM). 32x32 tile transpose of the (co,ci) plane through LDS for mode 0.
     __shared__ float tile[32][33];
     const int j = blockIdx.z;
+    const bool src_tm = mode & 8;                   // source stored tap-major: w[t][co][ci]
+    mode &= 7;
     const int t = mode ? (T - 1 - taps.t[j]) : taps.t[j];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const size_t sco = src_tm ? (size_t)Cin : (size_t)Cin * T, sci = src_tm ? 1 : (size_t)T;
+    const size_t st = src_tm ? (size_t)t * Cout * Cin : (size_t)t;
     if (mode == 0) {
         for (int r = ty; r < 32; r += 8) {          // read rows co, lanes ci (stride T)
             int co = co0 + r, ci = ci0 + tx;
-            tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+            tile[r][tx] = (co < Cout && ci < Cin) ? w[co * sco + ci * sci + st] : 0.f;
         }
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {          // write rows ci, lanes co
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         for (int r = ty; r < 32; r += 8) {
             int co = co0 + r, ci = ci0 + tx;
             if (co < Cout && ci < Cin)
-                wp[((size_t)j * dst_rows + row_off + co) * dst_cols + col_off + ci] = w[((size_t)co * Cin + ci) * T + t];
+                wp[((size_t)j * dst_rows + row_off + co) * dst_cols + col_off + ci] = w[co * sco + ci * sci + st];
         }
     }
 }
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 extern "C" int t2v_pack_weight_into(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
                                     int mode, int dst_rows, int dst_cols, int row_off, int col_off, void* stream) {
     if (!w || !wp || ntaps < 1 || ntaps > T2V_MAX_TAPS || T > T2V_MAX_TAPS || row_off < 0 || col_off < 0) return T2V_EINVAL;
-    const int rows = mode ? Cout : Cin, cols = mode ? Cin : Cout;
+    if ((mode & ~8) != 0 && (mode & ~8) != 1) return T2V_EINVAL;
+    const int rows = (mode & 7) ? Cout : Cin, cols = (mode & 7) ? Cin : Cout;
     if (row_off + rows > dst_rows || col_off + cols > dst_cols) return T2V_EINVAL;
     TapList tl;
     tl.n = ntaps;
@@ -181,7 +186,7 @@ extern "C" int t2v_pack_weight_into(const float* w, float* wp, int Cout, int Cin
 
 extern "C" int t2v_pack_weight(const float* w, float* wp, int Cout, int Cin, int T, const int32_t* taps, int ntaps,
                                int mode, void* stream) {
-    return t2v_pack_weight_into(w, wp, Cout, Cin, T, taps, ntaps, mode, mode ? Cout : Cin, mode ? Cin : Cout, 0, 0, stream);
+    return t2v_pack_weight_into(w, wp, Cout, Cin, T, taps, ntaps, mode, (mode & 7) ? Cout : Cin, (mode & 7) ? Cin : Cout, 0, 0, stream);
 }
 
 
@@ -215,8 +220,12 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     const int Cout = job.Cout, Cin = job.Cin, T = job.T;
     // mode 0 / 1: fp32 forward / mirrored data-gradient layouts (see t2v_pack_weight); mode 2 / 3: the bf16-compute layouts
     // (t2v_pack_weight_bf16 mode 0 / 1): 2 = dst[j][co][ci], 3 = dst[j][ci][co] mirrored, both bf16
-    const bool mirror = job.mode == 1 || job.mode == 3, transpose = job.mode == 0 || job.mode == 3, b16 = job.mode >= 2;
+    const int jm = job.mode & 7;
+    const bool src_tm = job.mode & 8;               // source stored tap-major: w[t][co][ci]
+    const bool mirror = jm == 1 || jm == 3, transpose = jm == 0 || jm == 3, b16 = jm >= 2;
     const int t = mirror ? (T - 1 - job.taps[j]) : job.taps[j];
+    const size_t sco = src_tm ? (size_t)Cin : (size_t)Cin * T, sci = src_tm ? 1 : (size_t)T;
+    const size_t st = src_tm ? (size_t)t * Cout * Cin : (size_t)t;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int co0 = byi * 32, ci0 = bxi * 32;
     const float* __restrict__ w = job.src;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     if (transpose) {
         for (int r = ty; r < 32; r += 8) {
             int co = co0 + r, ci = ci0 + tx;
-            tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+            tile[r][tx] = (co < Cout && ci < Cin) ? w[co * sco + ci * sci + st] : 0.f;
         }
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
             int co = co0 + r, ci = ci0 + tx;
             if (co < Cout && ci < Cin) {
                 const size_t o = ((size_t)j * job.dst_rows + job.row_off + co) * job.dst_cols + job.col_off + ci;
-                const float v = w[((size_t)co * Cin + ci) * T + t];
+                const float v = w[co * sco + ci * sci + st];
                 if (b16) wpb[o] = (__bf16)v; else wp[o] = v;
             }
         }
@@ -579,7 +588,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     for (int k = 1; k < T2V_MAX_GROUPS; ++k)
         if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
     const t2v_conv_group& gd = tab.g[gi];
-    const float* __restrict__ x = gd.x;
     const int D = gd.D, H = gd.H, W = gd.W;
     const int HW = H * W, DHW = D * HW;
     const int M = gd.N * DHW;
@@ -790,6 +798,205 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
                 for (int r = 0; r < 16; ++r) tot[i][j][r] = acc[i][j][r] + scratch[(i * NM + j) * 16 + r];
         igemm_epilogue<NCO, NM, WCO, WM>(tot, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
         return;
+    }
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// STRIP3: the strip GEMM with ALL THREE dx taps of a (row tap, channel block) in one barrier round, for the 64-voxel and
+// 128-voxel tiles. The per-dx strip kernel above runs only 16 MFMAs per wave between two barriers on those tiles, and the
+// vector instructions around them (staging, operand reads, masks, waits: ~250 per round) set its pace: 45-80 TFLOP/s
+// where the 256-voxel tile (64 MFMAs per round) reaches 100. Here a round = one staged strip + the weights of its three
+// taps = 48 (96) MFMAs per wave against about the same instruction overhead. Single LDS stage, two barriers per round
+// (the next round's gathers are issued right after the first and land during the MFMA loop), 4 waves as 2 (co) x 2 (m).
+// Rounds = (row tap, channel block of 32); split-K runs over rounds. Members one voxel wide (ndx = 1) run their single tap.
+// ------------------------------------------------------------------------------------------------
+template <int BM, bool VECB>
+__global__ __launch_bounds__(256) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, float* __restrict__ slab,
+                                                                const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int AP = BM + 4;              // [left halo][BM voxels][right halo][pad]
+    constexpr int LA = BKT * BM / 256;      // strip values per thread
+    constexpr int KSA = 256 / BM;
+    constexpr int NV = BKT * BN / 4;        // float4 per tap = 512 -> 2 per thread
+    constexpr int LBV = NV / 256;
+    constexpr int KSBV = 1024 / BN;         // k rows covered by one pass of 256 float4 loads
+    constexpr int LB = BKT * BN / 256;      // scalar path: 8 per thread per tap
+    constexpr int KSB = 256 / BN;
+    static_assert(NCO == 1 && NM >= 1, "tile");
+
+    __shared__ __attribute__((aligned(16))) float As[BKT * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W;
+    const int HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    const int ndx = gd.dx[0] < 0 ? 3 : 1;           // taps r*ndx + {0,1,2} = dx -1, 0, +1 of row tap r
+    const int nrow = ntaps / ndx;
+
+    const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
+    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    const int tab_widx = gd.widx[lane_t];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)M * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
+
+    // ---- staging coordinates (as in the per-dx strip kernel)
+    const int ma_l = tid % BM, ka_l = tid / BM;
+    const int he = tid / BKT, hk = tid % BKT;
+    const bool halo_thread = tid < 2 * BKT;
+    uint32_t rowmask = 0, rowmask_h = 0;
+    uint32_t xbase = 0, xbase_h = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {
+            const int n = m_a / DHW, sp = m_a - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
+            }
+        }
+        const int m_h = he ? m0 + BM : m0 - 1;
+        if (halo_thread && m_h >= 0 && m_h < M) {
+            const int n = m_h / DHW, sp = m_h - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
+            }
+        }
+    }
+    bool can_l[NM], can_r[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int m = m0 + wm * WM + j * 32 + l31;
+        const int w_ = m % W;
+        can_l[j] = w_ > 0;
+        can_r[j] = w_ < W - 1;
+    }
+    const int cob_l = tid % BN, kb_l = tid / BN;
+    const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4);
+    const bool co_ok = VECB ? (co0 + cv_l) < Cout : (co0 + cob_l) < Cout;
+    const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
+    const uint32_t xoff = (xbase + (uint32_t)ka_l * (uint32_t)DHW) * 4u, xoff_h = (xbase_h + (uint32_t)hk * (uint32_t)DHW) * 4u;
+    const uint32_t woff = co_ok ? (uint32_t)((VECB ? kv_l : kb_l) * Cout + co0 + (VECB ? cv_l : cob_l)) * 4u : 0u;
+
+    f32x16 acc[NCO][NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    float ra[LA], rah = 0.f;
+    float rb[VECB ? 1 : 3 * LB];
+    float4 rbv[VECB ? 3 * LBV : 1];
+    const int ncb = Cin / BKT;
+    const int nrounds = nrow * ncb;
+    const int rps = (nrounds + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * rps;
+    int q1 = q0 + rps;
+    if (q1 > nrounds) q1 = nrounds;
+    bool pend_av = false, pend_hv = false;
+
+    auto load_round = [&](int q) {
+        const int r_cur = q / ncb, cb = q - r_cur * ncb;
+        const int c0 = cb * BKT;
+        const int roff = __builtin_amdgcn_readlane(tab_roff, r_cur);
+        const int sx = c0 * DHW * 4;
+        pend_av = (rowmask >> r_cur) & 1u;
+        const uint32_t vo = xoff + (pend_av ? (uint32_t)roff : 0u);
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, sx + j * (KSA * 4) * DHW, 0));
+        if (halo_thread) {
+            pend_hv = (rowmask_h >> r_cur) & 1u;
+            rah = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff_h + (pend_hv ? (uint32_t)roff : 0u), sx, 0));
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < ndx) {                                        // (uniform)
+                const int sw = (__builtin_amdgcn_readlane(tab_widx, r_cur * ndx + d) * Cin + c0) * Cout * 4;
+                if (VECB) {
+#pragma unroll
+                    for (int j = 0; j < LBV; ++j)
+                        rbv[d * LBV + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, sw + j * (KSBV * 4) * Cout, 0));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j)
+                        rb[d * LB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, sw + j * (KSB * 4) * Cout, 0));
+                }
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) As[(ka_l + j * KSA) * AP + 1 + ma_l] = pend_av ? fmaxf(ra[j], relu_floor) : 0.f;
+        if (halo_thread) As[hk * AP + (he ? BM + 1 : 0)] = pend_hv ? fmaxf(rah, relu_floor) : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < ndx) {
+                float* bs = Bs + d * (BKT * BN);
+                if (VECB) {
+#pragma unroll
+                    for (int j = 0; j < LBV; ++j)
+                        *reinterpret_cast<float4*>(&bs[(kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rbv[d * LBV + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) bs[(kb_l + j * KSB) * BN + cob_l] = co_ok ? rb[d * LB + j] : 0.f;
+                }
+            }
+        }
+    };
+
+    if (q0 < q1) load_round(q0);
+    for (int q = q0; q < q1; ++q) {
+        stage();
+        __syncthreads();
+        if (q + 1 < q1) load_round(q + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < ndx) {
+                const int dx = ndx == 3 ? d - 1 : 0;
+                const float* as = As + 1 + dx + wm * WM + l31;
+                const float* bs = Bs + d * (BKT * BN) + wco * WCO + l31;
+                bool keep[NM];
+#pragma unroll
+                for (int j = 0; j < NM; ++j) keep[j] = dx < 0 ? can_l[j] : (dx > 0 ? can_r[j] : true);
+#pragma unroll
+                for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                    const int krow = k2 * 2 + hi;
+                    const float a = bs[krow * BN];
+#pragma unroll
+                    for (int j = 0; j < NM; ++j) {
+                        const float v = as[krow * AP + j * 32];
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, keep[j] ? v : 0.f, acc[0][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
     }
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
@@ -1432,7 +1639,8 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     else {
         p.bn = 64;
         const long t128 = ((Mtot + 127) / 128) * ((Cout + 63) / 64);
-        p.bm = (t128 >= 768) ? 128 : 64;
+        static const long tile128_min = getenv("T2V_TILE128_MIN") ? atol(getenv("T2V_TILE128_MIN")) : 768;
+        p.bm = (t128 >= tile128_min) ? 128 : 64;
         // 256 x 64 tiles, K chunks of 16, one wave = 64 co x 64 m (four accumulator chains, one LDS read per MFMA) for the
         // launches big enough to fill the chip with them (+3-6 % over the 128 x 64 tile there)
         static const long tile256_min = getenv("T2V_TILE256_MIN") ? atol(getenv("T2V_TILE256_MIN")) : 512;
@@ -1504,11 +1712,15 @@ static long g_ksplit_max_blocks = getenv("T2V_KSPLIT_MAX_BLOCKS") ? atol(getenv(
 // members carry their taps in (row, dx) order, and for the 64x64x32 strip tile the K-split wave layout (KS = 2: two
 // accumulator chains per wave cost a VGPR occupancy step, 3 instead of 4 waves per SIMD: worth it only for launches that
 // cannot put 4 workgroups on every CU anyway). Shared by the launcher and by t2v_conv_fwd_plan.
-struct ConvVariant { bool strip; int ks; };
+struct ConvVariant { bool strip; int ks; bool s3; };
+static bool g_strip3_enabled = getenv("T2V_NO_STRIP3") == nullptr;
+static bool g_strip3_128 = getenv("T2V_STRIP3_128") != nullptr;      // (measured: the 128-voxel form needs 174 registers -> 2 waves per SIMD, slower)
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
-    ConvVariant v{false, 1};
+    ConvVariant v{false, 1, false};
     if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
         v.strip = true;
+        // 64- and 128-voxel tiles with 64 output channels: all three dx taps per barrier round (conv_igemm_strip3_kernel)
+        if (g_strip3_enabled && (BM == 64 || (BM == 128 && g_strip3_128)) && BN == 64 && BKT == 32) { v.s3 = true; return v; }
         const long nblocks = (long)tab.tile_start[tab.n] * ((Cout + BN - 1) / BN) * p.S;
         if (BM == 64 && BN == 64 && BKT == 32 && g_ksplit_waves && nblocks <= g_ksplit_max_blocks) v.ks = 2;
     }
@@ -1520,6 +1732,13 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
                           const ConvPlan& p, hipStream_t s) {
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
     const ConvVariant v = conv_variant(tab, p, BM, BN, BKT, Cin, Cout, flags);
+    if (v.s3) {
+        if constexpr ((BM == 64 || BM == 128) && BN == 64 && BKT == 32) {
+            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            else T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        }
+        return;
+    }
     if (v.strip) {
         constexpr int KS = (BM == 64 && BN == 64 && BKT == 32) ? 2 : 1;
         if (KS == 2 && v.ks != 2) {
@@ -1559,7 +1778,7 @@ static void fill_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, in
     }
     const int bk = (p.bm == 256 && p.bn == 64) ? 16 : (p.bk == 32 ? 32 : 16);
     const ConvVariant v = conv_variant(tab, p, p.bm, p.bn, bk, Cin, Cout, flags);
-    out[0] = v.strip ? 1 : 0;
+    out[0] = v.s3 ? 5 : (v.strip ? 1 : 0);
     out[1] = p.bm; out[2] = p.bn; out[3] = p.fast ? bk : 16;
     out[4] = p.fast ? 1 : 0; out[5] = (p.fast && p.vecb) ? 1 : 0; out[6] = v.ks; out[7] = p.S;
 }
@@ -2742,7 +2961,7 @@ extern "C" int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group*
 }
 
 static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, float* dw,
-                      float* dbias, float* slab, int flags, void* stream);
+                      float* dbias, float* slab, int flags, void* stream, t2v_wgrad_src* out_src = nullptr);
 extern "C" int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW,
                                       float* dw, float* slab, int flags, void* stream) {
     return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, dw, nullptr, slab, flags, stream);
@@ -2753,10 +2972,10 @@ extern "C" int t2v_conv_wgrad_grouped_bias(const t2v_conv_group* groups, int ngr
     return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, dw, dbias, slab, flags, stream);
 }
 static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, float* dw,
-                      float* dbias, float* slab, int flags, void* stream) {
+                      float* dbias, float* slab, int flags, void* stream, t2v_wgrad_src* out_src) {
     WGroupTable tab;
     WgradPlan p;
-    if (!dw || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
+    if ((!dw && !out_src) || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;         // behind the weight-gradient slab
     const bool bias_fused = p.rows3 || Cin >= 64;                         // both MFMA weight-gradient kernels sum dL/dy on the side
@@ -2831,6 +3050,16 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     }
     int st = launch_status();
     if (st) return st;
+    if (out_src) {                  // deferred reduce (t2v_wgrad_reduce_multi): describe the partial sums instead of summing them
+        out_src->slab = slab;
+        out_src->bias_slab = (dbias && bias_fused) ? bias_part : (const float*)nullptr;
+        out_src->ntaps = live.n;
+        out_src->S = p.S;
+        out_src->tap_stride = (int64_t)Cout * Cin;
+        out_src->split_stride = (int64_t)live.n * Cout * Cin;
+        for (int t = 0; t < T2V_MAX_TAPS; ++t) out_src->map[t] = (int8_t)(t < T ? map.j[t] : -1);
+        return T2V_OK;
+    }
     const float* bias_in = (dbias && bias_fused) ? bias_part : (const float*)nullptr;   // summed by one workgroup of the reduce below
     const int accum_bias = (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0;
     const long CoCi = (long)Cout * Cin;
@@ -2841,6 +3070,138 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     else
         T2V_LAUNCH_PROF(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, live.n, p.S, map,
                    (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deferred, batched reduction of weight-gradient partial sums. A backward pass issues one weight-gradient launch per
+// layer (and more for the second-order terms of the gradient penalty); summing each one's k-split slab right away costs a
+// launch of ~10 us of pure latency per layer (60 per iteration). t2v_conv_wgrad_grouped_partial runs the main kernel only and
+// describes its slab; t2v_wgrad_reduce_multi sums every pending slab of every parameter in ONE launch driven by a
+// device-resident table of destinations, each listing its sources in the order they were produced (fixed summation order:
+// source by source, splits in the same 4-way interleave as the single reduce kernels).
+// ------------------------------------------------------------------------------------------------
+extern "C" int t2v_conv_wgrad_grouped_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH,
+                                              int kW, float* slab, int want_bias, int flags, t2v_wgrad_src* out_src,
+                                              void* stream) {
+    if (!out_src) return T2V_EINVAL;
+    WGroupTable tab;
+    WgradPlan p;
+    if (!build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
+    if (want_bias && !(p.rows3 || Cin >= 64)) return T2V_EINVAL;    // only the MFMA kernels sum dL/dy on the side
+    float dummy;                                                    // (non-null marker: the bias side-sums are wanted)
+    return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, nullptr, want_bias ? &dummy : nullptr, slab, flags, stream, out_src);
+}
+extern "C" int t2v_wgrad_dest_bytes(void) { return (int)sizeof(t2v_wgrad_dest); }
+
+__device__ __forceinline__ float slab_sum4(const float* __restrict__ p, size_t st, int S) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        v0 += p[(size_t)s * st]; v1 += p[(size_t)(s + 1) * st]; v2 += p[(size_t)(s + 2) * st]; v3 += p[(size_t)(s + 3) * st];
+    }
+    for (; s < S; ++s) v0 += p[(size_t)s * st];
+    return (v0 + v1) + (v2 + v3);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const t2v_wgrad_dest* __restrict__ table, int ndest) {
+    __shared__ float tile[64 * T2V_MAX_TAPS];
+    __shared__ float part[4][64];
+    __shared__ int s_dest;
+    if (threadIdx.x == 0) {                  // last destination with block_begin <= blockIdx.x
+        int lo = 0, hi = ndest - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        s_dest = lo;
+    }
+    __syncthreads();
+    const t2v_wgrad_dest& d = table[s_dest];
+    const int b = (int)blockIdx.x - d.block_begin;
+    const long CoCi = d.CoCi;
+    const int T = d.T, nsrc = d.nsrc;
+    if (d.dbias && b == 0) {                 // bias: one workgroup, sources in order
+        for (int co = threadIdx.x; co < d.Cout; co += 256) {
+            float v = 0.f;
+            bool first = true;
+            for (int k = 0; k < nsrc; ++k) {
+                const float* bs = d.src[k].bias_slab;
+                if (!bs) continue;
+                const float vk = slab_sum4(bs + co, (size_t)d.Cout, d.src[k].S);
+                v = first ? vk : v + vk;
+                first = false;
+            }
+            if (!first) d.dbias[co] = d.accum_bias ? d.dbias[co] + v : v;
+        }
+    }
+    if (d.kind == 0) {                       // 64 (co,ci) pairs x T taps; the 4 waves take taps t = wave, wave+4, ...
+        const long i0 = (long)b * 64;
+        const int il = threadIdx.x & 63, tg = threadIdx.x >> 6;
+        const long i = i0 + il;
+        for (int t = tg; t < T; t += 4) {
+            float v = 0.f;
+            bool any = false;
+            for (int k = 0; k < nsrc; ++k) {
+                const int j = d.src[k].map[t];
+                float vk = 0.f;
+                if (j >= 0 && i < CoCi) vk = slab_sum4(d.src[k].slab + (size_t)j * d.src[k].tap_stride + i, (size_t)d.src[k].split_stride, d.src[k].S);
+                any = any || j >= 0;
+                v = k == 0 ? vk : v + vk;
+            }
+            if (d.tap_major) {               // dw[t][co][ci]: lane-contiguous, taps no source touches are left as they are
+                if (any && i < CoCi) {
+                    float* q = d.dw + (size_t)t * CoCi + i;
+                    *q = d.accum ? *q + v : v;
+                }
+            } else tile[il * T + t] = v;
+        }
+        if (d.tap_major) return;
+        __syncthreads();
+        long cnt = CoCi - i0;
+        if (cnt > 64) cnt = 64;
+        const long nval = cnt * T;
+        float* p = d.dw + (size_t)i0 * T;
+        for (long k = threadIdx.x; k < nval; k += 256) p[k] = d.accum ? p[k] + tile[k] : tile[k];
+    } else {                                 // small weights with many splits: one workgroup per (64 pairs, tap), waves split S
+        const int t = b % T;
+        const long i = (long)(b / T) * 64 + (threadIdx.x & 63);
+        const int wv = threadIdx.x >> 6;
+        float v = 0.f;
+        bool any = false;
+        for (int k = 0; k < nsrc; ++k) {
+            const int j = d.src[k].map[t];
+            float v0 = 0.f, v1 = 0.f;
+            if (j >= 0 && i < CoCi) {
+                const float* p = d.src[k].slab + (size_t)j * d.src[k].tap_stride + i;
+                const size_t st = (size_t)d.src[k].split_stride;
+                const int S = d.src[k].S;
+                int s = wv;
+                for (; s + 4 < S; s += 8) { v0 += p[(size_t)s * st]; v1 += p[(size_t)(s + 4) * st]; }
+                if (s < S) v0 += p[(size_t)s * st];
+            }
+            any = any || j >= 0;
+            part[wv][threadIdx.x & 63] = v0 + v1;
+            __syncthreads();
+            if (wv == 0) {
+                const float vk = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+                v = k == 0 ? vk : v + vk;
+            }
+            __syncthreads();
+        }
+        if (wv == 0 && i < CoCi && (any || !d.tap_major)) {
+            float* q = d.tap_major ? d.dw + (size_t)t * CoCi + i : d.dw + (size_t)i * T + t;
+            *q = d.accum ? *q + v : v;
+        }
+    }
+}
+
+// `table`: DEVICE array of ndest t2v_wgrad_dest records; total_blocks = sum of nblocks
+// (kind 0: ceil(CoCi / 64) workgroups, kind 1: ceil(CoCi / 64) * T)
+extern "C" int t2v_wgrad_reduce_multi(const void* table, int ndest, int total_blocks, void* stream) {
+    if (!table || ndest < 1 || total_blocks < 1) return T2V_EINVAL;
+    T2V_LAUNCH(wgrad_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+               (const t2v_wgrad_dest*)table, ndest);
     return launch_status();
 }
 

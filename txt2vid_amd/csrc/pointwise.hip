@@ -995,6 +995,190 @@ extern "C" int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const floa
     return launch_status();
 }
 
+// ---------------------------------------------------------------- fused non-local attention (layers.py:23-36)
+// o[b][c][i] = sum_j softmax_j(sum_k theta[b][k][i] * phi[b][k][j]) * g[b][c][j]   for i < N queries, j < Nk keys.
+// The generator's 2-D block has thin heads (C8 = ch/8 = 4, C2 = ch/2 = 16: no MFMA tile fits), so this is vector-ALU
+// work; what the unfused form pays for is beta [b, N, Nk] in HBM (268 MB per materialisation at 64x64 maps, written
+// and re-read by bmm / softmax / bmm and again by their adjoints). Here beta never leaves registers:
+//   forward  : one lane per QUERY; phi / g tiles of 256 keys staged in LDS as [key][channel] (every lane reads the same
+//              key: LDS broadcast); two passes over the keys (row max, then exp + weighted sum) = the exact
+//              max-subtracted softmax of the unfused kernels; saves lse[b][i] = max + log(sum) for the adjoint;
+//   backward : D_i = sum_c do[c][i] * o[c][i];  ds_ij = beta_ij * (sum_c do[c][i] g[c][j] - D_i),  beta_ij recomputed
+//              from lse. One lane per query accumulates dtheta[:, i] = sum_j ds_ij phi[:, j]; a second kernel with one
+//              lane per KEY (query tiles in LDS) accumulates dphi[:, j] = sum_i ds_ij theta[:, i] and
+//              dg[:, j] = sum_i beta_ij do[:, i]. No atomics: deterministic.
+#define NL_TILE 256
+template <int C8, int C2>
+__global__ __launch_bounds__(256) void nonlocal_fwd_k(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                      const float* __restrict__ g, float* __restrict__ o,
+                                                      float* __restrict__ lse, int N, int Nk) {
+    __shared__ float sk[NL_TILE * (C8 + C2)];
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const bool qv = i < N;
+    const float* th = theta + (size_t)b * C8 * N;
+    const float* ph = phi + (size_t)b * C8 * Nk;
+    const float* gg = g + (size_t)b * C2 * Nk;
+    float t[C8];
+#pragma unroll
+    for (int k = 0; k < C8; ++k) t[k] = qv ? th[(size_t)k * N + i] : 0.f;
+    // pass 1: row maximum (scores only need phi)
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < Nk; j0 += NL_TILE) {
+        const int nj = min(NL_TILE, Nk - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nj * C8; e += 256) { const int k = e / nj, j = e - k * nj; sk[j * C8 + k] = ph[(size_t)k * Nk + j0 + j]; }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int k = 0; k < C8; ++k) sc += t[k] * sk[j * C8 + k];
+            mx = fmaxf(mx, sc);
+        }
+    }
+    // pass 2: exp, sum, weighted sum of g
+    float l = 0.f, acc[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) acc[c] = 0.f;
+    for (int j0 = 0; j0 < Nk; j0 += NL_TILE) {
+        const int nj = min(NL_TILE, Nk - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nj * C8; e += 256) { const int k = e / nj, j = e - k * nj; sk[j * (C8 + C2) + k] = ph[(size_t)k * Nk + j0 + j]; }
+        for (int e = threadIdx.x; e < nj * C2; e += 256) { const int c = e / nj, j = e - c * nj; sk[j * (C8 + C2) + C8 + c] = gg[(size_t)c * Nk + j0 + j]; }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            const float* r = &sk[j * (C8 + C2)];
+            float sc = 0.f;
+#pragma unroll
+            for (int k = 0; k < C8; ++k) sc += t[k] * r[k];
+            const float p = expf(sc - mx);
+            l += p;
+#pragma unroll
+            for (int c = 0; c < C2; ++c) acc[c] += p * r[C8 + c];
+        }
+    }
+    if (qv) {
+        const float inv = 1.f / l;
+        float* po = o + (size_t)b * C2 * N + i;
+#pragma unroll
+        for (int c = 0; c < C2; ++c) po[(size_t)c * N] = acc[c] * inv;
+        lse[(size_t)b * N + i] = mx + logf(l);
+    }
+}
+
+template <int C8, int C2>
+__global__ __launch_bounds__(256) void nonlocal_bwd_q_k(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                        const float* __restrict__ g, const float* __restrict__ o,
+                                                        const float* __restrict__ lse, const float* __restrict__ go,
+                                                        float* __restrict__ dtheta, float* __restrict__ dsum, int N, int Nk) {
+    __shared__ float sk[NL_TILE * (C8 + C2)];
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const bool qv = i < N;
+    const float* ph = phi + (size_t)b * C8 * Nk;
+    const float* gg = g + (size_t)b * C2 * Nk;
+    float t[C8], d_o[C2], dt[C8], Dsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < C8; ++k) { t[k] = qv ? theta[((size_t)b * C8 + k) * N + i] : 0.f; dt[k] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+        d_o[c] = qv ? go[((size_t)b * C2 + c) * N + i] : 0.f;
+        Dsum += d_o[c] * (qv ? o[((size_t)b * C2 + c) * N + i] : 0.f);
+    }
+    const float ls = qv ? lse[(size_t)b * N + i] : 0.f;
+    for (int j0 = 0; j0 < Nk; j0 += NL_TILE) {
+        const int nj = min(NL_TILE, Nk - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nj * C8; e += 256) { const int k = e / nj, j = e - k * nj; sk[j * (C8 + C2) + k] = ph[(size_t)k * Nk + j0 + j]; }
+        for (int e = threadIdx.x; e < nj * C2; e += 256) { const int c = e / nj, j = e - c * nj; sk[j * (C8 + C2) + C8 + c] = gg[(size_t)c * Nk + j0 + j]; }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            const float* r = &sk[j * (C8 + C2)];
+            float sc = 0.f, db = 0.f;
+#pragma unroll
+            for (int k = 0; k < C8; ++k) sc += t[k] * r[k];
+#pragma unroll
+            for (int c = 0; c < C2; ++c) db += d_o[c] * r[C8 + c];
+            const float ds = expf(sc - ls) * (db - Dsum);
+#pragma unroll
+            for (int k = 0; k < C8; ++k) dt[k] += ds * r[k];
+        }
+    }
+    if (qv) {
+#pragma unroll
+        for (int k = 0; k < C8; ++k) dtheta[((size_t)b * C8 + k) * N + i] = dt[k];
+        dsum[(size_t)b * N + i] = Dsum;
+    }
+}
+
+template <int C8, int C2>
+__global__ __launch_bounds__(256) void nonlocal_bwd_k_k(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                        const float* __restrict__ g, const float* __restrict__ lse,
+                                                        const float* __restrict__ go, const float* __restrict__ dsum,
+                                                        float* __restrict__ dphi, float* __restrict__ dg, int N, int Nk) {
+    constexpr int QW = C8 + C2 + 2;                 // per query: theta, do, lse, D
+    __shared__ float sq[NL_TILE * QW];
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const bool kv = j < Nk;
+    float p_[C8], g_[C2], dp[C8], dgv[C2];
+#pragma unroll
+    for (int k = 0; k < C8; ++k) { p_[k] = kv ? phi[((size_t)b * C8 + k) * Nk + j] : 0.f; dp[k] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < C2; ++c) { g_[c] = kv ? g[((size_t)b * C2 + c) * Nk + j] : 0.f; dgv[c] = 0.f; }
+    const float* th = theta + (size_t)b * C8 * N;
+    const float* pg = go + (size_t)b * C2 * N;
+    for (int i0 = 0; i0 < N; i0 += NL_TILE) {
+        const int ni = min(NL_TILE, N - i0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ni * C8; e += 256) { const int k = e / ni, i = e - k * ni; sq[i * QW + k] = th[(size_t)k * N + i0 + i]; }
+        for (int e = threadIdx.x; e < ni * C2; e += 256) { const int c = e / ni, i = e - c * ni; sq[i * QW + C8 + c] = pg[(size_t)c * N + i0 + i]; }
+        for (int i = threadIdx.x; i < ni; i += 256) {
+            sq[i * QW + C8 + C2] = lse[(size_t)b * N + i0 + i];
+            sq[i * QW + C8 + C2 + 1] = dsum[(size_t)b * N + i0 + i];
+        }
+        __syncthreads();
+        for (int i = 0; i < ni; ++i) {
+            const float* r = &sq[i * QW];
+            float sc = 0.f, db = 0.f;
+#pragma unroll
+            for (int k = 0; k < C8; ++k) sc += r[k] * p_[k];
+#pragma unroll
+            for (int c = 0; c < C2; ++c) db += r[C8 + c] * g_[c];
+            const float p = expf(sc - r[C8 + C2]);
+            const float ds = p * (db - r[C8 + C2 + 1]);
+#pragma unroll
+            for (int k = 0; k < C8; ++k) dp[k] += ds * r[k];
+#pragma unroll
+            for (int c = 0; c < C2; ++c) dgv[c] += p * r[C8 + c];
+        }
+    }
+    if (kv) {
+#pragma unroll
+        for (int k = 0; k < C8; ++k) dphi[((size_t)b * C8 + k) * Nk + j] = dp[k];
+#pragma unroll
+        for (int c = 0; c < C2; ++c) dg[((size_t)b * C2 + c) * Nk + j] = dgv[c];
+    }
+}
+
+extern "C" int t2v_nonlocal_ok(int C8, int C2) { return (C8 == 4 && C2 == 16) ? 1 : 0; }
+extern "C" int t2v_nonlocal_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int b, int C8,
+                                int C2, int N, int Nk, void* st) {
+    if (!theta || !phi || !g || !o || !lse || b < 1 || N < 1 || Nk < 1 || !t2v_nonlocal_ok(C8, C2)) return T2V_EINVAL;
+    T2V_LAUNCH((nonlocal_fwd_k<4, 16>), dim3((unsigned)((N + 255) / 256), (unsigned)b), dim3(256), 0, S_(st), theta, phi, g, o, lse, N, Nk);
+    return launch_status();
+}
+extern "C" int t2v_nonlocal_bwd(const float* theta, const float* phi, const float* g, const float* o, const float* lse,
+                                const float* go, float* dtheta, float* dphi, float* dg, float* ws, int b, int C8, int C2,
+                                int N, int Nk, void* st) {
+    if (!theta || !phi || !g || !o || !lse || !go || !dtheta || !dphi || !dg || !ws || b < 1 || N < 1 || Nk < 1 ||
+        !t2v_nonlocal_ok(C8, C2)) return T2V_EINVAL;
+    T2V_LAUNCH((nonlocal_bwd_q_k<4, 16>), dim3((unsigned)((N + 255) / 256), (unsigned)b), dim3(256), 0, S_(st), theta, phi, g, o, lse, go,
+               dtheta, ws, N, Nk);
+    int rc = launch_status();
+    if (rc) return rc;
+    T2V_LAUNCH((nonlocal_bwd_k_k<4, 16>), dim3((unsigned)((Nk + 255) / 256), (unsigned)b), dim3(256), 0, S_(st), theta, phi, g, lse, go, ws,
+               dphi, dg, N, Nk);
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- sentence encoder (models/txt/basic.py:49-70)
 // One time step of one (layer, direction) of the packed-sequence LSTM: the recurrent product h_prev[b] . W_hh^T is added to the
 // input projection of step t (computed for all steps by one GEMM), the gates (order i, f, g, o) are applied and — pack_padded_

@@ -100,7 +100,7 @@ class GradArena(object):
         p0 = self.params[0]
         self.flat = torch.zeros(n, device=p0.device, dtype=p0.dtype)
         self.copy_fn = copy_fn
-        self.sparse = []                       # (offset in flat, rows = Cout*Cin, taps per row T, live tap list, offset in compact)
+        self.sparse = []                       # (offset in flat, rows = Cout*Cin, taps per row T, live tap list, offset in compact, tap-major?)
         m = 0
         for p in sparse:
             taps = [int(t) for t in live_taps[p]]
@@ -108,12 +108,15 @@ class GradArena(object):
             for d in p.shape[2:]:
                 T *= int(d)
             rows = p.numel() // T
-            self.sparse.append((self.offsets[len(dense) + len(self.sparse)], rows, T, taps, m))
+            self.sparse.append((self.offsets[len(dense) + len(self.sparse)], rows, T, taps, m, not p.is_contiguous()))
             m += rows * len(taps)
         self.compact = torch.zeros(m, device=p0.device, dtype=p0.dtype) if m else None
 
     def views(self):
-        return [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        """One view per parameter with the parameter's own shape AND strides (tap-major master weights keep their layout: the
+        optimiser walks parameter, gradient and moments with the same flat index)."""
+        return [self.flat[o:o + p.numel()].view_as(p) if p.is_contiguous() else torch.as_strided(self.flat, p.shape, p.stride(), o)
+                for o, p in zip(self.offsets, self.params)]
 
     def gather(self):
         """p.grad -> arena slice (missing grads count as zero)."""
@@ -129,7 +132,17 @@ class GradArena(object):
 
     def _taps(self, pack):
         """live taps: arena -> compact (pack) or compact -> arena (unpack); strided column copies."""
-        for off, rows, T, taps, coff in self.sparse:
+        for off, rows, T, taps, coff, tap_major in self.sparse:
+            if tap_major:                     # [T][rows] in memory: a live tap is one contiguous run
+                for j, t in enumerate(taps):
+                    a = self.flat[off + t * rows:off + (t + 1) * rows]
+                    b = self.compact[coff + j * rows:coff + (j + 1) * rows]
+                    src_, dst_ = (a, b) if pack else (b, a)
+                    if self.flat.is_cuda and self.copy_fn is not None:
+                        self.copy_fn(src_, dst_)
+                    else:
+                        dst_.copy_(src_)
+                continue
             src = self.flat[off:off + rows * T].view(rows, T)
             dst = self.compact[coff:coff + rows * len(taps)].view(rows, len(taps))
             for j, t in enumerate(taps):

@@ -18,7 +18,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, MAX_TAPS, MAX_GROUPS
+from ._lib import lib, check, ConvGeom, ConvGroup, PackJob, WgradSrc, WgradDest, WGRAD_MAX_SRC, MAX_TAPS, MAX_GROUPS
 
 FLAG_BIAS, FLAG_RELU_IN, FLAG_ACCUM, FLAG_MASK_OUT, FLAG_ACCUM_BIAS, FLAG_BF16 = 1, 2, 4, 8, 16, 32
 
@@ -43,6 +43,31 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def tap_major(w):
+    """The same conv weight [Cout,Cin,*k] with its MEMORY laid out [*k][Cout][Cin] (a permuted view of a dense buffer)."""
+    nd = w.dim()
+    fwd = tuple(range(2, nd)) + (0, 1)
+    back = tuple(range(nd - 2, nd)) + tuple(range(nd - 2))
+    return w.permute(*fwd).contiguous().permute(*back)
+
+
+def is_tap_major(w):
+    """True for the layout `tap_major` produces (False for dense weights; anything else is rejected)."""
+    if w.is_contiguous():
+        return False
+    nd = w.dim()
+    if nd >= 3 and w.permute(*(tuple(range(2, nd)) + (0, 1))).is_contiguous():
+        return True
+    raise ValueError('conv weights are dense [Cout,Cin,*k] or tap-major; got strides %s for shape %s' % (w.stride(), tuple(w.shape)))
+
+
+def tap_rows(t):
+    """[T, Cout*Cin] view of a tap-major tensor (each kernel tap one contiguous row)."""
+    nd = t.dim()
+    v = t.permute(*(tuple(range(2, nd)) + (0, 1)))
+    return v.reshape(-1, t.shape[0] * t.shape[1])
+
+
 _param_grads_enabled = True
 WEIGHT_EPOCH = 0     # bumped by the optimiser after each in-place update (invalidates packed weights)
 
@@ -62,30 +87,138 @@ def input_grads_only():
         _param_grads_enabled = old
 
 
+class _PendingDest(object):
+    __slots__ = ('wid', 'bid', 'dw', 'dbias', 'CoCi', 'T', 'Cout', 'accum', 'accum_bias', 'srcs', 'keep', 'tap_major')
+
+
 class GradSink(object):
     """Weight / bias gradients written straight into a flat per-model arena (`dist.GradArena`) by the kernels that
     produce them: the first producer of a step stores, later producers of the same parameter accumulate in place
     (T2V_CONV_ACCUM) and hand autograd nothing — no per-parameter sum kernels, and the data-parallel exchange finds
     the gradients already in its buffer. Only used while autograd is not recording (the final `loss.backward()`);
-    `reset()` belongs wherever the model's gradients are cleared."""
+    `reset()` belongs wherever the model's gradients are cleared.
+
+    Convolution weight gradients are DEFERRED: each layer's weight-gradient launch leaves its k-split partial sums in its
+    slab (`t2v_conv_wgrad_grouped_partial`) and `flush()` — called once after the backward pass — sums every pending slab of
+    every parameter in ONE launch (`t2v_wgrad_reduce_multi`) instead of one ~10 us reduce launch per layer. A producer
+    that writes a parameter's slot directly while slabs are pending for it flushes that parameter first (ordering)."""
 
     def __init__(self, arenas):
         self.slots, self.count = {}, {}
         for arena in arenas:
             for off, p in zip(arena.offsets, arena.params):
                 self.slots[id(p)] = (arena, off, p.numel())
+        self.defer = os.environ.get('T2V_NO_DEFERRED_REDUCE') is None
+        self.pending, self.pending_bias = {}, {}          # id(weight) -> _PendingDest; id(bias) -> id(weight)
+        # Destination tables live in a fixed device buffer, uploaded from a fixed pinned buffer (both allocated HERE, outside
+        # any graph capture): a table is uploaded once per distinct content (slot per signature) — a copy from pinned memory
+        # is also a legal graph node should a capture meet a new table.
+        self.tables = {}                                  # table bytes -> slot
+        self.slot_bytes, self.nslots = 65536, 48
+        dev = arenas[0].flat.device if arenas else None
+        self.tab_pin = self.tab_dev = None
+        if dev is not None and dev.type == 'cuda' and self.defer:
+            self.tab_pin = torch.empty(self.slot_bytes * self.nslots, dtype=torch.uint8).pin_memory()
+            self.tab_dev = torch.empty(self.slot_bytes * self.nslots, dtype=torch.uint8, device=dev)
+        else:
+            self.defer = False
+        # k-split slabs come from one bump-allocated workspace sized by the first iteration: every later iteration — eager,
+        # captured or replayed — hands each launch the same address, so the destination tables repeat and are uploaded once
+        self.ws, self.ws_off, self.ws_used = None, 0, 0
 
     def reset(self):
+        self.flush()
         self.count.clear()
+        if self.ws_used > (self.ws.numel() if self.ws is not None else 0) and not torch.cuda.is_current_stream_capturing():
+            self.ws = None                                # (release before growing)
+            self.ws = torch.empty(self.ws_used + (self.ws_used >> 3), dtype=torch.float32, device=self.tab_dev.device)
+            torch.cuda.current_stream().synchronize()      # (first iterations only) pending table uploads are done with their slots
+            self.tables.clear()
+        self.ws_off = self.ws_used = 0
 
-    def take(self, param):
+    def alloc_slab(self, n, device):
+        """`n` floats for one launch's partial sums: from the workspace when it has room, else a tensor of its own (first
+        iteration, or a pass that needs more than any before)."""
+        n = (int(n) + 63) & ~63
+        self.ws_used += n
+        if self.ws is not None and self.ws_off + n <= self.ws.numel():
+            v = self.ws[self.ws_off:self.ws_off + n]
+            self.ws_off += n
+            return v
+        return torch.empty((n,), device=device, dtype=torch.float32)
+
+    def take(self, param, deferred=False):
         slot = self.slots.get(id(param))
         if slot is None:
             return None
+        if not deferred and self.pending:
+            wid = id(param) if id(param) in self.pending else self.pending_bias.get(id(param))
+            if wid is not None:
+                self._flush([self.pending[wid]])
         arena, off, n = slot
         c = self.count.get(id(param), 0)
         self.count[id(param)] = c + 1
         return arena.flat[off:off + n], c > 0
+
+    # ---- deferred weight gradients
+    def add_partial(self, wbase, dw, wacc, b, dbias, bacc, src, keep, T, Cout, CoCi, tap_major=False):
+        """Register one weight-gradient launch's slab (`src`: a filled WgradSrc) for parameter `wbase` (+ bias `b`)."""
+        d = self.pending.get(id(wbase))
+        if d is not None and (len(d.srcs) >= WGRAD_MAX_SRC or (d.bid is not None and b is not None and d.bid != id(b))):
+            self._flush([d])
+            d, wacc, bacc = None, True, True
+        if d is None:
+            d = _PendingDest()
+            d.wid, d.bid, d.dw, d.dbias = id(wbase), None, dw.data_ptr(), 0
+            d.CoCi, d.T, d.Cout, d.accum, d.accum_bias, d.srcs, d.keep = CoCi, T, Cout, 1 if wacc else 0, 0, [], []
+            d.tap_major = 1 if tap_major else 0
+            self.pending[id(wbase)] = d
+        if b is not None and d.bid is None:
+            d.bid, d.dbias, d.accum_bias = id(b), dbias.data_ptr(), 1 if bacc else 0
+            self.pending_bias[id(b)] = id(wbase)
+        d.srcs.append(src)
+        d.keep.append(keep)
+
+    def flush(self):
+        if self.pending:
+            self._flush(list(self.pending.values()))
+
+    def _flush(self, dests):
+        arr = (WgradDest * len(dests))()
+        blocks = 0
+        sig = []
+        for a, d in zip(arr, dests):
+            a.dw, a.dbias, a.CoCi, a.T, a.Cout = d.dw, d.dbias or None, d.CoCi, d.T, d.Cout
+            a.nsrc, a.accum, a.accum_bias, a.tap_major = len(d.srcs), d.accum, d.accum_bias, d.tap_major
+            smax = max(sr.S for sr in d.srcs)
+            a.kind = 1 if (d.CoCi <= 16384 and smax >= 16) else 0
+            a.block_begin = blocks
+            a.nblocks = ((d.CoCi + 63) // 64) * (d.T if a.kind else 1)
+            blocks += a.nblocks
+            for k, sr in enumerate(d.srcs):
+                C.memmove(C.byref(a.src[k]), C.byref(sr), C.sizeof(WgradSrc))
+        raw = bytes(arr)
+        slot = self.tables.get(raw)
+        if slot is None:
+            assert C.sizeof(WgradDest) == lib().t2v_wgrad_dest_bytes()
+            if len(raw) > self.slot_bytes:
+                raise RuntimeError('weight-gradient destination table of %d bytes' % len(raw))
+            if len(self.tables) >= self.nslots:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('out of destination-table slots during graph capture')
+                torch.cuda.current_stream().synchronize()  # (eager, pointers drifting: earlier uploads are done with their slots)
+                self.tables.clear()
+            slot = len(self.tables)
+            lo = slot * self.slot_bytes
+            self.tab_pin[lo:lo + len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))     # host memcpy
+            self.tab_dev[lo:lo + len(raw)].copy_(self.tab_pin[lo:lo + len(raw)], non_blocking=True)
+            self.tables[raw] = slot
+        check(lib().t2v_wgrad_reduce_multi(C.c_void_p(self.tab_dev.data_ptr() + slot * self.slot_bytes), len(dests), blocks, _stream()),
+              't2v_wgrad_reduce_multi')
+        for d in dests:
+            self.pending.pop(d.wid, None)
+            if d.bid is not None:
+                self.pending_bias.pop(d.bid, None)
 
 
 _grad_sink = None
@@ -94,12 +227,21 @@ _grad_sink = None
 def set_grad_sink(sink):
     global _grad_sink
     old, _grad_sink = _grad_sink, sink
+    if old is not None and old is not sink:
+        old.flush()
     return old
 
 
 def grad_sink_reset():
     if _grad_sink is not None:
         _grad_sink.reset()
+
+
+def grad_sink_flush():
+    """Sum every pending weight-gradient slab into its parameter's slot (one launch). Call after a backward pass, before
+    anything reads the gradients (optimiser step, gradient exchange)."""
+    if _grad_sink is not None:
+        _grad_sink.flush()
 
 
 def _to_sink_wb(w, b, xs, gys, relu_in):
@@ -111,10 +253,30 @@ def _to_sink_wb(w, b, xs, gys, relu_in):
     wbase = w._base if w._base is not None else w
     if id(wbase) not in _grad_sink.slots or id(b) not in _grad_sink.slots:
         return False, None, None
-    wflat, wacc = _grad_sink.take(wbase)
-    bflat, bacc = _grad_sink.take(b)
-    conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
+    deferred = _grad_sink.defer and _wgrad_bias_fused(xs, tuple(w.shape))
+    wflat, wacc = _grad_sink.take(wbase, deferred)
+    bflat, bacc = _grad_sink.take(b, deferred)
+    if deferred:
+        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, b, bflat, bacc)
+    else:
+        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
     return True, (None if wacc else wflat.view(w.shape)), (None if bacc else bflat.view(b.shape))
+
+
+def _to_sink_w(w, xs, gys, relu_in):
+    """Weight gradient of one (grouped) convolution into its sink slot, deferred when the sink batches its reductions.
+    Returns (handled, gw) like `_to_sink`."""
+    if _grad_sink is None or w is None or torch.is_grad_enabled():
+        return False, None
+    wbase = w._base if w._base is not None else w
+    if id(wbase) not in _grad_sink.slots:
+        return False, None
+    wflat, wacc = _grad_sink.take(wbase, _grad_sink.defer)
+    if _grad_sink.defer:
+        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, None, None, False)
+    else:
+        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc)
+    return True, (None if wacc else wflat.view(w.shape))
 
 
 def _to_sink(param_like, compute):
@@ -351,14 +513,16 @@ def packed_fused(ws, ts, mode):
     for i, w in enumerate(ws):
         ro, co = (0, i * Cout) if mode == 0 else (i * Cout, 0)
 
-        def fn(wi, ro=ro, co=co):
-            check(lib().t2v_pack_weight_into(_p(wi), _p(wp), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode, rows, cols,
+        tm = 8 if is_tap_major(w) else 0         # (mode | 8: the source is stored tap-major)
+
+        def fn(wi, ro=ro, co=co, tm=tm):
+            check(lib().t2v_pack_weight_into(_p(wi), _p(wp), Cout, Cin, ts.T, ts.taps_c, len(ts.taps), mode | tm, rows, cols,
                                              ro, co, _stream()), 't2v_pack_weight_into')
         refresh.append(fn)
         fn(w)
         if cacheable:                      # lets `repack_params` refresh this member in its one multi-tensor launch
             _pack_cache.setdefault(id(bases[i]), {})[('fused', key, i)] = [weakref.ref(bases[i]), _wtag(bases[i], w.data_ptr()), wp, fn,
-                                                                           (w, wp, Cout, Cin, ts.T, list(ts.taps), mode, rows, cols, ro, co)]
+                                                                           (w, wp, Cout, Cin, ts.T, list(ts.taps), mode | tm, rows, cols, ro, co)]
     if cacheable:
         _fused_cache[key] = [[weakref.ref(b_) for b_ in bases], tuple(_wtag(b_, w.data_ptr()) for b_, w in zip(bases, ws)), wp, refresh]
     return wp
@@ -480,7 +644,7 @@ class Conv(Function):
                 both, gw, gb = _to_sink_wb(w, ctx.bias, [x], [gy], False)
             if not both:
                 if ctx.needs_input_grad[1]:
-                    done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), out=out, accum=acc))
+                    done, gw = _to_sink_w(w, [x], [gy], False)
                     if not done:
                         gw = ConvWgrad.apply(x, gy, tuple(w.shape))
                 if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -505,7 +669,7 @@ class ConvDgrad(Function):
         if ctx.needs_input_grad[0]:
             d_gy = Conv.apply(ggx, w, None)
         if ctx.needs_input_grad[1] and _param_grads_enabled:
-            done, d_w = _to_sink(w, lambda out, acc: conv_wgrad_raw(ggx, gy, tuple(w.shape), out=out, accum=acc))
+            done, d_w = _to_sink_w(w, [ggx], [gy], False)
             if not done:
                 d_w = ConvWgrad.apply(ggx, gy, tuple(w.shape))
         return d_gy, d_w
@@ -554,7 +718,7 @@ class ReluConv(Function):
                 both, gw, gb = _to_sink_wb(w, ctx.bias, [x], [gy], True)
             if not both:
                 if ctx.needs_input_grad[1]:
-                    done, gw = _to_sink(w, lambda out, acc: conv_wgrad_raw(x, gy, tuple(w.shape), relu_in=True, out=out, accum=acc))
+                    done, gw = _to_sink_w(w, [x], [gy], True)
                     if not done:
                         gw = ReluConvWgrad.apply(x, gy, tuple(w.shape))
                 if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1044,6 +1208,44 @@ class SoftmaxBwd(Function):
 
 def softmax_lastdim(x):
     return Softmax.apply(x)
+
+
+class NonlocalAttend(Function):
+    """o = g . softmax(theta^T phi)^T fused (`t2v_nonlocal_fwd/_bwd`): beta [b, N, Nk] never reaches HBM. First-order only
+    (the generator's 2-D block, layers.py:23-36; the discriminator's 3-D block sits inside the gradient penalty's recorded
+    graph and stays on the closed bmm / softmax set). theta [b,C8,N], phi [b,C8,Nk], g [b,C2,Nk] -> o [b,C2,N]."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        theta, phi, g = _c(theta), _c(phi), _c(g)
+        b, C8, N = theta.shape
+        C2, Nk = g.shape[1], g.shape[2]
+        o = torch.empty((b, C2, N), device=theta.device, dtype=torch.float32)
+        lse = torch.empty((b, N), device=theta.device, dtype=torch.float32)
+        check(lib().t2v_nonlocal_fwd(_p(theta), _p(phi), _p(g), _p(o), _p(lse), b, C8, C2, N, Nk, _stream()), 't2v_nonlocal_fwd')
+        ctx.save_for_backward(theta, phi, g, o, lse)
+        return o
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        theta, phi, g, o, lse = ctx.saved_tensors
+        go = _c(go)
+        b, C8, N = theta.shape
+        C2, Nk = g.shape[1], g.shape[2]
+        dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+        ws = torch.empty((b, N), device=theta.device, dtype=torch.float32)
+        check(lib().t2v_nonlocal_bwd(_p(theta), _p(phi), _p(g), _p(o), _p(lse), _p(go), _p(dtheta), _p(dphi), _p(dg), _p(ws),
+                                     b, C8, C2, N, Nk, _stream()), 't2v_nonlocal_bwd')
+        return dtheta, dphi, dg
+
+
+def nonlocal_attend_ok(c8, c2):
+    return bool(lib().t2v_nonlocal_ok(int(c8), int(c2)))
+
+
+def nonlocal_attend(theta, phi, g):
+    return NonlocalAttend.apply(theta, phi, g)
 
 
 class Dot(Function):
@@ -1674,8 +1876,19 @@ class ConvLSTMFn(Function):
             gx, _ = conv_packed_raw(gpre[0], wpx1, 4 * Cc, Cc, k)
             gx = gx.squeeze(2)
         w4shape = (4 * Cc, Cc) + k
-        gwx4 = conv_wgrad_raw(x5, gpre[0], w4shape)                       # all four gates at once
         gb4 = channel_sum_raw(gpre.view(steps * B, 4 * Cc, 1, h, w))      # every step contributes to the bias
+        gbx = [gb4[g * Cc:(g + 1) * Cc] for g in range(4)]
+        sink = _grad_sink
+        if (sink is not None and sink.defer and not torch.is_grad_enabled() and steps > 1 and
+                all(id(t) in sink.slots and not t.is_contiguous() and is_tap_major(t) for t in tuple(wx) + tuple(wh))):
+            # tap-major master weights with slots in the gradient sink: the partial sums of the two fused launches are summed
+            # straight into the gates' slots by the sink's one reduce launch — live taps only, no [4C, C, 3, 3] intermediates
+            gwx = _fused_gates_to_sink(sink, wx, x5, gpre[0], w4shape)
+            hin = hs[:steps - 1].reshape((steps - 1) * B, Cc, 1, h, w)    # time folded into the batch
+            gin = gpre[1:].reshape((steps - 1) * B, 4 * Cc, 1, h, w)
+            gwh = _fused_gates_to_sink(sink, wh, hin, gin, w4shape)
+            return (gx, None) + tuple(gwx) + tuple(gbx) + tuple(gwh)
+        gwx4 = conv_wgrad_raw(x5, gpre[0], w4shape)                       # all four gates at once
         if steps > 1:
             hin = hs[:steps - 1].reshape((steps - 1) * B, Cc, 1, h, w)    # time folded into the batch
             gin = gpre[1:].reshape((steps - 1) * B, 4 * Cc, 1, h, w)
@@ -1684,7 +1897,6 @@ class ConvLSTMFn(Function):
             gwh4 = _zeros_like(gwx4)
         gwx = [gwx4[g * Cc:(g + 1) * Cc].squeeze(2) for g in range(4)]
         gwh = [gwh4[g * Cc:(g + 1) * Cc].squeeze(2) for g in range(4)]
-        gbx = [gb4[g * Cc:(g + 1) * Cc] for g in range(4)]
         return (gx, None) + tuple(gwx) + tuple(gbx) + tuple(gwh)
 
 
@@ -2684,6 +2896,55 @@ def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False
     return dw
 
 
+def _wgrad_bias_fused(xs5, wshape):
+    """True when the weight-gradient kernel for these members sums dL/dy on the side (the MFMA kernels: Cin >= 64)."""
+    return wshape[1] >= 64
+
+
+def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None):
+    """The weight-gradient main kernel alone: returns (WgradSrc describing the k-split partial sums, the slab holding them)."""
+    xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
+    Cout, Cin = wshape[0], wshape[1]
+    k = tuple(wshape[2:])
+    geoms = [conv_geom(t.shape[0], Cin, t.shape[2], t.shape[3], t.shape[4], Cout, k[0], k[1], k[2]) for t in xs5]
+    arr = _group_table(xs5, gys5, geoms, None)
+    query = lib().t2v_conv_wgrad_grouped_bias_slab_floats if want_bias else lib().t2v_conv_wgrad_grouped_slab_floats
+    n = int(query(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
+    if n <= 0:
+        raise RuntimeError('bad grouped wgrad geometry')
+    slab = sink.alloc_slab(n, xs5[0].device) if sink is not None else torch.empty((n,), device=xs5[0].device, dtype=torch.float32)
+    src = WgradSrc()
+    flags = (FLAG_RELU_IN if relu_in else 0) | (FLAG_BF16 if CONV_PRECISION == 'bf16' else 0)
+    check(lib().t2v_conv_wgrad_grouped_partial(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(slab), 1 if want_bias else 0, flags,
+                                               C.byref(src), _stream()), 't2v_conv_wgrad_grouped_partial')
+    return src, slab
+
+
+def conv_group_wgrad_partial(xs5, gys5, wshape, relu_in, sink, wbase, dw, wacc, b, dbias, bacc):
+    """The weight-gradient launch WITHOUT its reduce pass: the k-split partial sums stay in a slab that `sink` keeps alive
+    and sums (with every other pending slab) in its one `flush()` launch."""
+    src, slab = _wgrad_partial_launch(xs5, gys5, wshape, relu_in, b is not None, sink)
+    k = tuple(wshape[2:])
+    sink.add_partial(wbase, dw, wacc, b, dbias, bacc, src, slab, k[0] * k[1] * k[2], wshape[0], wshape[0] * wshape[1])
+
+
+def _fused_gates_to_sink(sink, gates, x5, gy5, w4shape):
+    """Weight gradients of the ConvLSTM's four gates (ONE launch on the side-by-side [4C, C, ...] weight) straight into the
+    gates' tap-major sink slots: each gate is a row block of every slab plane. Returns the four gradient views."""
+    src, slab = _wgrad_partial_launch([x5], [gy5], w4shape, False, False, sink)
+    Cc = w4shape[1]
+    T = w4shape[2] * w4shape[3] * w4shape[4]
+    out = []
+    for g, w in enumerate(gates):
+        flat, acc = sink.take(w, deferred=True)
+        sg = WgradSrc()
+        C.memmove(C.byref(sg), C.byref(src), C.sizeof(WgradSrc))
+        sg.slab = src.slab + 4 * g * Cc * Cc                      # rows [g*C, (g+1)*C) of each [4C][C] plane
+        sink.add_partial(w, flat, acc, None, None, False, sg, slab, T, Cc, Cc * Cc, tap_major=True)
+        out.append(None if acc else flat.as_strided(w.shape, w.stride()))
+    return out
+
+
 def _zeros_like(t):
     out = torch.empty_like(t)
     check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
@@ -2734,7 +2995,7 @@ def _group_param_grads(w, b, relu_in, lx, lg, need_w, need_b):
         both, gw, gb = _to_sink_wb(w, b, lx, lg, relu_in)
     if not both:
         if need_w:
-            done, gw = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), relu_in, out=out, accum=acc))
+            done, gw = _to_sink_w(w, lx, lg, relu_in)
             if not done:
                 gw = ConvWgradG.apply(tuple(w.shape), relu_in, len(lx), *(lx + lg))
         if need_b:
@@ -2842,7 +3103,7 @@ class ConvDgradG(Function):
             return (None,) + tuple(d_gys)
         if ctx.needs_input_grad[0] and _param_grads_enabled:
             lx, lg = [ggxs[i] for i in live], [gys[i] for i in live]
-            done, d_w = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), False, out=out, accum=acc))
+            done, d_w = _to_sink_w(w, lx, lg, False)
             if not done:
                 d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *(lx + lg))
         need = [i for i in live if ctx.needs_input_grad[1 + i]]
@@ -2881,7 +3142,7 @@ class ConvDgradMaskG(Function):
                 hs = {i: ReluMask.apply(ggxs[i], xs[i]) for i in live}
             if ctx.needs_input_grad[0] and _param_grads_enabled:
                 lx, lg = [hs[i] for i in live], [gys[i] for i in live]
-                done, d_w = _to_sink(w, lambda out, acc: conv_group_wgrad_raw(lx, lg, tuple(w.shape), False, out=out, accum=acc))
+                done, d_w = _to_sink_w(w, lx, lg, False)
                 if not done:
                     d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *(lx + lg))
             need = [i for i in live if ctx.needs_input_grad[2 + i]]

@@ -1,6 +1,7 @@
 """Sample dumps — `save_frames` / `save_sentences` of txt2vid/gan/trainer.py:92-108 without torchvision:
 a [b,C,T,H,W] batch becomes one PNG grid (one row per clip, `nrow = T`, 2-pixel padding, min/max
-normalisation over the whole tensor like `torchvision.utils.save_image(normalize=True)`). Host-side I/O."""
+normalisation over the whole tensor like `torchvision.utils.save_image(normalize=True)`). `.png` paths go through the
+built-in writer, any other extension through PIL (the reference's sampling path writes `.jpg`). Host-side I/O."""
 import struct
 import zlib
 
@@ -52,7 +53,12 @@ def save_frames(x, path=None, channel_first=True, is_images=False):
     lo, hi = float(frames.min()), float(frames.max())
     frames = (frames - lo) / max(hi - lo, 1e-5)
     grid = make_grid(frames, nrow)
-    _png(path, (np.clip(grid, 0, 1) * 255 + 0.5).astype(np.uint8).transpose(1, 2, 0))
+    img = (np.clip(grid, 0, 1) * 255 + 0.5).astype(np.uint8).transpose(1, 2, 0)
+    if str(path).lower().endswith('.png'):
+        _png(path, img)
+    else:                                   # the reference's `<h>x<w>_<i>_<j>.jpg`: the format follows the extension
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(img)).save(path)
 
 
 def save_sentences(captions, path=None, vocab=None):

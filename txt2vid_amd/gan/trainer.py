@@ -115,6 +115,7 @@ class TrainStep(object):
         loss = self.gan.discrim_step(real=self.xs, fake=[f.detach() for f in self.fake], cond=self.conds,
                                      loss=self.losses.discrim_loss, gp_lambda=p.gp_lambda)
         loss.backward(retain_graph=self.end2end)
+        TF.grad_sink_flush()              # the weight-gradient partial sums of the whole pass, summed in one launch
         self.lD = loss.detach()
 
     def part_g(self):
@@ -133,6 +134,7 @@ class TrainStep(object):
                     _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
             loss = self.gan.gen_step(fake=self.fake, real_pred=real_pred, cond=self.conds, loss=self.losses.gen_loss)
         loss.backward()
+        TF.grad_sink_flush()
         self.lG = loss.detach()
 
     def part_end(self):
@@ -293,8 +295,10 @@ class GraphedSentenceEncoder(object):
 
 
 def test(gan=None, num_samples=1, dataset=None, device=None, params=None, channel_first=True, vocab=None):
-    """Sampling path — trainer.py:44-90: eval-mode generator renders one full [B,C,16,S,S] clip per latent
-    (no sub-sampling, last level only); real and generated grids (+ captions) are written per batch."""
+    """Sampling path — trainer.py:44-90. `num_samples` times: take the FIRST batch of the loader (the reference `break`s after
+    one), encode its captions, draw z, run the eval-mode generator (one full [B,C,16,S,S] clip per latent: no sub-sampling,
+    last level only unless `output_blocks` asks for more) and write, with the reference's file names,
+    `real_<i>.png`, `sentences_<i>_<j>.txt` and one `<h>x<w>_<i>_<j>.jpg` grid per rendered level."""
     from .samples import save_frames, save_sentences
     from ..data import DevicePrefetcher
     ensure_exists(params.out_samples)
@@ -304,19 +308,22 @@ def test(gan=None, num_samples=1, dataset=None, device=None, params=None, channe
             pre = DevicePrefetcher(dataset, device)
             j = 0
             x, y = pre.next()
-            while x is not None:
-                x = TF.video_to_channel_first(x)
-                cond = None
-                if gan.cond_encoder is not None and len(y) >= 2:
-                    _, _, cond = gan.cond_encoder.encode(y[0], y[1])
-                z = torch.randn(x.size(0), gan.gen.latent_size).to(device)
-                fake = gan(z, cond=cond)
-                save_frames(x, '%s/real_%d_%d.png' % (params.out_samples, i, j))
-                save_frames(fake[-1], '%s/fake_%d_%d.png' % (params.out_samples, i, j))
-                if cond is not None and vocab is not None:
-                    save_sentences(y[0], path='%s/sentences_%d_%d.txt' % (params.out_samples, i, j), vocab=vocab)
-                x, y = pre.next()
-                j += 1
+            if x is None:
+                break
+            x = TF.video_to_channel_first(x)
+            cond = None
+            if gan.cond_encoder is not None and len(y) >= 2:
+                _, _, cond = gan.cond_encoder.encode(y[0], y[1])
+            z = torch.randn(x.size(0), gan.gen.latent_size).to(device)
+            fake = gan(z, cond=cond)
+            save_frames(x, '%s/real_%d.png' % (params.out_samples, i), is_images=getattr(params, 'img_model', False))
+            if cond is not None and vocab is not None:
+                save_sentences(y[0], path='%s/sentences_%d_%d.txt' % (params.out_samples, i, j), vocab=vocab)
+            for f in fake:
+                h, w = f.size(3), f.size(4)
+                path = '%s/%dx%d_%d_%d.jpg' % (params.out_samples, h, w, i, j)
+                status('saving to %s' % path)
+                save_frames(f, path, is_images=getattr(params, 'img_model', False))
     gan.gen.train()
 
 

@@ -99,8 +99,13 @@ def _nonlocal(self, x, pooled_planes):
     theta = theta.reshape(b, self.ch // 8, -1)
     phi = phi.reshape(b, self.ch // 8, -1)
     g = g.reshape(b, self.ch // 2, -1)
-    beta = TF.softmax_lastdim(TF.bmm(theta, phi, True, False))          # [b, N, N/4]
-    o = TF.bmm(g, beta, False, True).reshape((b, self.ch // 2) + tuple(x.shape[2:]))
+    if getattr(self, 'fused_attend', False) and TF.nonlocal_attend_ok(self.ch // 8, self.ch // 2):
+        # the generator's 2-D block: scores -> softmax -> weighted sum in one kernel, beta [b, N, N/4] never materialised
+        o = TF.nonlocal_attend(theta, phi, g)
+    else:
+        beta = TF.softmax_lastdim(TF.bmm(theta, phi, True, False))          # [b, N, N/4]
+        o = TF.bmm(g, beta, False, True)
+    o = o.reshape((b, self.ch // 2) + tuple(x.shape[2:]))
     o = self.o(o)
     return TF.scale_add(self.gamma, o, x)
 
@@ -139,6 +144,7 @@ class Attention(nn.Module):
         self.g = which_conv(ch, ch // 2, kernel_size=1, padding=0, bias=False)
         self.o = which_conv(ch // 2, ch, kernel_size=1, padding=0, bias=False)
         self.gamma = P(torch.tensor(0.), requires_grad=True)
+        self.fused_attend = True          # first-order use only (generator): the fused kernel has no second-order adjoint
 
     def forward(self, x, y=None):
         return _nonlocal(self, x, 2)

@@ -51,6 +51,8 @@ class MultiScaleGen(nn.Module):
         levels += [UpBlock(in_channels=widths[i - 1], out_channels=widths[i], with_non_local=(i == nl_at)) for i in range(1, len(widths))]
         self.abstract_blocks = nn.ModuleList(levels)
         self.render_blocks = nn.ModuleList([RenderBlock(in_channels=w, out_channels=num_channels) for w in widths])
+        for weight, taps in self.structurally_live_taps().items():
+            weight._t2v_live_taps = list(taps)          # the optimiser only walks these taps of the (tap-major) master copies
 
     def structurally_live_taps(self):
         """{weight: live kernel taps} for the ConvLSTM when its state is 1x1 (frames below 128x128): a 3x3 kernel on a 1x1

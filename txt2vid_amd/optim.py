@@ -12,9 +12,10 @@ def _densify_state(opt):
             if isinstance(v, torch.Tensor) and v.dim() > 0:
                 if tuple(v.shape) != tuple(p.shape):
                     raise ValueError('optimiser state %r has shape %s for a parameter of shape %s' % (k, tuple(v.shape), tuple(p.shape)))
-                dense = v.is_contiguous() and v.untyped_storage().nbytes() >= v.numel() * v.element_size()
+                dense = (v.stride() == p.stride() and v.untyped_storage().nbytes() >= (v.storage_offset() + v.numel()) * v.element_size()
+                         and (p.is_contiguous() or TF.is_tap_major(p)))
                 if not dense or v.dtype != p.dtype or v.device != p.device:
-                    st[k] = v.to(device=p.device, dtype=p.dtype).contiguous().clone()
+                    st[k] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(v)   # the parameter's layout
 
 
 class Adam(torch.optim.Optimizer):
@@ -75,8 +76,20 @@ class Adam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] = int(st['step']) + 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault(st['step'], []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
+                g = p.grad
+                if g.stride() != p.stride():             # the kernel walks p, g, m, v with one flat index
+                    g = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(g)
+                live = getattr(p, '_t2v_live_taps', None)
+                if live is not None and not p.is_contiguous() and TF.is_tap_major(p):
+                    # structurally dead kernel taps (ConvLSTM on a 1x1 state: gradient exactly 0, moments stay 0, update 0): only
+                    # the live taps' contiguous rows are read and written
+                    rows = [TF.tap_rows(t) for t in (p, g, st['exp_avg'], st['exp_avg_sq'])]
+                    for t in live:
+                        by_step.setdefault(st['step'], []).append(tuple(r[t] for r in rows))
+                else:
+                    if not (p.is_contiguous() or TF.is_tap_major(p)):
+                        raise ValueError('parameter layout not supported by the fused optimiser: strides %s' % (p.stride(),))
+                    by_step.setdefault(st['step'], []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
                 touched.append(p)
             for step, items in by_step.items():
                 TF.adam_step_multi(items, group['lr'], b1, b2, group['eps'], step, self.grad_scale, self.step_dev)

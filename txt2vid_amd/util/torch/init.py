@@ -10,6 +10,15 @@ DRAWN = ('Linear', 'Conv', 'Embedding')          # substrings of the class names
 
 
 def _draw(kind, weight, residual):
+    if not weight.is_contiguous():
+        # (tap-major master copies, models/conv_lstm.py) torch fills a non-contiguous tensor in MEMORY order; the draws must land
+        # in logical order like the reference's: draw into a dense temporary, then copy
+        import torch
+        tmp = torch.empty(weight.shape, dtype=weight.dtype, device=weight.device)
+        _draw(kind, tmp, residual)
+        with torch.no_grad():
+            weight.copy_(tmp)
+        return
     if kind == 'xavier':
         schemes.xavier_normal_(weight, gain=math.sqrt(2)) if residual else schemes.xavier_normal_(weight)
     elif kind == 'ortho':
