@@ -12,17 +12,17 @@ def test_benchmark_shapes_select_the_big_tile_paths():
     name, cin, cout, k, members, _ = cc.GROUPED_CASES[0]
     assert name == 'stem_conv2_B32_8members'
     assert sum(n * d * h * w for n, d, h, w in members) == 393216
-    assert cc.fwd_plan(members, cin, cout, k) == ('strip', 256, 64, 16, 1, 1, 1, 1)          # conv_igemm_strip_kernel<256,64,1,16,true,1>
-    assert cc.fwd_plan(members, cout, cin, k) == ('strip', 256, 64, 16, 1, 1, 1, 1)          # its data gradient
+    assert cc.fwd_plan(members, cin, cout, k) == ('strip3', 256, 64, 16, 1, 1, 1, 1)         # conv_igemm_strip3_kernel<256,16,1,true>
+    assert cc.fwd_plan(members, cout, cin, k) == ('strip3', 256, 64, 16, 1, 1, 1, 1)         # its data gradient
     w = cc.wgrad_plan(members, cin, cout, k)
     assert w[0] == 'rows3' and w[4] == 'reduce_small' and w[1] >= 16                          # conv_wgrad3_kernel, many-splits reduce
     # the gradient-penalty members alone (M = 131072) still fill 512 tiles of 256 voxels
     _, cin, cout, k, members, _ = cc.GROUPED_CASES[1]
-    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 256, 64, 16)
-    # 64 -> 128 at M = 49152: 128x64 strip tiles forward, 64x64 tiles with three dx taps per round for the data gradient
+    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip3', 256, 64, 16)
+    # 64 -> 128 at M = 49152: 128x64 tiles forward, 64x64 tiles for the data gradient
     _, cin, cout, k, members, _ = cc.GROUPED_CASES[3]
     assert sum(n * d * h * w for n, d, h, w in members) == 49152
-    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip', 128, 64, 32)
+    assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip3', 128, 64, 32)
     assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip3', 64, 64, 32, 1, 1, 1)
 
 
@@ -32,7 +32,7 @@ ALL_FWD = set()
 for bm, bn, bk in _TILES:
     for vecb in (1, 0):
         ALL_FWD.add(('igemm', bm, bn, bk, 1, vecb, 1))                       # conv_igemm_kernel<BM,BN,*,BK,true,VECB>
-        if (bm, bn, bk) == (64, 64, 32):
+        if (bm, bn, bk) in ((64, 64, 32), (128, 64, 32), (256, 64, 16)):
             ALL_FWD.add(('strip3', bm, bn, bk, 1, vecb, 1))                  # conv_igemm_strip3_kernel<BM,VECB>: 3 dx taps per round
         elif bk == 32 or bm == 256:
             ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>

@@ -690,7 +690,7 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
             key = (('taps', 'cols', 'rows3')[plan[0]], ('reduce', 'reduce_small')[plan[4]])
             launched.add(key)
             assert key in checked_wgrad, key
-    assert ('strip', 256, 64, 16, 1, 1, 1) in launched and ('rows3', 'reduce_small') in launched
+    assert ('strip3', 256, 64, 16, 1, 1, 1) in launched and ('rows3', 'reduce_small') in launched
     print('B=32: %d convolution launches on %d instantiations, all covered by op-level parity cases' % (len(rows), len(launched)))
 
 

@@ -811,11 +811,11 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
 // (the next round's gathers are issued right after the first and land during the MFMA loop), 4 waves as 2 (co) x 2 (m).
 // Rounds = (row tap, channel block of 32); split-K runs over rounds. Members one voxel wide (ndx = 1) run their single tap.
 // ------------------------------------------------------------------------------------------------
-template <int BM, bool VECB>
-__global__ __launch_bounds__(256) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
+template <int BM, int BKT, int WAVES_CO, bool VECB>
+__global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ slab,
                                                                 const int Cin, const int Cout, const int flags, const int nsplit) {
-    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int BN = 64, WAVES_M = 4 / WAVES_CO;
     constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
     constexpr int NCO = WCO / 32, NM = WM / 32;
     constexpr int AP = BM + 4;              // [left halo][BM voxels][right halo][pad]
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_igemm_strip3_kernel(const GroupTable
     constexpr int KSBV = 1024 / BN;         // k rows covered by one pass of 256 float4 loads
     constexpr int LB = BKT * BN / 256;      // scalar path: 8 per thread per tap
     constexpr int KSB = 256 / BN;
-    static_assert(NCO == 1 && NM >= 1, "tile");
+    static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LBV >= 1 && 2 * BKT <= 256, "tile");
 
     __shared__ __attribute__((aligned(16))) float As[BKT * AP];
     __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
@@ -903,9 +903,11 @@ __global__ __launch_bounds__(256) void conv_igemm_strip3_kernel(const GroupTable
 
     f32x16 acc[NCO][NM];
 #pragma unroll
-    for (int j = 0; j < NM; ++j)
+    for (int i = 0; i < NCO; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[LA], rah = 0.f;
     float rb[VECB ? 1 : 3 * LB];
@@ -986,12 +988,19 @@ __global__ __launch_bounds__(256) void conv_igemm_strip3_kernel(const GroupTable
 #pragma unroll
                 for (int k2 = 0; k2 < BKT / 2; ++k2) {
                     const int krow = k2 * 2 + hi;
-                    const float a = bs[krow * BN];
+                    float a[NCO], b[NM];
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i) a[i] = bs[krow * BN + i * 32];
 #pragma unroll
                     for (int j = 0; j < NM; ++j) {
                         const float v = as[krow * AP + j * 32];
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, keep[j] ? v : 0.f, acc[0][j], 0, 0, 0);
+                        b[j] = keep[j] ? v : 0.f;
                     }
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+                        for (int j = 0; j < NM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -1705,24 +1714,19 @@ static bool strip_fits32(const GroupTable& tab, int Cin) {
     return true;
 }
 static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
-static bool g_ksplit_waves = getenv("T2V_NO_KSPLIT_WAVES") == nullptr;
-static long g_ksplit_max_blocks = getenv("T2V_KSPLIT_MAX_BLOCKS") ? atol(getenv("T2V_KSPLIT_MAX_BLOCKS")) : 768;
 
 // Which instantiation a (tile, chunk) choice ends up in: the strip variant (three dx taps from one staged strip) when the
 // members carry their taps in (row, dx) order, and for the 64x64x32 strip tile the K-split wave layout (KS = 2: two
 // accumulator chains per wave cost a VGPR occupancy step, 3 instead of 4 waves per SIMD: worth it only for launches that
 // cannot put 4 workgroups on every CU anyway). Shared by the launcher and by t2v_conv_fwd_plan.
 struct ConvVariant { bool strip; int ks; bool s3; };
-static bool g_strip3_enabled = getenv("T2V_NO_STRIP3") == nullptr;
-static bool g_strip3_128 = getenv("T2V_STRIP3_128") != nullptr;      // (measured: the 128-voxel form needs 174 registers -> 2 waves per SIMD, slower)
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
     ConvVariant v{false, 1, false};
     if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
         v.strip = true;
-        // 64- and 128-voxel tiles with 64 output channels: all three dx taps per barrier round (conv_igemm_strip3_kernel)
-        if (g_strip3_enabled && (BM == 64 || (BM == 128 && g_strip3_128)) && BN == 64 && BKT == 32) { v.s3 = true; return v; }
-        const long nblocks = (long)tab.tile_start[tab.n] * ((Cout + BN - 1) / BN) * p.S;
-        if (BM == 64 && BN == 64 && BKT == 32 && g_ksplit_waves && nblocks <= g_ksplit_max_blocks) v.ks = 2;
+        // tiles with 64 output channels (64 / 128 voxels x 32 channels, 256 voxels x 16 channels): all three dx taps per barrier
+        // round (conv_igemm_strip3_kernel; +12-15 % over one dx per round on every one of them); 128 x 32 keeps the per-dx form
+        v.s3 = BN == 64;
     }
     return v;
 }
@@ -1733,21 +1737,18 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + BN - 1) / BN), (unsigned)p.S);
     const ConvVariant v = conv_variant(tab, p, BM, BN, BKT, Cin, Cout, flags);
     if (v.s3) {
-        if constexpr ((BM == 64 || BM == 128) && BN == 64 && BKT == 32) {
-            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-            else T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+        if constexpr (BN == 64 && ((BM != 256 && BKT == 32) || (BM == 256 && BKT == 16))) {
+            constexpr int WCO3 = BM == 256 ? 1 : 2;
+            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            else T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
         }
         return;
     }
     if (v.strip) {
-        constexpr int KS = (BM == 64 && BN == 64 && BKT == 32) ? 2 : 1;
-        if (KS == 2 && v.ks != 2) {
+        if constexpr (BN == 32) {
             if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-            return;
         }
-        if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true, KS>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-        else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false, KS>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
         return;
     }
     if (p.fast) {
@@ -2899,12 +2900,16 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     const long base = p.rows3 ? (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows
                     : (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
-    static const long wg_target = getenv("T2V_WGRAD_TARGET") ? atol(getenv("T2V_WGRAD_TARGET")) : 1536;
-    long S = (wg_target + base - 1) / base;       // aim at ~6 workgroups per CU
+    // workgroups to aim at: the kernels run 4 workgroups per CU (1024 resident); two to three "waves" of them balance the
+    // uneven members best (measured: 1024 -> 918 us, 1536 -> 831, 2304 -> 734 on the stem layer; 2048 best on the mid-size ones)
+    static const long wg_env = getenv("T2V_WGRAD_TARGET") ? atol(getenv("T2V_WGRAD_TARGET")) : 0;
+    static const long s_cap = getenv("T2V_WGRAD_SCAP") ? atol(getenv("T2V_WGRAD_SCAP")) : 256;
+    const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : 2048);
+    long S = (wg_target + base - 1) / base;
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    if (S > s_cap) S = s_cap;
     p.cps = (int)((nch + S - 1) / S);
     p.S = (int)((nch + p.cps - 1) / p.cps);
     return true;
