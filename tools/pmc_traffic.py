@@ -1,15 +1,17 @@
-"""Assemble profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over tools/conv_micro.py:
+"""Assemble profiles/r02_pmc_traffic.json from two rocprofv3 PMC passes over tools/conv_micro.py:
 
     cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/conv_micro.py both 3
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/conv_micro.py both 3
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r02_pmc_traffic.json
 
 (one counter family per pass, MI355X_MICROARCH.md; FETCH_SIZE / WRITE_SIZE are in KB, summed over the TCC instances)."""
 import collections
 import csv
 import glob
 import json
+import hashlib
+import os
 import sys
 
 
@@ -36,7 +38,9 @@ M, C, T = 262144, 64, 27
 alg = (M * C * 4) * 2 + C * C * T * 4
 print(json.dumps({
     'workload': 'tools/conv_micro.py: grouped stem conv2 (64->64, 3x3x3) over the 4 pyramid levels at B=32 x2 (M=262144 voxels), '
-                'forward+dgrad = conv_igemm_strip_kernel<256,64,1,16>, wgrad = conv_wgrad3_kernel + wgrad_reduce',
+                'forward+dgrad = conv_igemm_strip3_kernel<256,16,1>, wgrad = conv_wgrad3_kernel + wgrad_reduce',
+    'conv_hip_sha1': hashlib.sha1(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'txt2vid_amd', 'csrc',
+                                                   'conv.hip'), 'rb').read()).hexdigest(),
     'algorithmic_bytes_per_launch': {'igemm (x + y + w)': alg, 'wgrad (x + gy + dw)': alg},
     'notes': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md: TCC slots). Units KB. '
              'WRITE_SIZE calibrates exactly on the known 64 MiB output of the forward; FETCH_SIZE may read low by up to 2x on '
