@@ -2404,12 +2404,21 @@ struct LiveRows { int8_t r[9]; int32_t n; };    // slab row slot -> original ker
 // 32-bit element offsets from the member's base pointers (build_wtable guarantees M * C < 2^31) and the 8 rows a thread
 // gathers are a constant stride apart; the three shifted copies of x are written unconditionally (the two writes that
 // fall outside the tile land in dummy columns).
+template <bool BF16>
 __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                           const int Cout, const int kD, const int kH, const int flags,
                                                           const int chunks_per_split, const LiveRows live,
                                                           float* __restrict__ bias_slab) {
-    __shared__ float As[64 * W3_AP];          // gy^T tile [co][m]
-    __shared__ float Bs[3 * 64 * W3_XP];      // three shifted + masked copies of the x tile: [dx][ci][1 + m]
+    // fp32: As[co][m] (pitch 33), Bs[dx][ci][1 + m] (pitch 35, columns -1 and 32 are dummies)
+    // bf16-compute mode (BF16): the same tiles rounded to bf16 when written, [row][voxel] with voxel contiguous (= the K of
+    //   v_mfma_f32_32x32x16_bf16), pitch 40: columns 32 / 33 of the padding take the two out-of-tile writes
+    constexpr int LDS_A = BF16 ? 64 * B16_KP * 2 : 64 * W3_AP * 4;
+    constexpr int LDS_B = BF16 ? 3 * 64 * B16_KP * 2 : 3 * 64 * W3_XP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_A + LDS_B];
+    float* const As = reinterpret_cast<float*>(lds_raw);
+    float* const Bs = reinterpret_cast<float*>(lds_raw + LDS_A);
+    __bf16* const Ah = reinterpret_cast<__bf16*>(lds_raw);
+    __bf16* const Bh = reinterpret_cast<__bf16*>(lds_raw + LDS_A);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wco = wave & 1, wci = wave >> 1;
@@ -2540,6 +2549,28 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
 #pragma unroll
                 for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
             }
+            if constexpr (BF16) {
+                const int c_m1 = ml + 1, c_p1 = ml >= 1 ? ml - 1 : 33;       // (columns 32 / 33: padding)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int row = rl + p * 8;
+                    float a = ra[p], v = fmaxf(rb[p], relu_floor);
+                    if (!full) {
+                        a = (co0 + row < Cout) ? a : 0.f;
+                        v = (ci0 + row < Cin) ? v : 0.f;
+                    }
+                    Ah[row * B16_KP + ml] = (__bf16)a;
+                    Bh[(0 * 64 + row) * B16_KP + c_m1] = (__bf16)(v0 ? v : 0.f);
+                    Bh[(1 * 64 + row) * B16_KP + ml] = (__bf16)(v1 ? v : 0.f);
+                    Bh[(2 * 64 + row) * B16_KP + c_p1] = (__bf16)(v2 ? v : 0.f);
+                }
+                if (tid < 128) {
+                    const int row = tid >> 1, side = tid & 1;
+                    float v = (ci0 + row < Cin) ? fmaxf(rh, relu_floor) : 0.f;
+                    if (side) Bh[(2 * 64 + row) * B16_KP + WG_BK - 1] = (__bf16)(((pm2 >> 31) & 1u) ? v : 0.f);
+                    else Bh[(0 * 64 + row) * B16_KP + 0] = (__bf16)((pm0 & 1u) ? v : 0.f);
+                }
+            } else {
             float* pa = &As[rl * W3_AP + ml];
             float* pb = &Bs[rl * W3_XP + 1 + ml];
 #pragma unroll
@@ -2561,9 +2592,23 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
                 if (side) Bs[(2 * 64 + row) * W3_XP + 1 + WG_BK - 1] = ((pm2 >> 31) & 1u) ? v : 0.f;
                 else Bs[(0 * 64 + row) * W3_XP + 1 + 0] = (pm0 & 1u) ? v : 0.f;
             }
+            }
         }
         __syncthreads();
         if (q + 1 < q1) load_chunk(q + 1);
+        if constexpr (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < WG_BK / 16; ++ks) {      // K = 16 voxels per bf16 MFMA: lane (row l31, half hi) reads 8 of them
+                const int kc = ks * 16 + 8 * hi;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ah + (wco * 32 + l31) * B16_KP + kc);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bh + (0 * 64 + wci * 32 + l31) * B16_KP + kc);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bh + (1 * 64 + wci * 32 + l31) * B16_KP + kc);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bh + (2 * 64 + wci * 32 + l31) * B16_KP + kc);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc2, 0, 0, 0);
+            }
+        } else {
         const float* qa = &As[(wco * 32 + l31) * W3_AP + hi];
         const float* qb = &Bs[(wci * 32 + l31) * W3_XP + 1 + hi];
 #pragma unroll
@@ -2576,179 +2621,6 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc2, 0, 0, 0);
         }
-        __syncthreads();
-    }
-    if (do_bias) {                            // lanes ml = 0..31 of a half-wave hold the same 8 output channels
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            float v = bsum[p];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            const int co = co0 + rl + p * 8;
-            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
-        }
-    }
-    // slab[((split*nslots + rslot*3 + dx+1)*Cout + co)*Cin + ci]
-    const int ci = ci0 + wci * 32 + l31;
-    if (ci < Cin) {
-        const size_t CoCi = (size_t)Cout * Cin;
-        float* ps = slab + ((size_t)split * (live.n * 3) + (size_t)rslot * 3) * CoCi + ci;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (co < Cout) {
-                ps[(size_t)co * Cin] = acc0[r];
-                ps[CoCi + (size_t)co * Cin] = acc1[r];
-                ps[2 * CoCi + (size_t)co * Cin] = acc2[r];
-            }
-        }
-    }
-}
-
-// bf16-compute variant of conv_wgrad3_kernel (opt-in mode): same gathers, masks, slab and bias side-sum; the tiles are
-// rounded to bf16 when they are written to LDS ([row][voxel], voxel contiguous = the K of v_mfma_f32_32x32x16_bf16).
-__global__ __launch_bounds__(256) void conv_wgrad3_bf16_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
-                                                          const int Cout, const int kD, const int kH, const int flags,
-                                                          const int chunks_per_split, const LiveRows live,
-                                                          float* __restrict__ bias_slab) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[64 * B16_KP];        // gy^T tile [co][m], m contiguous
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[3 * 64 * B16_KP];    // three shifted + masked copies of the x tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wco = wave & 1, wci = wave >> 1;
-    const int nco_t = (Cout + 63) / 64;
-    const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
-    const int lin = xcd_remap((int)(blockIdx.y + blockIdx.z * gridDim.y), (int)(gridDim.y * gridDim.z));
-    const int rslot = lin % (int)gridDim.y;
-    const int split = lin / (int)gridDim.y;
-    const int krow = live.r[rslot];
-    const int dz = krow / kH - kD / 2, dy = krow % kH - kH / 2;
-    const bool relu_in = flags & T2V_CONV_RELU_IN;
-    const int ml = tid & 31, rl = tid >> 5;
-
-    f32x16 acc0, acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
-
-    const int nchunks = tab.chunk_start[tab.n];
-    const int q0 = split * chunks_per_split;
-    int q1 = q0 + chunks_per_split;
-    if (q1 > nchunks) q1 = nchunks;
-
-    float ra[8], rb[8], rh = 0.f;
-    uint32_t pm0 = 0, pm1 = 0, pm2 = 0;       // pending chunk: validity of (voxel, dx) as 32-bit masks
-    int pend_DHW = 1;
-    // bias gradient on the side: the workgroups of the first channel tile and first kernel row also add up the dL/dy
-    // values they stage anyway (bias_slab[split][co], summed over the splits by one workgroup of the reduce kernel)
-    const bool do_bias = bias_slab != nullptr && ci0 == 0 && rslot == 0;
-    bool pend_mv = false;
-    float bsum[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
-#ifdef T2V_ABLATION
-    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
-#endif
-    auto load_chunk = [&](int q) {
-#ifdef T2V_ABLATION
-        if (dbg_noload && q != q0) return;
-#endif
-        int gi = 0;
-#pragma unroll
-        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
-            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
-        const t2v_conv_group& gd = tab.g[gi];
-        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
-        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
-        const bool mv = m < M;
-        bool vc = false;
-        int w_ = 0;
-        size_t gbase = 0;
-        ptrdiff_t xb = 0;              // element index of x[n, 0, voxel + (dz,dy,0)] (0 when not loadable)
-        if (mv) {
-            const bool small = M < (1 << 24);
-            const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
-            const int sp = m - n * DHW;
-            const int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
-            const int r = sp - d * HW;
-            const int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
-            w_ = r - h * W;
-            gbase = (size_t)n * Cout * DHW + sp;
-            vc = (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H;
-            xb = vc ? (ptrdiff_t)((size_t)n * Cin * DHW + sp) + (ptrdiff_t)(dz * HW + dy * W) : 0;
-        }
-        // wave-uniform validity masks (every wave sees the same 32 voxels in lanes 0-31)
-        pm0 = (uint32_t)__ballot(vc && w_ >= 1);
-        pm1 = (uint32_t)__ballot(vc);
-        pm2 = (uint32_t)__ballot(vc && w_ + 1 < W);
-        pend_DHW = DHW;
-        pend_mv = mv;
-        const float* __restrict__ gy = gd.y;
-        const float* __restrict__ x = gd.x;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {           // unconditional loads from clamped addresses
-            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
-            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
-            rb[p] = x[xb + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
-        }
-        // the two extra strip columns: linear neighbours of voxel 0 (left) and voxel 31 (right) of the chunk
-        const ptrdiff_t xb_l = __shfl(xb, 0, 64), xb_r = __shfl(xb, 31, 64);
-        const bool use_l = (pm0 & 1u) != 0, use_r = (pm2 >> 31) != 0;
-        if (tid < 128) {
-            const int row = tid >> 1, side = tid & 1;
-            const int ci = ci0 + row;
-            const ptrdiff_t base = side ? (use_r ? xb_r + 1 : 0) : (use_l ? xb_l - 1 : 0);
-            rh = x[base + (ptrdiff_t)(ci < Cin ? ci : Cin - 1) * DHW];
-        }
-    };
-
-    // Staging writes THREE shifted + masked copies of the x strip (dx = -1, 0, +1), so the MFMA loop is four plain
-    // LDS reads per three MFMAs with no per-step mask arithmetic on the vector ALU.
-    const bool m_c = true;
-    (void)m_c;
-    if (q0 < q1) load_chunk(q0);
-    for (int q = q0; q < q1; ++q) {
-#ifdef T2V_ABLATION
-        if (!(dbg_nostage && q != q0))
-#endif
-        {
-            const bool v0 = ml + 1 < WG_BK && ((pm0 >> (ml + 1)) & 1u);   // my voxel is the LEFT neighbour of voxel ml+1
-            const bool v1 = (pm1 >> ml) & 1u;
-            const bool v2 = ml >= 1 && ((pm2 >> (ml - 1)) & 1u);          // ... the RIGHT neighbour of voxel ml-1
-            if (do_bias) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int row = rl + p * 8;
-                const int co = co0 + row, ci = ci0 + row;
-                As[row * B16_KP + ml] = (__bf16)((co < Cout) ? ra[p] : 0.f);
-                float v = (ci < Cin) ? rb[p] : 0.f;
-                v = relu_in ? fmaxf(v, 0.f) : v;
-                Bs[(1 * 64 + row) * B16_KP + ml] = (__bf16)(v1 ? v : 0.f);
-                if (ml + 1 < WG_BK) Bs[(0 * 64 + row) * B16_KP + ml + 1] = (__bf16)(v0 ? v : 0.f);
-                if (ml >= 1) Bs[(2 * 64 + row) * B16_KP + ml - 1] = (__bf16)(v2 ? v : 0.f);
-            }
-            if (tid < 128) {
-                const int row = tid >> 1, side = tid & 1;
-                float v = (ci0 + row < Cin) ? rh : 0.f;
-                v = relu_in ? fmaxf(v, 0.f) : v;
-                if (side) Bs[(2 * 64 + row) * B16_KP + WG_BK - 1] = (__bf16)(((pm2 >> 31) & 1u) ? v : 0.f);
-                else Bs[(0 * 64 + row) * B16_KP + 0] = (__bf16)((pm0 & 1u) ? v : 0.f);
-            }
-        }
-        __syncthreads();
-        if (q + 1 < q1) load_chunk(q + 1);
-#pragma unroll
-        for (int ks = 0; ks < WG_BK / 16; ++ks) {          // K = 16 voxels per bf16 MFMA: lane (row l31, half hi) reads 8 of them
-            const int kc = ks * 16 + 8 * hi;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wco * 32 + l31) * B16_KP + kc);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + (0 * 64 + wci * 32 + l31) * B16_KP + kc);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs + (1 * 64 + wci * 32 + l31) * B16_KP + kc);
-            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bs + (2 * 64 + wci * 32 + l31) * B16_KP + kc);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, acc2, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -2778,6 +2650,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_bf16_kernel(const WGroupTable
         }
     }
 }
+
 
 // one workgroup's share of  dbias[co] = (accum ? dbias[co] : 0) + sum_s bias_slab[s][co]  (fixed order); called by ONE
 // workgroup of the weight-gradient reduce kernels so that the bias needs no launch of its own
@@ -3041,10 +2914,10 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
         if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
             if (flags & T2V_CONV_BF16)
-                T2V_LAUNCH_PROF(conv_wgrad3_bf16_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
+                T2V_LAUNCH_PROF(conv_wgrad3_kernel<true>, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
                                 dbias ? bias_part : (float*)nullptr);
             else
-                T2V_LAUNCH_PROF(conv_wgrad3_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
+                T2V_LAUNCH_PROF(conv_wgrad3_kernel<false>, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
                                 dbias ? bias_part : (float*)nullptr);
         } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
