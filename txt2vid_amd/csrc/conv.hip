@@ -970,6 +970,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
         }
     };
 
+    if (tid < BKT) As[tid * AP + BM + 3] = 0.f;          // the zero column (staging never writes past column BM + 1)
     if (q0 < q1) load_round(q0);
     for (int q = q0; q < q1; ++q) {
         stage();
@@ -980,11 +981,15 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
         for (int d = 0; d < 3; ++d) {
             if (d < ndx) {
                 const int dx = ndx == 3 ? d - 1 : 0;
-                const float* as = As + 1 + dx + wm * WM + l31;
                 const float* bs = Bs + d * (BKT * BN) + wco * WCO + l31;
-                bool keep[NM];
+                // a lane whose voxel sits at a row end reads this tap from the all-zero column instead of masking every
+                // operand (one address select per tap instead of one v_cndmask per MFMA)
+                const float* as[NM];
 #pragma unroll
-                for (int j = 0; j < NM; ++j) keep[j] = dx < 0 ? can_l[j] : (dx > 0 ? can_r[j] : true);
+                for (int j = 0; j < NM; ++j) {
+                    const bool keep = dx < 0 ? can_l[j] : (dx > 0 ? can_r[j] : true);
+                    as[j] = keep ? As + 1 + dx + wm * WM + j * 32 + l31 : As + (BM + 3);
+                }
 #pragma unroll
                 for (int k2 = 0; k2 < BKT / 2; ++k2) {
                     const int krow = k2 * 2 + hi;
@@ -992,10 +997,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
 #pragma unroll
                     for (int i = 0; i < NCO; ++i) a[i] = bs[krow * BN + i * 32];
 #pragma unroll
-                    for (int j = 0; j < NM; ++j) {
-                        const float v = as[krow * AP + j * 32];
-                        b[j] = keep[j] ? v : 0.f;
-                    }
+                    for (int j = 0; j < NM; ++j) b[j] = as[j][krow * AP];
 #pragma unroll
                     for (int i = 0; i < NCO; ++i)
 #pragma unroll
