@@ -497,6 +497,50 @@ def text_encode(P, tokens, lengths, prefix='encoder.', hidden=256, layers=4):
     return torch.cat((hn[-1, 0], hn[-1, 1]), dim=1)
 
 
+def text_encode_grad(P, tokens, lengths, prefix='encoder.', hidden=256, layers=4):
+    """The same sentence code with the LSTM run on the tensors of `P` themselves (`torch._VF.lstm` on the packed batch, what
+    `nn.LSTM.forward` calls), so that gradients reach them: the `--end2end` path (train/gan.py:82-85), where the encoder trains
+    with the GAN. Forward values are identical to `text_encode`."""
+    from torch.nn.utils.rnn import pack_padded_sequence
+    flat = []
+    for l in range(layers):
+        for suf in ('', '_reverse'):
+            flat += [P[prefix + 'lstm.%s_l%d%s' % (n, l, suf)] for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    e = F.embedding(tokens, P[prefix + 'embed.weight'])
+    packed = pack_padded_sequence(e, [int(l) for l in lengths], batch_first=True)
+    B = int(packed.batch_sizes[0])
+    zeros = torch.zeros(layers * 2, B, hidden // 2)
+    _, hn, _ = torch._VF.lstm(packed.data, packed.batch_sizes, (zeros, zeros), flat, True, layers, 0.0, True, True)
+    hn = hn.view(layers, 2, -1, hidden // 2)
+    return torch.cat((hn[-1, 0], hn[-1, 1]), dim=1)
+
+
+class AdamOnData(object):
+    """torch.optim.Adam's arithmetic (single-tensor path, no weight decay / amsgrad) applied through `p.data`: the update does
+    not bump the parameters' autograd version counters. That is how the optimiser of the reference's pinned torch 0.4.1 behaved,
+    and it is what lets `--end2end` run there: `optD.step()` rewrites the text encoder's weights between the two backward
+    passes through ONE encoder graph (trainer.py:240 `retain_graph=... or end2end`), which torch >= 1.x rejects ("modified by an
+    inplace operation") when the optimiser updates the parameters themselves."""
+
+    def __init__(self, params, lr, betas, eps=1e-8):
+        self.params, self.lr, self.betas, self.eps = list(params), lr, betas, eps
+        self.state = {}
+
+    def step(self):
+        b1, b2 = self.betas
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.setdefault(id(p), {'step': 0, 'm': torch.zeros_like(p.data), 'v': torch.zeros_like(p.data)})
+            st['step'] += 1
+            g = p.grad.data
+            st['m'].lerp_(g, 1 - b1)
+            st['v'].mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** st['step'], 1 - b2 ** st['step']
+            denom = (st['v'].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            p.data.addcdiv_(st['m'], denom, value=-self.lr / bc1)
+
+
 # --------------------------------------------------------------------------------------------
 # the training iteration — txt2vid/gan/trainer.py:190-267
 # --------------------------------------------------------------------------------------------
@@ -540,7 +584,10 @@ class OracleTrainer(object):
     """
 
     def __init__(self, PG, PD, d_prefix='single_discrim.', lr=2e-4, betas=(0.5, 0.999),
-                 frame_sizes=(8, 16, 32, 64), gp_lambda=0.5, cond_encoder=None):
+                 frame_sizes=(8, 16, 32, 64), gp_lambda=0.5, cond_encoder=None, end2end_txt=None):
+        """`end2end_txt`: the text encoder's state dict — the `--end2end` mode (train/gan.py:82-85, trainer.py:211-263): its
+        parameters join BOTH optimisers, the sentence code keeps its graph, the D backward retains it and the G backward runs
+        through it again after `optD.step()` has moved the encoder (see `AdamOnData`)."""
         self.PG, self.PD, self.d_prefix = PG, PD, d_prefix
         self.frame_sizes, self.gp_lambda = list(frame_sizes), gp_lambda
         self.cond_encoder = cond_encoder
@@ -550,8 +597,41 @@ class OracleTrainer(object):
             PG[k].requires_grad_(True)
         for k in self.d_params:
             PD[k].requires_grad_(True)
-        self.optG = torch.optim.Adam([PG[k] for k in self.g_params], lr=lr, betas=betas)
-        self.optD = torch.optim.Adam([PD[k] for k in self.d_params], lr=lr, betas=betas)
+        self.PT = end2end_txt
+        if end2end_txt is None:
+            self.optG = torch.optim.Adam([PG[k] for k in self.g_params], lr=lr, betas=betas)
+            self.optD = torch.optim.Adam([PD[k] for k in self.d_params], lr=lr, betas=betas)
+        else:
+            self.t_params = [k for k, v in end2end_txt.items() if 'to_vocab' not in k]        # (the decoder head gets no gradient)
+            for k in self.t_params:
+                end2end_txt[k].requires_grad_(True)
+            txt = [end2end_txt[k] for k in self.t_params]
+            self.optG = AdamOnData([PG[k] for k in self.g_params] + txt, lr, betas)
+            self.optD = AdamOnData([PD[k] for k in self.d_params] + txt, lr, betas)
+
+    def step_end2end(self, x, tokens, lengths, z=None, latent=256):
+        """One `--end2end` iteration (trainer.py:211-263). Returns (lossD, lossG)."""
+        cond = text_encode_grad(self.PT, tokens, lengths)                      # NOT detached (trainer.py:213-214)
+        B = x.size(0)
+        xs, conds, _ = multiscale_data(x, cond, self.frame_sizes)
+        if z is None:
+            z = torch.randn(B, latent)
+        fake = multiscale_gen(self.PG, z, conds[0], training=True)
+        self.zero(self.PD, self.d_params)                                       # discrim_step zeroes D and the encoder
+        self.zero(self.PT, self.t_params)
+        fc0 = conds[0][gen_perm(conds[0].size(0))]
+        fake_conds = [fc0[0:c.size(0)] for c in conds]
+        lD = discrim_loss(self.PD, self.d_prefix, xs, [f.detach() for f in fake], conds, fake_conds, self.gp_lambda)
+        lD.backward(retain_graph=True)                                          # trainer.py:240
+        self.optD.step()                                                        # moves D AND the text encoder
+        gen_perm(conds[0].size(0))                                              # all_discrim_forward draws a perm it never uses
+        real_pred = multiscale_discrim(self.PD, xs, conds, self.d_prefix)       # graph kept: the encoder is reached through it
+        self.zero(self.PG, self.g_params)                                       # gen_step zeroes G and the encoder
+        self.zero(self.PT, self.t_params)
+        lG = gen_loss(self.PD, self.d_prefix, fake, real_pred, conds)
+        lG.backward()
+        self.optG.step()
+        return float(lD.detach()), float(lG.detach())
 
     def zero(self, P, keys):
         for k in keys:

@@ -119,3 +119,16 @@ def test_cli_resumes_from_checkpoints_written_by_the_real_reference(tmp_path):
     m = re.search(r'Iter 4, Loss_D: ([-0-9.naninf]+) Loss_G: ([-0-9.naninf]+)', log)
     assert m and all(abs(float(v)) < 1e3 for v in m.groups()), log[-1500:]
     assert 'HIP-graph replay' in log
+
+
+def test_cond_cli_end2end(tmp_path):
+    """`--end2end` through the CLI (train/gan.py:82-85): the text encoder in both optimisers, eager launches (the encoder graph spans
+    the D and the G step), three iterations without a version-counter error and with finite losses."""
+    import re
+    out_dir, smp = str(tmp_path / 'out'), str(tmp_path / 'samples')
+    log = run(COMMON + ['--G', 'txt2vid.models.tganv2_cond.gen.MultiScaleGen', '--D', 'txt2vid.models.tganv2_cond.discrim.MultiScaleDiscrim',
+                        '--sent', 'txt2vid.models.txt.basic.Seq2Seq', '--end2end', '--batch_size', '8', '--epochs', '1', '--out', out_dir,
+                        '--out_samples', smp, '--max_iters', '3', '--save_model_period', '1000', '--save_example_period', '0'], tmp_path)
+    m = re.search(r'Iter 3, Loss_D: ([-0-9.naninf]+) Loss_G: ([-0-9.naninf]+)', log)
+    assert m and all(abs(float(v)) < 1e3 for v in m.groups()), log[-1500:]
+    assert 'HIP-graph replay' not in log

@@ -795,6 +795,66 @@ def test_cond_iteration_bf16_and_fp32_vs_oracle(size, channels, batch, frame_siz
         torch.cuda.empty_cache()
 
 
+def test_end2end_iteration_vs_oracle():
+    """`--end2end` (train/gan.py:82-85, trainer.py:211-263): the text encoder's parameters sit in BOTH optimisers, the sentence
+    code keeps its graph through the D step (retain_graph) and the G backward runs through that graph again AFTER optD.step() has
+    moved the encoder — the sequence the reference's pinned torch 0.4.1 executes (its optimiser writes through `.data`: no version
+    bump) and stock torch >= 1.x rejects. Here Adam is a kernel writing through raw pointers, so it runs; the oracle's extension
+    (`OracleTrainer(end2end_txt=...)`, `AdamOnData`) states the same semantics on the CPU. No fixture from the reference can
+    exist for this path on torch 2.x: parity for this row is HIP vs oracle only (unpinned). One iteration: both losses, the
+    encoder's gradient norms left by the G step, and the encoder's parameters after both updates."""
+    from txt2vid_amd.gan.trainer import train_iteration
+    from txt2vid_amd.optim import Adam
+    V, B = 21, 4
+    gan, _, _, losses, prm = _make_cond(V)
+    txt = gan.cond_encoder.differentiable(True)
+    dis, gen = gan.discrims[0], gan.gen
+    optD = Adam([{'params': dis.parameters()}, {'params': txt.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    optG = Adam([{'params': gen.parameters()}, {'params': txt.parameters()}], lr=2e-4, betas=(0.5, 0.999))
+    PT = O.recipe_state(O.text_encoder_shapes(V))
+    before = {k: v.detach().clone() for k, v in PT.items()}
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1, cond_dim=256, cond_variant=True)),
+                         O.recipe_state(O.resnet3d_shapes('single_discrim.module.', 1, 64, 256)),
+                         d_prefix='single_discrim.module.', end2end_txt=PT)
+    tg = torch.Generator()
+    tg.manual_seed(5)
+    tokens = torch.randint(4, V, (B, 8), generator=tg)
+    tokens[:, 0], tokens[:, -1] = 1, 2
+    lengths = [8, 8, 6, 5]
+    for b_, n in enumerate(lengths):
+        tokens[b_, n:] = 0
+        tokens[b_, n - 1] = 2
+    random.seed(31)
+    np.random.seed(31)
+    torch.manual_seed(31)
+    x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+    state = (torch.get_rng_state(), np.random.get_state(), random.getstate())
+    _, _, cond = txt.encode(tokens.to(DEV), lengths)                 # keeps its graph (trainer.py:213-214)
+    assert cond.requires_grad
+    lD, lG, _, _ = train_iteration(gan, x.to(DEV), cond, optD, optG, losses, prm, DEV, end2end=True)
+    lD, lG = float(lD), float(lG)
+    torch.set_rng_state(state[0])
+    np.random.set_state(state[1])
+    random.setstate(state[2])
+    lDo, lGo = tr.step_end2end(x, tokens, lengths)
+    print('end2end: HIP lossD %.6f lossG %.6f | oracle %.6f %.6f' % (lD, lG, lDo, lGo))
+    assert abs(lD - lDo) < 1e-3 and abs(lG - lGo) < 1e-3
+    named = dict(txt.encoder.named_parameters())
+    ref_max = max(float(PT[k].grad.norm()) for k in tr.t_params)
+    worst = 0.0
+    for k in tr.t_params:                                            # gradients the G step left on the encoder
+        got, want = float(named[k[len('encoder.'):]].grad.norm()), float(PT[k].grad.norm())
+        assert abs(got - want) <= 1e-2 * want + 1e-5 * ref_max, (k, got, want)
+        worst = max(worst, abs(got - want) / (want + 1e-5 * ref_max))
+    # parameters after optD.step() and optG.step(): early Adam updates are ~ lr * sign(g), compare the applied deltas
+    for k in ('encoder.embed.weight', 'encoder.lstm.weight_hh_l0', 'encoder.lstm.weight_ih_l3_reverse', 'encoder.lstm.bias_ih_l2'):
+        d_o = PT[k].detach() - before[k]
+        d_p = named[k[len('encoder.'):]].detach().cpu() - before[k]
+        rel = float((d_p - d_o).abs().mean() / d_o.abs().mean().clamp_min(1e-12))
+        assert float(d_o.abs().max()) > 0 and rel < 0.05, (k, rel)
+    print('end2end: worst relative encoder gradient-norm deviation %.2e' % worst)
+
+
 def test_graphed_sentence_encoder_matches_eager():
     """`GraphedSentenceEncoder`: first batch of a length eager, second captured, third replayed — all equal to the plain
     forward for ragged batches of two different longest lengths (the per-sample lengths live on the device)."""

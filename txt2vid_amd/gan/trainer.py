@@ -73,7 +73,8 @@ def multiscale_data(x, cond, frame_sizes, subsample_input=True):
             st, sb = st * 2, sb * 2
             Bl, Tl = (Bl + 1) // 2, Tl // 2
             if cond is not None:
-                cond = TF.stride_rows(cond, 2)
+                # cond[::2] (trainer.py:160); --end2end keeps the sentence code's graph, so the slice must be differentiable
+                cond = cond[::2] if cond.requires_grad else TF.stride_rows(cond, 2)
     return xs, (conds if conds else None)
 
 

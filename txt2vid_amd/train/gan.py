@@ -72,11 +72,15 @@ def main(args):
     D_params = [{'params': d.parameters()} for d in discrims]
     G_params = [{'params': gen.parameters()}]
     if args.end2end and txt_encoder is not None:
-        raise NotImplementedError(
-            '--end2end is not built: as written it cannot run — the reference puts the text encoder in BOTH optimisers '
-            '(train/gan.py:82-85), so optD.step() rewrites the LSTM weights in place between the two backward passes '
-            'through one encoder graph (trainer.py:240 retain_graph) and autograd rejects the generator backward '
-            '("modified by an inplace operation"); see DESIGN.md §7')
+        # train/gan.py:82-85: the text encoder trains with the GAN — its parameters join BOTH optimisers, the sentence code keeps
+        # its graph (trainer.py:213-214), the D backward retains it (trainer.py:240) and the G backward runs through it again after
+        # optD.step() has moved the encoder. That sequence only runs where the optimiser's in-place update does not bump autograd's
+        # version counters: the reference's pinned torch 0.4.1 (updates through `.data`) — and here, where Adam is a kernel
+        # writing through raw pointers. Stock torch >= 1.x raises "modified by an inplace operation" on the G backward.
+        # Eager launches (the encoder graph spans the D and the G step: no graph replay), no gradient sink.
+        D_params.append({'params': txt_encoder.parameters()})
+        G_params.append({'params': txt_encoder.parameters()})
+        txt_encoder.differentiable(True)
     if args.sgd:                                   # train/gan.py:86-89: momentum = beta1
         status('Using SGD')
         optD = SGD(D_params, lr=args.D_lr, momentum=args.D_beta1)
