@@ -24,6 +24,7 @@ torch.manual_seed(0)
 D = cc.d_step_members
 SUITE = [
     # name, Cin, Cout, kernel, members (N, D, H, W)
+    ('D stem conv1 8m', 1, 64, (3, 3, 3), D(32, 0)),
     ('D stem conv2 8m', 64, 64, (3, 3, 3), D(32, 0)),
     ('D stem conv2 gp', 64, 64, (3, 3, 3), cc.gp_members(32, 0)),
     ('D down0 conv1 8m', 64, 64, (3, 3, 3), D(32, 1)),

@@ -2052,42 +2052,74 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
     float bsum[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
-    const bool dbg_noload = flags & 64, dbg_nostage = flags & 128;
-    auto load_chunk = [&](int q) {
-        if (dbg_noload && q != q0) return;
+    // member state cached in scalars + shift decode + buffer loads with scalar row strides: see conv_wgrad3_kernel (this kernel
+    // runs only 16 MFMAs per wave and chunk, so the ~400 vector instructions of the old per-chunk decode set its pace)
+    const bool full = co0 + 64 <= Cout && ci0 + 64 <= Cin;
+    int g_i = -1, g_begin = 0, g_end = 0;
+    int gD = 1, gH = 1, gW = 1, gHW = 1, gDHW = 1, gM = 0, g_lw = 0, g_lhw = 0, g_shift = 0;
+    bool g_pow2 = false, g_live = false;
+    __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_y = g_x;
+    auto enter_group = [&](int q) {
         int gi = 0;
 #pragma unroll
         for (int k = 1; k < T2V_MAX_GROUPS; ++k)
             if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
         const t2v_conv_group& gd = tab.g[gi];
-        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
+        g_i = gi;
+        g_begin = tab.chunk_start[gi];
+        g_end = tab.chunk_start[gi + 1];
+        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW; gM = gd.N * gDHW;
+        g_pow2 = ((gD & (gD - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
+        g_lw = __builtin_ctz(gW);
+        g_lhw = g_lw + __builtin_ctz(gH);
+        g_shift = dz * gHW + dy * gW + dx;
         // a dim of extent 1 keeps its centre tap only (same rule as the forward)
-        const bool tap_live = !((D == 1 && dz) || (H == 1 && dy) || (W == 1 && dx));
-        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
-        const bool mv = tap_live && m < M;
-        bool xv = false;
-        size_t gbase = 0, xb = 0;      // clamped: voxel 0 of sample 0 when this lane has nothing to load
-        if (mv) {
-            const bool small = M < (1 << 24);
-            int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
-            int sp = m - n * DHW;
-            int d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
-            int r = sp - d * HW;
-            int h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
-            int w_ = r - h * W;
-            gbase = (size_t)n * Cout * DHW + sp;
-            int dd = d + dz, hh = h + dy, ww = w_ + dx;
-            xv = (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            xb = (size_t)n * Cin * DHW + sp + (xv ? (ptrdiff_t)(dz * HW + dy * W + dx) : 0);
+        g_live = !((gD == 1 && dz) || (gH == 1 && dy) || (gW == 1 && dx));
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)gM * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
+        g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
+    };
+    auto load_chunk = [&](int q) {
+        if (q >= g_end || g_i < 0) enter_group(q);
+        const int D = gD, H = gH, W = gW, HW = gHW, DHW = gDHW;
+        const int m = (q - g_begin) * WG_BK + ml;
+        const bool mv = g_live && m < gM;
+        int sp, d, h, w_;
+        if (g_pow2) {
+            sp = m & (DHW - 1);
+            d = sp >> g_lhw;
+            h = (sp >> g_lw) & (H - 1);
+            w_ = sp & (W - 1);
+        } else {
+            const bool small = gM < (1 << 24);
+            const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+            sp = m - n * DHW;
+            d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+            const int r = sp - d * HW;
+            h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+            w_ = r - h * W;
         }
-        const float* __restrict__ gy = gd.y;
-        const float* __restrict__ x = gd.x;
-        // unconditional loads from clamped addresses, masked afterwards (no branch + wait per element)
+        const bool xv = mv && (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H && (unsigned)(w_ + dx) < (unsigned)W;
+        const uint32_t gbase = mv ? (uint32_t)(m - sp) * (uint32_t)Cout + (uint32_t)sp : 0u;       // clamped: voxel 0 of sample 0
+        const uint32_t xb = mv ? (uint32_t)(m - sp) * (uint32_t)Cin + (uint32_t)(sp + (xv ? g_shift : 0)) : 0u;
+        const uint32_t uDHW = (uint32_t)DHW;
+        if (full) {
+            const uint32_t oa = (gbase + (uint32_t)(co0 + rl) * uDHW) * 4u, ob = (xb + (uint32_t)(ci0 + rl) * uDHW) * 4u;
+            const int st = 32 * DHW;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
-            ra[p] = gy[gbase + (size_t)(co < Cout ? co : Cout - 1) * DHW];
-            rb[p] = x[xb + (size_t)(ci < Cin ? ci : Cin - 1) * DHW];
+            for (int p = 0; p < 8; ++p) {
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, oa, p * st, 0));
+                rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, ob, p * st, 0));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uDHW) * 4u, 0, 0));
+                rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    g_x, (xb + (uint32_t)(ci < Cin ? ci : Cin - 1) * uDHW) * 4u, 0, 0));
+            }
         }
         pend_v = xv;
         pend_mv = mv;
@@ -2099,7 +2131,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGroupTable tab, 
 #pragma unroll
             for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
         }
-        if (!(dbg_nostage && q != q0))
 #pragma unroll
         for (int p = 0; p < 8; ++p) {          // masking + fused ReLU at the LDS write, one chunk after the loads
             const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
@@ -2315,36 +2346,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
     float ra[8], rb[8];
     bool pend_m = false;
     uint32_t pend_x = 0;
-    auto load_chunk = [&](int q) {
+    // member state cached in scalars + shift decode + buffer loads (see conv_wgrad3_kernel)
+    int g_i = -1, g_begin = 0, g_end = 0;
+    int gD = 1, gH = 1, gW = 1, gHW = 1, gDHW = 1, gM = 0, g_lw = 0, g_lhw = 0;
+    bool g_pow2 = false;
+    int c_off[8];                      // per column: x offset of its tap inside the member, -1 << 30 when the tap is dead there
+    __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_y = g_x;
+    bool c_live[8];
+    auto enter_group = [&](int q) {
         int gi = 0;
 #pragma unroll
         for (int k = 1; k < T2V_MAX_GROUPS; ++k)
             if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
         const t2v_conv_group& gd = tab.g[gi];
-        const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
-        const int m = (q - tab.chunk_start[gi]) * WG_BK + ml;
-        const bool mv = m < M;
-        int n = 0, sp = 0, d = 0, h = 0, w_ = 0;
-        if (mv) {
-            const bool small = M < (1 << 24);
-            n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
+        g_i = gi;
+        g_begin = tab.chunk_start[gi];
+        g_end = tab.chunk_start[gi + 1];
+        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW; gM = gd.N * gDHW;
+        g_pow2 = ((gD & (gD - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
+        g_lw = __builtin_ctz(gW);
+        g_lhw = g_lw + __builtin_ctz(gH);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            c_live[p] = c_ok[p] && !((gD == 1 && c_dz[p]) || (gH == 1 && c_dy[p]) || (gW == 1 && c_dx[p]));
+            c_off[p] = c_dz[p] * gHW + c_dy[p] * gW + c_dx[p];
+        }
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)gM * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
+        g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
+    };
+    auto load_chunk = [&](int q) {
+        if (q >= g_end || g_i < 0) enter_group(q);
+        const int D = gD, H = gH, W = gW, HW = gHW, DHW = gDHW;
+        const int m = (q - g_begin) * WG_BK + ml;
+        const bool mv = m < gM;
+        int sp = 0, d = 0, h = 0, w_ = 0;
+        if (g_pow2) {
+            sp = m & (DHW - 1);
+            d = sp >> g_lhw;
+            h = (sp >> g_lw) & (H - 1);
+            w_ = sp & (W - 1);
+        } else {
+            const bool small = gM < (1 << 24);
+            const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
             sp = m - n * DHW;
             d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
             const int r = sp - d * HW;
             h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
             w_ = r - h * W;
         }
-        const float* __restrict__ gy = gd.y + (size_t)n * Cout * DHW + sp;
-        const float* __restrict__ x = gd.x + (size_t)n * Cin * DHW + sp;
+        const uint32_t uDHW = (uint32_t)DHW;
+        const uint32_t gbase = mv ? (uint32_t)(m - sp) * (uint32_t)Cout + (uint32_t)sp : 0u;
+        const uint32_t xb = mv ? (uint32_t)(m - sp) * (uint32_t)Cin + (uint32_t)sp : 0u;
         bool xv[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {          // unconditional loads from clamped addresses
             const int co = co0 + rl + p * 8;
-            ra[p] = gy[(size_t)(co < Cout ? co : Cout - 1) * DHW];
+            ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uDHW) * 4u, 0, 0));
             const int dd = d + c_dz[p], hh = h + c_dy[p], ww = w_ + c_dx[p];
-            const bool live_tap = !((D == 1 && c_dz[p]) || (H == 1 && c_dy[p]) || (W == 1 && c_dx[p]));
-            xv[p] = mv && c_ok[p] && live_tap && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            rb[p] = x[(size_t)c_ci[p] * DHW + (xv[p] ? (ptrdiff_t)(c_dz[p] * HW + c_dy[p] * W + c_dx[p]) : 0)];
+            xv[p] = mv && c_live[p] && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                g_x, (xb + (uint32_t)c_ci[p] * uDHW + (uint32_t)(xv[p] ? c_off[p] : 0)) * 4u, 0, 0));
         }
         pend_m = mv;
         pend_x = 0;
@@ -2756,7 +2819,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
         if (need_ptrs && (!g.x || !g.y)) return false;
         if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1) return false;
         const long M = (long)g.N * g.D * g.H * g.W;
-        if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;
+        if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return false;     // the gathers use 32-bit BYTE offsets (buffer loads)
         if (M * (long)(Cin > Cout ? Cin : Cout) > maxMC) maxMC = M * (long)(Cin > Cout ? Cin : Cout);
         tab.g[i] = g;
         tab.chunk_start[i] = (int32_t)nch;
@@ -2786,7 +2849,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     static const long wg_env = getenv("T2V_WGRAD_TARGET") ? atol(getenv("T2V_WGRAD_TARGET")) : 0;
     static const long s_cap = getenv("T2V_WGRAD_SCAP") ? atol(getenv("T2V_WGRAD_SCAP")) : 256;
     const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : 2048);
-    long S = (wg_target + base - 1) / base;
+    long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
