@@ -27,6 +27,8 @@ SUITE = [
     ('D stem conv1 8m', 1, 64, (3, 3, 3), D(32, 0)),
     ('D stem conv2 8m', 64, 64, (3, 3, 3), D(32, 0)),
     ('D stem conv2 gp', 64, 64, (3, 3, 3), cc.gp_members(32, 0)),
+    ('D stem conv2 Gstep', 64, 64, (3, 3, 3), cc.gp_members(32, 0) + cc.gp_members(32, 0)),
+    ('D stem conv2 N64x4', 64, 64, (3, 3, 3), [(2 * n, d, h, w) for n, d, h, w in cc.gp_members(32, 0)]),
     ('D down0 conv1 8m', 64, 64, (3, 3, 3), D(32, 1)),
     ('D down0 conv2 8m', 64, 128, (3, 3, 3), D(32, 1)),
     ('D down1 conv1 8m', 128, 128, (3, 3, 3), D(32, 2)),
@@ -34,6 +36,12 @@ SUITE = [
     ('D down2 conv1 8m', 256, 256, (3, 3, 3), D(32, 3)),
     ('D down2 conv2 8m', 256, 512, (3, 3, 3), D(32, 3)),
     ('D down3 conv2 8m', 512, 1024, (3, 3, 3), D(32, 4)),
+    ('D down1 conv1 gp', 128, 128, (3, 3, 3), cc.gp_members(32, 2)),
+    ('D down1 conv2 gp', 128, 256, (3, 3, 3), cc.gp_members(32, 2)),
+    ('D down1 conv1 Gs', 128, 128, (3, 3, 3), cc.gp_members(32, 2) * 2),
+    ('D down1 conv2 Gs', 128, 256, (3, 3, 3), cc.gp_members(32, 2) * 2),
+    ('D down2 conv2 gp', 256, 512, (3, 3, 3), cc.gp_members(32, 3)),
+    ('D down3 conv2 gp', 512, 1024, (3, 3, 3), cc.gp_members(32, 4)),
     ('G up2 128x128 8x8', 128, 128, (3, 3), [(512, 1, 8, 8)]),
     ('G up1 256x256 4x4', 256, 256, (3, 3), [(512, 1, 4, 4)]),
     ('G up0 512x512 2x2', 512, 512, (3, 3), [(512, 1, 2, 2)]),

@@ -1685,6 +1685,8 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         while (S > 1 && (double)S * ot * 4.0 > 256e6) --S;   // keep the slab small (L2 / MALL resident)
         if (S < 1) S = 1;
     }
+    static const long force_S = getenv("T2V_FORCE_S") ? atol(getenv("T2V_FORCE_S")) : 0;     // developer knob (tools/conv_suite.py sweeps)
+    if (force_S > 0) S = force_S > min_chunks / 2 ? (min_chunks / 2 > 0 ? min_chunks / 2 : 1) : force_S;
     p.S = (int)S;
     return true;
 }
@@ -1733,6 +1735,39 @@ static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM
     return v;
 }
 
+// Wave quantisation of the 256-voxel tile: the kernel fits 3 workgroups on a CU but runs no faster per CU with 3 than with 2
+// (2 x 255 us = 3 x 382 us per 256 tiles), so a launch of e.g. 1024 tiles (the generator step's D forward, M = 262144) took
+// one round of 768 and a tail of 256 = 692 us where two rounds of 512 take 510. The launcher therefore picks the resident
+// workgroups per CU (2 or 3) that minimises rounds x residents and pads the dynamic LDS request to enforce it.
+struct OccInfo { int occ = 0, lds = 0, cus = 0; };
+template <class K>
+static int occupancy_pad(K kernel, OccInfo& info, long nwg) {
+    if (!info.occ) {
+        hipFuncAttributes a;
+        int dev = 0, n = 0, cus = 0;
+        if (hipFuncGetAttributes(&a, (const void*)kernel) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1 || cus < 1) {
+            (void)hipGetLastError();
+            info.occ = -1;
+        } else {
+            info.occ = n; info.lds = (int)a.sharedSizeBytes; info.cus = cus;
+        }
+    }
+    static const bool off = getenv("T2V_NO_OCC_PAD") != nullptr;
+    if (info.occ < 3 || off) return 0;
+    long best = -1;
+    int pick = info.occ;
+    for (int o = info.occ; o >= 2; --o) {                   // ties go to the higher occupancy
+        const long cost = ((nwg + (long)info.cus * o - 1) / ((long)info.cus * o)) * o;
+        if (best < 0 || cost < best) { best = cost; pick = o; }
+    }
+    if (pick == info.occ) return 0;
+    const int lds_total = 160 * 1024;
+    const int need = lds_total / (pick + 1) + 512;          // more than a (pick+1)-th of the CU's LDS per workgroup
+    return need > info.lds ? need - info.lds : 0;
+}
+
 template <int BM, int BN, int WAVES_CO, int BKT>
 static void launch_conv_t(const GroupTable& tab, const float* wp, const float* bias, float* slab, int Cin, int Cout, int flags,
                           const ConvPlan& p, hipStream_t s) {
@@ -1741,8 +1776,17 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
     if (v.s3) {
         if constexpr (BN == 64 && ((BM != 256 && BKT == 32) || (BM == 256 && BKT == 16))) {
             constexpr int WCO3 = BM == 256 ? 1 : 2;
-            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-            else T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            const long nwg = (long)grid.x * grid.y * grid.z;
+            int pad = 0;
+            if (p.vecb) {
+                static OccInfo oi;
+                if (BM == 256) pad = occupancy_pad(conv_igemm_strip3_kernel<BM, BKT, WCO3, true>, oi, nwg);
+                T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, true>), grid, dim3(256), pad, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            } else {
+                static OccInfo oi;
+                if (BM == 256) pad = occupancy_pad(conv_igemm_strip3_kernel<BM, BKT, WCO3, false>, oi, nwg);
+                T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<BM, BKT, WCO3, false>), grid, dim3(256), pad, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            }
         }
         return;
     }
@@ -2854,6 +2898,11 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     if (S > s_cap) S = s_cap;
+    // wave quantisation: 1024 workgroups are resident at a time; a last round that is under a fifth full (2052 = 2 x 1024 + 4)
+    // costs most of a round for little work: give those workgroups' chunks to the full rounds instead
+    static const bool no_q = getenv("T2V_WGRAD_NOQ") != nullptr;
+    const long rounds = (base * S) / 1024, tail = (base * S) % 1024;
+    if (!no_q && rounds >= 1 && tail > 0 && tail * 5 <= 1024 && (rounds * 1024) / base >= 1) S = (rounds * 1024) / base;
     p.cps = (int)((nch + S - 1) / S);
     p.S = (int)((nch + p.cps - 1) / p.cps);
     return true;
