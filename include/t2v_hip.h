@@ -142,7 +142,8 @@ typedef struct {
     int64_t CoCi;             /* Cout * Cin                                                           */
     int32_t T, Cout, nsrc;
     int32_t accum, accum_bias; /* add to what dw / dbias hold instead of overwriting                  */
-    int32_t kind;             /* 0: one workgroup per 64 (co,ci) pairs; 1: per (64 pairs, tap), for small weights with many splits */
+    int32_t kind;             /* 0: one workgroup per 64 (co,ci) pairs; 1: per (64 pairs, tap), for small weights with many splits;
+                                 2 / 3: the same with 256 pairs per workgroup and 16-byte loads (CoCi % 4 == 0, slabs 16-byte aligned) */
     int32_t block_begin, nblocks;
     int32_t tap_major;        /* dw is stored [T][Cout][Cin] (tap-major master weights); taps no source touches stay untouched */
     int32_t pad_;

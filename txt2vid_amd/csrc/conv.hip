@@ -2791,6 +2791,30 @@ __device__ __forceinline__ float slab_sum4(const float* __restrict__ p, size_t s
     for (; s < S; ++s) v[0] += p[(size_t)s * st];
     return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
+// the same (and in the same order) over four neighbouring pairs: 16-byte loads, 1 KB per wave and plane
+__device__ __forceinline__ float4 slab_sum_v4(const float* __restrict__ p, size_t st, int S) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)(s + u) * st);
+            v[u].x += a.x; v[u].y += a.y; v[u].z += a.z; v[u].w += a.w;
+        }
+    }
+    for (; s < S; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * st);
+        v[0].x += a.x; v[0].y += a.y; v[0].z += a.z; v[0].w += a.w;
+    }
+    float4 r;
+    r.x = ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+    r.y = ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+    r.z = ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+    r.w = ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+    return r;
+}
 struct TapMap { int32_t j[T2V_MAX_TAPS]; };   // original tap t -> slab slot or -1 (never touched: write 0)
 
 // dw[co][ci][t] = sum_s slab[s][j(t)][co][ci] (0 for taps that only ever multiply padding). Reads are
@@ -3094,8 +3118,8 @@ extern "C" int t2v_wgrad_dest_bytes(void) { return (int)sizeof(t2v_wgrad_dest); 
 
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const t2v_wgrad_dest* __restrict__ table, int ndest) {
-    __shared__ float tile[64 * T2V_MAX_TAPS];
-    __shared__ float part[4][64];
+    __shared__ __attribute__((aligned(16))) float tile[256 * T2V_MAX_TAPS];
+    __shared__ __attribute__((aligned(16))) float part[4][256];
     __shared__ int s_dest;
     if (threadIdx.x == 0) {                  // last destination with block_begin <= blockIdx.x
         int lo = 0, hi = ndest - 1;
@@ -3124,7 +3148,86 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const t2v_wgrad
             if (!first) d.dbias[co] = d.accum_bias ? d.dbias[co] + v : v;
         }
     }
-    if (d.kind == 0) {                       // 64 (co,ci) pairs x T taps; the 4 waves take taps t = wave, wave+4, ...
+    if (d.kind == 2) {                       // kind 0 with 16-byte loads: 256 pairs x T taps per workgroup, a lane owns 4 pairs
+        const long i0 = (long)b * 256;
+        const int l4 = (threadIdx.x & 63) * 4, tg = threadIdx.x >> 6;
+        const long i = i0 + l4;
+        for (int t = tg; t < T; t += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool any = false;
+            for (int k = 0; k < nsrc; ++k) {
+                const int j = d.src[k].map[t];
+                float4 vk = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j >= 0 && i < CoCi) vk = slab_sum_v4(d.src[k].slab + (size_t)j * d.src[k].tap_stride + i, (size_t)d.src[k].split_stride, d.src[k].S);
+                any = any || j >= 0;
+                if (k == 0) v = vk; else { v.x += vk.x; v.y += vk.y; v.z += vk.z; v.w += vk.w; }
+            }
+            if (d.tap_major) {
+                if (any && i < CoCi) {
+                    float* q = d.dw + (size_t)t * CoCi + i;
+                    if (d.accum) { v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
+                    q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+                }
+            } else {
+                tile[(l4 + 0) * T + t] = v.x; tile[(l4 + 1) * T + t] = v.y; tile[(l4 + 2) * T + t] = v.z; tile[(l4 + 3) * T + t] = v.w;
+            }
+        }
+        if (d.tap_major) return;
+        __syncthreads();
+        long cnt = CoCi - i0;
+        if (cnt > 256) cnt = 256;
+        const long nval = cnt * T;
+        float* p = d.dw + (size_t)i0 * T;
+        for (long k = threadIdx.x; k < nval; k += 256) p[k] = d.accum ? p[k] + tile[k] : tile[k];
+    } else if (d.kind == 3) {                // kind 1 with 16-byte loads: one workgroup per (256 pairs, tap), the waves split S
+        const int t = b % T;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const long i = (long)(b / T) * 256 + lane * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any = false;
+        for (int k = 0; k < nsrc; ++k) {
+            const int j = d.src[k].map[t];
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j >= 0 && i < CoCi) {            // (same summation order as kind 1 and wgrad_reduce_small_kernel)
+                const float* p = d.src[k].slab + (size_t)j * d.src[k].tap_stride + i;
+                const size_t st = (size_t)d.src[k].split_stride;
+                const int S = d.src[k].S;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                int s = wv;
+#pragma unroll 4
+                for (; s + 4 < S; s += 8) {
+                    const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * st), c = *reinterpret_cast<const float4*>(p + (size_t)(s + 4) * st);
+                    v0.x += a.x; v0.y += a.y; v0.z += a.z; v0.w += a.w;
+                    v1.x += c.x; v1.y += c.y; v1.z += c.z; v1.w += c.w;
+                }
+                if (s < S) {
+                    const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * st);
+                    v0.x += a.x; v0.y += a.y; v0.z += a.z; v0.w += a.w;
+                }
+                vp.x = v0.x + v1.x; vp.y = v0.y + v1.y; vp.z = v0.z + v1.z; vp.w = v0.w + v1.w;
+            }
+            any = any || j >= 0;
+            *reinterpret_cast<float4*>(&part[wv][lane * 4]) = vp;
+            __syncthreads();
+            if (wv == 0) {
+                const float4 p0 = *reinterpret_cast<const float4*>(&part[0][lane * 4]), p1 = *reinterpret_cast<const float4*>(&part[1][lane * 4]);
+                const float4 p2 = *reinterpret_cast<const float4*>(&part[2][lane * 4]), p3 = *reinterpret_cast<const float4*>(&part[3][lane * 4]);
+                float4 vk;
+                vk.x = (p0.x + p1.x) + (p2.x + p3.x); vk.y = (p0.y + p1.y) + (p2.y + p3.y);
+                vk.z = (p0.z + p1.z) + (p2.z + p3.z); vk.w = (p0.w + p1.w) + (p2.w + p3.w);
+                if (k == 0) v = vk; else { v.x += vk.x; v.y += vk.y; v.z += vk.z; v.w += vk.w; }
+            }
+            __syncthreads();
+        }
+        if (wv == 0 && i < CoCi && (any || !d.tap_major)) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* q = d.tap_major ? d.dw + (size_t)t * CoCi + i + e : d.dw + (size_t)(i + e) * T + t;
+                *q = d.accum ? *q + vv[e] : vv[e];
+            }
+        }
+    } else if (d.kind == 0) {                // 64 (co,ci) pairs x T taps; the 4 waves take taps t = wave, wave+4, ...
         const long i0 = (long)b * 64;
         const int il = threadIdx.x & 63, tg = threadIdx.x >> 6;
         const long i = i0 + il;
@@ -3186,7 +3289,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const t2v_wgrad
 }
 
 // `table`: DEVICE array of ndest t2v_wgrad_dest records; total_blocks = sum of nblocks
-// (kind 0: ceil(CoCi / 64) workgroups, kind 1: ceil(CoCi / 64) * T)
+// (kind 0: ceil(CoCi / 64) workgroups, kind 1: ceil(CoCi / 64) * T; kinds 2 / 3: the same with 256 pairs per workgroup and
+// 16-byte slab loads — they need CoCi % 4 == 0 and 16-byte aligned slabs)
 extern "C" int t2v_wgrad_reduce_multi(const void* table, int ndest, int total_blocks, void* stream) {
     if (!table || ndest < 1 || total_blocks < 1) return T2V_EINVAL;
     T2V_LAUNCH(wgrad_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,

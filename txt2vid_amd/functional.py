@@ -87,6 +87,9 @@ def input_grads_only():
         _param_grads_enabled = old
 
 
+_NO_VEC_REDUCE = bool(os.environ.get('T2V_NO_VEC_REDUCE'))       # developer A/B switch: scalar slab loads in the batched reduce
+
+
 class _PendingDest(object):
     __slots__ = ('wid', 'bid', 'dw', 'dbias', 'CoCi', 'T', 'Cout', 'accum', 'accum_bias', 'srcs', 'keep', 'tap_major')
 
@@ -191,9 +194,15 @@ class GradSink(object):
             a.dw, a.dbias, a.CoCi, a.T, a.Cout = d.dw, d.dbias or None, d.CoCi, d.T, d.Cout
             a.nsrc, a.accum, a.accum_bias, a.tap_major = len(d.srcs), d.accum, d.accum_bias, d.tap_major
             smax = max(sr.S for sr in d.srcs)
-            a.kind = 1 if (d.CoCi <= 16384 and smax >= 16) else 0
+            vec = not _NO_VEC_REDUCE and d.CoCi % 4 == 0 and d.CoCi >= 1024 and all(sr.slab % 16 == 0 and sr.tap_stride % 4 == 0 and sr.split_stride % 4 == 0
+                                                             for sr in d.srcs)
+            if vec:                  # 16-byte slab loads, 256 pairs per workgroup; same split between the two forms (and same
+                a.kind = 3 if (d.CoCi <= 16384 and smax >= 16) else 2          # summation order) as the scalar kinds 1 / 0
+                a.nblocks = ((d.CoCi + 255) // 256) * (d.T if a.kind == 3 else 1)
+            else:
+                a.kind = 1 if (d.CoCi <= 16384 and smax >= 16) else 0
+                a.nblocks = ((d.CoCi + 63) // 64) * (d.T if a.kind else 1)
             a.block_begin = blocks
-            a.nblocks = ((d.CoCi + 63) // 64) * (d.T if a.kind else 1)
             blocks += a.nblocks
             for k, sr in enumerate(d.srcs):
                 C.memmove(C.byref(a.src[k]), C.byref(sr), C.sizeof(WgradSrc))
