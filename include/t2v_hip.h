@@ -121,7 +121,7 @@ int t2v_conv_wgrad_grouped(const t2v_conv_group* groups, int ngroups, int Cin, i
 /* Deferred, batched reduction of the weight-gradient partial sums (one reduce launch per backward pass instead of one per
  * layer). t2v_conv_wgrad_grouped_partial = t2v_conv_wgrad_grouped[_bias] without its second (reduce) kernel: the k-split
  * partial sums stay in `slab` (same size query as the full call; `want_bias` != 0 also keeps the dL/dy side-sums behind
- * it — MFMA kernels only, i.e. Cin >= 64) and *out_src describes them. t2v_wgrad_reduce_multi then sums, for every
+ * it) and *out_src describes them. t2v_wgrad_reduce_multi then sums, for every
  * destination of a DEVICE table, its sources in order: dw (+)= sum_src sum_splits slab, dbias likewise.
  * Replaces the per-parameter accumulation autograd does for conv weights (AccumulateGrad of the call sites above). */
 #define T2V_WGRAD_MAX_SRC 6
@@ -166,8 +166,8 @@ int t2v_wgrad_reduce_multi(const void* table /* device t2v_wgrad_dest[ndest] */,
 int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out);
 int t2v_conv_wgrad_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, int32_t* out);
 /* Same, plus the bias gradient dbias[Cout] = sum over all members and voxels of dL/dy (what t2v_channel_sum_grouped
- * computes, layers.py / resnet3d.py conv biases): on the 3-tap-row path the weight-gradient kernel adds up the dL/dy
- * tiles it stages anyway, elsewhere the stand-alone channel sum runs. The slab must hold
+ * computes, layers.py / resnet3d.py conv biases): every weight-gradient kernel adds up the dL/dy tiles it stages anyway
+ * (k-split partial sums behind the slab, summed by the reduce pass). The slab must hold
  * t2v_conv_wgrad_grouped_bias_slab_floats() floats. */
 int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
                                                 int kH, int kW);

@@ -97,7 +97,7 @@ def test_conv_grouped_at_benchmark_size(case):
     (64, 64, (3, 3, 3), [(4, 4, 16, 16), (2, 2, 32, 32)]),          # 3-tap rows, many splits of a small weight (kind 1)
     (128, 256, (3, 3, 3), [(4, 2, 4, 4), (2, 1, 8, 8)]),             # 3-tap rows, one workgroup per 64 pairs (kind 0)
     (64, 96, (1, 1, 1), [(3, 4, 8, 8)]),                             # per-tap kernel
-    (16, 32, (3, 3, 3), [(2, 4, 6, 6)]),                             # Cin < 64: (tap, ci) column tiles, no fused bias
+    (16, 32, (3, 3, 3), [(2, 4, 6, 6)]),                             # Cin < 64: (tap, ci) column tiles, bias side sums in the first column tile
 ])
 def test_deferred_weight_gradient_reduce(cin, cout, k, members):
     """`GradSink` leaves each weight-gradient launch's k-split slab pending and sums all of them in ONE
@@ -231,8 +231,10 @@ def test_relu_conv_grouped_first_and_second_order(shapes):
 @pytest.mark.parametrize('cin,cout,k,shapes', [
     (64, 96, (3, 3, 3), [(2, 64, 4, 8, 8), (1, 64, 2, 16, 16), (3, 64, 1, 4, 4)]),     # 3-tap-row kernel: bias summed on the side
     (64, 64, (1, 3, 3), [(4, 64, 1, 16, 16)]),                                          # 2-D, one member
-    (32, 48, (3, 3, 3), [(2, 32, 4, 8, 8), (2, 32, 2, 4, 4)]),                          # Cin < 64: stand-alone channel sum
+    (32, 48, (3, 3, 3), [(2, 32, 4, 8, 8), (2, 32, 2, 4, 4)]),                          # Cin < 64: (tap, ci) column-tile kernel with its own bias side sums
     (128, 40, (1, 1, 1), [(2, 128, 4, 8, 8), (5, 128, 1, 1, 1)]),                       # 1x1x1 kernel (per-tap kernel, bias on the side)
+    (1, 64, (3, 3, 3), [(2, 1, 4, 8, 8), (3, 1, 2, 16, 16), (2, 1, 1, 5, 3)]),          # the stem's Cin = 1: 27 columns in one tile, ragged member
+    (3, 72, (3, 3, 3), [(2, 3, 4, 8, 8)]),                                              # RGB stem, two output-channel tiles x two column tiles
     (64, 32, (3, 3, 3), [(3, 64, 2, 1, 1), (2, 64, 1, 1, 1)]),                          # 3^3 kernel on W = 1 maps: centre-tap workgroups sum the bias
 ])
 def test_wgrad_with_bias_gradient(cin, cout, k, shapes):

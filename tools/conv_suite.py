@@ -30,6 +30,10 @@ SUITE = [
     ('D stem conv2 Gstep', 64, 64, (3, 3, 3), cc.gp_members(32, 0) + cc.gp_members(32, 0)),
     ('D stem conv2 N64x4', 64, 64, (3, 3, 3), [(2 * n, d, h, w) for n, d, h, w in cc.gp_members(32, 0)]),
     ('D down0 conv1 8m', 64, 64, (3, 3, 3), D(32, 1)),
+    ('X down0c1 1m 16^3', 64, 64, (3, 3, 3), [(12, 16, 16, 16)]),
+    ('X down0c1 1m 2D64', 64, 64, (3, 3), [(12, 1, 64, 64)]),
+    ('X down0c1 1m W4', 64, 64, (3, 3, 3), [(192, 16, 4, 4)]),
+    ('X down0c1 lv3', 64, 64, (3, 3, 3), [(12, 4, 32, 32)]),
     ('D down0 conv2 8m', 64, 128, (3, 3, 3), D(32, 1)),
     ('D down1 conv1 8m', 128, 128, (3, 3, 3), D(32, 2)),
     ('D down1 conv2 8m', 128, 256, (3, 3, 3), D(32, 2)),

@@ -2353,7 +2353,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WGroupTable 
 // (C -> 64 stem convs: 27 columns instead of 27 tiles that are 1/64 full).
 __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                               const int Cout, const int T, const int kH, const int kW,
-                                                              const int flags, const int chunks_per_split, const LiveTaps live) {
+                                                              const int flags, const int chunks_per_split, const LiveTaps live,
+                                                              float* __restrict__ bias_slab) {
     __shared__ __attribute__((aligned(16))) float As[64 * WG_PITCH];   // gy^T tile  [co][m]
     __shared__ __attribute__((aligned(16))) float Bs[64 * WG_PITCH];   // x   tile   [col][m]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2389,6 +2390,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
     if (q1 > nchunks) q1 = nchunks;
     float ra[8], rb[8];
     bool pend_m = false;
+    // bias gradient on the side (see conv_wgrad3_kernel): the first column tile's workgroups see every voxel exactly once
+    const bool do_bias = bias_slab != nullptr && col0 == 0;
+    float bsum[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
     uint32_t pend_x = 0;
     // member state cached in scalars + shift decode + buffer loads (see conv_wgrad3_kernel)
     int g_i = -1, g_begin = 0, g_end = 0;
@@ -2460,6 +2466,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
     };
     if (q0 < q1) load_chunk(q0);
     for (int q = q0; q < q1; ++q) {
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) bsum[p] += pend_m ? ra[p] : 0.f;
+        }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int co = co0 + rl + p * 8;
@@ -2477,6 +2487,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = bsum[p];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int co = co0 + rl + p * 8;
+            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
+        }
     }
     // column -> (slot, ci): slab[((split*nlive + slot)*Cout + co)*Cin + ci]
     const int col = col0 + wcl * 32 + l31;
@@ -2965,14 +2985,10 @@ extern "C" int t2v_conv_wgrad_plan(const t2v_conv_group* groups, int ngroups, in
 extern "C" int64_t t2v_channel_sum_grouped_ws_floats(const t2v_conv_group* groups, int ngroups, int C);
 extern "C" int t2v_channel_sum_grouped(const t2v_conv_group* groups, int ngroups, int C, float* out, float* ws, int accum, void* stream);
 
-// floats the bias part needs behind the weight-gradient slab: S x Cout partial sums when the 3-tap kernel produces them
-// on the side, else the workspace of the stand-alone channel sum
+// floats the bias part needs behind the weight-gradient slab: S x Cout partial sums (every weight-gradient kernel sums the
+// dL/dy tiles it stages on the side)
 static int64_t wgrad_bias_extra(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const WgradPlan& p) {
-    if (p.rows3 || Cin >= 64) return (int64_t)p.S * Cout;
-    t2v_conv_group tmp[T2V_MAX_GROUPS];
-    for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
-    const int64_t n = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
-    return n < 0 ? 0 : n;
+    return (int64_t)p.S * Cout;
 }
 extern "C" int64_t t2v_conv_wgrad_grouped_bias_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD,
                                                            int kH, int kW) {
@@ -3000,15 +3016,7 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
     if ((!dw && !out_src) || !slab || !build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;         // behind the weight-gradient slab
-    const bool bias_fused = p.rows3 || Cin >= 64;                         // both MFMA weight-gradient kernels sum dL/dy on the side
-    if (dbias && !bias_fused) {                                           // Cin < 64: the stand-alone channel sum
-        t2v_conv_group tmp[T2V_MAX_GROUPS];
-        for (int i = 0; i < ngroups; ++i) { tmp[i] = groups[i]; tmp[i].x = groups[i].y; }
-        const int64_t nws = t2v_channel_sum_grouped_ws_floats(tmp, ngroups, Cout);
-        const int rc = t2v_channel_sum_grouped(tmp, ngroups, Cout, dbias, nws > 0 ? bias_part : nullptr,
-                                               (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0, stream);
-        if (rc) return rc;
-    }
+    const bool bias_fused = true;                                         // all three weight-gradient kernels sum dL/dy on the side
 #ifdef T2V_ABLATION
     if (const char* e = getenv("T2V_DEBUG_FLAGS")) flags |= atoi(e);     // developer ablations (wrong results)
 #endif
@@ -3059,7 +3067,8 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
                                 dbias ? bias_part : (float*)nullptr);
         } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
-            T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live);
+            T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
+                            dbias ? bias_part : (float*)nullptr);
         } else {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)live.n, (unsigned)p.S);
             if (flags & T2V_CONV_BF16)
@@ -3110,7 +3119,6 @@ extern "C" int t2v_conv_wgrad_grouped_partial(const t2v_conv_group* groups, int 
     WGroupTable tab;
     WgradPlan p;
     if (!build_wtable(groups, ngroups, Cin, Cout, kD, kH, kW, false, tab, p)) return T2V_EINVAL;
-    if (want_bias && !(p.rows3 || Cin >= 64)) return T2V_EINVAL;    // only the MFMA kernels sum dL/dy on the side
     float dummy;                                                    // (non-null marker: the bias side-sums are wanted)
     return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, nullptr, want_bias ? &dummy : nullptr, slab, flags, stream, out_src);
 }

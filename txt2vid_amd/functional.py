@@ -2911,8 +2911,8 @@ def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False
 
 
 def _wgrad_bias_fused(xs5, wshape):
-    """True when the weight-gradient kernel for these members sums dL/dy on the side (the MFMA kernels: Cin >= 64)."""
-    return wshape[1] >= 64
+    """True when the weight-gradient kernel for these members sums dL/dy on the side (all three kernels do)."""
+    return True
 
 
 def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None):
