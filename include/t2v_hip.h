@@ -234,6 +234,9 @@ int t2v_rowbcast(const float* g, float* gx, int64_t rows, int64_t S, void* strea
 /* nearest x2 up-sampling of (H,W) planes (nn.Upsample, layers.py:168,180) and its adjoint. */
 int t2v_upsample2x(const float* x, float* y, int64_t planes, int H, int W, void* stream);
 int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* stream);
+/* y[planes,2H,2W] = upsample2x(x[planes,H,W]) + h[planes,2H,2W]: UpBlock's closing residual add (layers.py:152-195) with the
+ * identity path's nearest up-sampling folded in (its 1x1 convolution runs BEFORE the up-sampling: same values, a quarter of the work). */
+int t2v_upsample2x_add(const float* x, const float* h, float* y, int64_t planes, int H, int W, void* stream);
 
 /* BatchNorm2d, training mode (layers.py:171,175,249): per-channel batch statistics over (N,H,W),
  * running stats updated with `momentum` (unbiased variance), y = relu?((x-mean)*invstd*gamma+beta).
@@ -255,6 +258,13 @@ int t2v_bn_train_fwd(const float* x, const float* gamma, const float* beta, floa
                      int64_t* num_batches_tracked /* nn.BatchNorm's step counter, += 1 on the device; may be NULL */, void* stream);
 int t2v_bn_train_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
                      float* ggamma, float* gbeta, float* ws, int N, int C, int64_t S, int relu, void* stream);
+/* BatchNorm2d -> [ReLU] -> Upsample(2), the head of UpBlock's main path (layers.py:152-195), in the same two launches:
+   x / gx are [N,C,H,W], y / gy the up-sampled [N,C,2H,2W] tensors (the adjoint sums the 2x2 copies while it reads gy). */
+int t2v_bn_train_fwd_up(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* running_mean,
+                        float* running_var, float* ws, int N, int C, int H, int W, float momentum, float eps, int relu,
+                        int64_t* num_batches_tracked, void* stream);
+int t2v_bn_train_bwd_up(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
+                        float* ggamma, float* gbeta, float* ws, int N, int C, int H, int W, int relu, void* stream);
 int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta,
                 float* y, int N, int C, int64_t S, float eps, int relu, void* stream);
 

@@ -505,6 +505,37 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
+@pytest.mark.parametrize('cin,cout', [(16, 16), (32, 16)])
+def test_upblock_identity_path_on_the_small_map(cin, cout):
+    """UpBlock (layers.py:152-195): the identity path Up [-> conv1x1] is evaluated as conv1x1 on the small map and one
+    `t2v_upsample2x_add` launch; output identical to the reference order of operations (torch modules), gradients of x and of
+    every parameter within rounding."""
+    from txt2vid_amd.models.layers import UpBlock
+    torch.manual_seed(3)
+    blk = UpBlock(in_channels=cin, out_channels=cout)
+    x = rnd(11, 3, cin, 6, 6)
+    m, idm = blk.main.inner_module, blk.main.identity_map
+    xr = x.clone().requires_grad_(True)
+    h = F.relu(F.batch_norm(xr, None, None, m[0].weight, m[0].bias, True, 0.1, 1e-5))
+    h = F.conv2d(F.interpolate(h, scale_factor=2), m[3].weight, m[3].bias, padding=1)
+    h = F.relu(F.batch_norm(h, None, None, m[4].weight, m[4].bias, True, 0.1, 1e-5))
+    h = F.conv2d(h, m[6].weight, m[6].bias, padding=1)
+    s = F.interpolate(xr, scale_factor=2)
+    if cin != cout:
+        s = F.conv2d(s, idm[1].weight, idm[1].bias)
+    yr = s + h
+    gy = rnd(12, *yr.shape)
+    params = list(blk.parameters())
+    gref = torch.autograd.grad((yr * gy).sum(), [xr] + params)
+    blk = blk.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    yd = blk(xd)
+    close(yd, yr.detach(), rtol=1e-4, atol=1e-4)
+    gd = torch.autograd.grad((yd * gy.to(dev())).sum(), [xd] + list(blk.parameters()))
+    for a, r in zip(gd, gref):
+        close(a, r, rtol=2e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize('hw,C,B', [(1, 16, 3), (2, 16, 3), (1, 128, 5), (1, 256, 33)])
 def test_conv_lstm(hw, C, B):
     """conv_lstm.py:75-97 vs the oracle; C % 128 == 0 on 1x1 maps takes the wave-per-strip GEMM + slab-summing gate

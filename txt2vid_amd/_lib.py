@@ -130,12 +130,15 @@ SIGNATURES = {
     't2v_rowbcast': [_P, _P, _L, _L, _P],
     't2v_upsample2x': [_P, _P, _L, _I, _I, _P],
     't2v_upsample2x_bwd': [_P, _P, _L, _I, _I, _P],
+    't2v_upsample2x_add': [_P, _P, _P, _L, _I, _I, _P],
     't2v_bn_ws_floats': [_I, _I, _L],
     't2v_bn_stats': [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
     't2v_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_train_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P, _P],
     't2v_bn_train_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
+    't2v_bn_train_fwd_up': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P],
+    't2v_bn_train_bwd_up': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
     't2v_lstm_gates': [_P, _P, _P, _P, _P, _I, _L, _P],
     't2v_lstm_gates_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P],

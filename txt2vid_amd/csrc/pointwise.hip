@@ -403,13 +403,14 @@ extern "C" int t2v_rowbcast(const float* g, float* gx, int64_t rows, int64_t S, 
 }
 
 // ---------------------------------------------------------------- nearest x2 up-sampling
-__global__ void upsample2x_k(const float* x, float* y, long planes, int H, int W) {
+__global__ void upsample2x_k(const float* x, const float* add, float* y, long planes, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W;
     const long n = planes * Ho * Wo;
     GRID_STRIDE(i, n) {
         int wo = i % Wo; long r = i / Wo;
         int ho = r % Ho; long pl = r / Ho;
-        y[i] = x[(pl * H + (ho >> 1)) * W + (wo >> 1)];
+        const float v = x[(pl * H + (ho >> 1)) * W + (wo >> 1)];
+        y[i] = add ? v + add[i] : v;
     }
 }
 __global__ void upsample2x_bwd_k(const float* gy, float* gx, long planes, int H, int W) {
@@ -424,7 +425,14 @@ __global__ void upsample2x_bwd_k(const float* gy, float* gx, long planes, int H,
 }
 extern "C" int t2v_upsample2x(const float* x, float* y, int64_t planes, int H, int W, void* st) {
     if (!x || !y || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
-    T2V_LAUNCH(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, y, (long)planes, H, W);
+    T2V_LAUNCH(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, (const float*)nullptr, y, (long)planes, H, W);
+    return launch_status();
+}
+// y = upsample2x(x) + h: the residual add of an UpBlock whose identity path is Upsample [-> 1x1 conv] (layers.py:152-195; the
+// 1x1 convolution commutes with nearest up-sampling, so it runs on the small map and this kernel closes the block)
+extern "C" int t2v_upsample2x_add(const float* x, const float* h, float* y, int64_t planes, int H, int W, void* st) {
+    if (!x || !h || !y || planes < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    T2V_LAUNCH(upsample2x_k, dim3(nblocks(planes * 4 * H * W)), dim3(256), 0, S_(st), x, h, y, (long)planes, H, W);
     return launch_status();
 }
 extern "C" int t2v_upsample2x_bwd(const float* gy, float* gx, int64_t planes, int H, int W, void* st) {
@@ -502,8 +510,25 @@ __global__ void bn_apply_k(const float* x, const float* stats, const float* gamm
     }
 }
 // pass 1: per channel sums  s1 = sum g', s2 = sum g' * xhat   (g' = gy masked by relu); grid (C, SPLIT)
+// UP: the forward wrote its output through a nearest x2 up-sampling (y and gy are [N,C,2H,2W], W = width of x): the
+// gradient of the small map is the sum of its 2x2 copies, the ReLU mask is read from the top-left copy
+template <bool UP>
+__device__ __forceinline__ float bn_gy(const float* gy, const float* y, size_t idx, long sp, int W, int relu) {
+    if (!UP) {
+        float g = gy[idx];
+        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        return g;
+    }
+    const long h = sp / W, w = sp - h * W;
+    const size_t plane = idx - sp;                       // (n*C + c) * S
+    const size_t o = plane * 4 + (size_t)(2 * h) * (2 * W) + 2 * w;
+    float g = (gy[o] + gy[o + 1]) + (gy[o + 2 * W] + gy[o + 2 * W + 1]);
+    if (relu && !(y[o] > 0.f)) g = 0.f;
+    return g;
+}
+template <bool UP>
 __global__ __launch_bounds__(256) void bn_bwd_part_k(const float* gy, const float* x, const float* y, const float* stats,
-                                                     float* part, int N, int C, long S, int relu, int split) {
+                                                     float* part, int N, int C, long S, int relu, int split, int W) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     const float mean = stats[c], istd = stats[C + c];
@@ -516,8 +541,7 @@ __global__ __launch_bounds__(256) void bn_bwd_part_k(const float* gy, const floa
     for (long e = e0 + threadIdx.x; e < e1; e += 256) {
         const long n = e / S, sp = e - n * S;
         const size_t idx = ((size_t)n * C + c) * S + sp;
-        float g = gy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        const float g = bn_gy<UP>(gy, y, idx, sp, W, relu);
         s1 += g;
         s2 += g * (x[idx] - mean) * istd;
     }
@@ -552,10 +576,11 @@ __global__ void bn_bwd_apply_k(const float* gy, const float* x, const float* y, 
 // Fused second passes: every workgroup (channel c, slice y) first merges the channel's partial statistics itself — a
 // short serial Chan merge / sum, identical in every workgroup of the channel — and then normalises its slice; the
 // y == 0 workgroup also publishes the merged values (stats, running stats / dgamma, dbeta). No `final` launch.
+template <bool UP>
 __global__ __launch_bounds__(256) void bn_apply_merge_k(const float* x, const float* part, int split, const float* gamma,
                                                         const float* beta, float* y, float* stats, float* rmean, float* rvar,
                                                         int N, int C, long S, float momentum, float eps, int relu,
-                                                        long long* batches_tracked) {
+                                                        long long* batches_tracked, int W) {
     const int c = blockIdx.x;
     if (batches_tracked && c == 0 && blockIdx.y == 0 && threadIdx.x == 0) *batches_tracked += 1;     // nn.BatchNorm's step counter
     float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -588,13 +613,19 @@ __global__ __launch_bounds__(256) void bn_apply_merge_k(const float* x, const fl
     for (long e = e0 + threadIdx.x; e < e1; e += 256) {
         const long nn = e / S, sp = e - nn * S;
         const size_t idx = ((size_t)nn * C + c) * S + sp;
-        const float v = (x[idx] - mean) * sc + sh;
-        y[idx] = relu ? fmaxf(v, 0.f) : v;
+        float v = (x[idx] - mean) * sc + sh;
+        v = relu ? fmaxf(v, 0.f) : v;
+        if (UP) {                                        // BN -> ReLU -> Upsample(2) of an UpBlock in one pass
+            const long h = sp / W, w = sp - h * W;
+            float* q = y + (idx - sp) * 4 + (size_t)(2 * h) * (2 * W) + 2 * w;
+            q[0] = v; q[1] = v; q[2 * W] = v; q[2 * W + 1] = v;
+        } else y[idx] = v;
     }
 }
+template <bool UP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_merge_k(const float* gy, const float* x, const float* y, const float* stats,
                                                             const float* gamma, const float* part, int split, float* gx,
-                                                            float* ggamma, float* gbeta, int N, int C, long S, int relu) {
+                                                            float* ggamma, float* gbeta, int N, int C, long S, int relu, int W) {
     const int c = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < split; ++k) { s1 += part[((size_t)c * split + k) * 2]; s2 += part[((size_t)c * split + k) * 2 + 1]; }
@@ -610,8 +641,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_merge_k(const float* gy, con
     for (long e = e0 + threadIdx.x; e < e1; e += 256) {
         const long nn = e / S, sp = e - nn * S;
         const size_t idx = ((size_t)nn * C + c) * S + sp;
-        float g = gy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        const float g = bn_gy<UP>(gy, y, idx, sp, W, relu);
         const float xh = (x[idx] - mean) * istd;
         gx[idx] = k0 * (g - a1 - xh * a2);
     }
@@ -657,7 +687,7 @@ extern "C" int t2v_bn_bwd(const float* gy, const float* x, const float* y, const
     if (relu && !y) return T2V_EINVAL;
     const int sp = bn_split(N, C, (long)S);
     float* part = ws + 2 * C;
-    T2V_LAUNCH(bn_bwd_part_k, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, part, N, C, (long)S, relu, sp);
+    T2V_LAUNCH(bn_bwd_part_k<false>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, part, N, C, (long)S, relu, sp, 1);
     T2V_LAUNCH(bn_bwd_final_k, dim3((C + 255) / 256), dim3(256), 0, S_(st), part, ws, ggamma, gbeta, C, sp);
     T2V_LAUNCH(bn_bwd_apply_k, dim3(nblocks((long)N * C * S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, gx, N, C, (long)S, relu);
     return launch_status();
@@ -668,8 +698,33 @@ extern "C" int t2v_bn_train_fwd(const float* x, const float* gamma, const float*
     if (!x || !gamma || !beta || !y || !stats || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
     const int sp = bn_split(N, C, (long)S);
     T2V_LAUNCH(bn_stats_part_k, dim3(C, sp), dim3(256), 0, S_(st), x, ws, N, C, (long)S, sp);
-    T2V_LAUNCH(bn_apply_merge_k, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), x, ws, sp, gamma, beta, y, stats, rm, rv, N,
-               C, (long)S, momentum, eps, relu, (long long*)batches_tracked);
+    T2V_LAUNCH(bn_apply_merge_k<false>, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), x, ws, sp, gamma, beta, y, stats, rm, rv, N,
+               C, (long)S, momentum, eps, relu, (long long*)batches_tracked, 1);
+    return launch_status();
+}
+// BatchNorm2d -> [ReLU] -> Upsample(2) (the head of UpBlock's main path, layers.py:152-195) in the same two launches: x is
+// [N,C,H,W], y is [N,C,2H,2W]
+extern "C" int t2v_bn_train_fwd_up(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* rm,
+                                   float* rv, float* ws, int N, int C, int H, int W, float momentum, float eps, int relu,
+                                   int64_t* batches_tracked, void* st) {
+    if (!x || !gamma || !beta || !y || !stats || !ws || N < 1 || C < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    const long S = (long)H * W;
+    const int sp = bn_split(N, C, S);
+    T2V_LAUNCH(bn_stats_part_k, dim3(C, sp), dim3(256), 0, S_(st), x, ws, N, C, S, sp);
+    T2V_LAUNCH(bn_apply_merge_k<true>, dim3(C, bn_slices(N, C, S)), dim3(256), 0, S_(st), x, ws, sp, gamma, beta, y, stats, rm, rv, N,
+               C, S, momentum, eps, relu, (long long*)batches_tracked, W);
+    return launch_status();
+}
+// its adjoint: gy and y are the up-sampled [N,C,2H,2W] tensors, gx is [N,C,H,W]
+extern "C" int t2v_bn_train_bwd_up(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
+                                   float* ggamma, float* gbeta, float* ws, int N, int C, int H, int W, int relu, void* st) {
+    if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    if (relu && !y) return T2V_EINVAL;
+    const long S = (long)H * W;
+    const int sp = bn_split(N, C, S);
+    T2V_LAUNCH(bn_bwd_part_k<true>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, S, relu, sp, W);
+    T2V_LAUNCH(bn_bwd_apply_merge_k<true>, dim3(C, bn_slices(N, C, S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
+               ggamma, gbeta, N, C, S, relu, W);
     return launch_status();
 }
 extern "C" int t2v_bn_train_bwd(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
@@ -677,9 +732,9 @@ extern "C" int t2v_bn_train_bwd(const float* gy, const float* x, const float* y,
     if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || S < 1) return T2V_EINVAL;
     if (relu && !y) return T2V_EINVAL;
     const int sp = bn_split(N, C, (long)S);
-    T2V_LAUNCH(bn_bwd_part_k, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, (long)S, relu, sp);
-    T2V_LAUNCH(bn_bwd_apply_merge_k, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
-               ggamma, gbeta, N, C, (long)S, relu);
+    T2V_LAUNCH(bn_bwd_part_k<false>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, (long)S, relu, sp, 1);
+    T2V_LAUNCH(bn_bwd_apply_merge_k<false>, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
+               ggamma, gbeta, N, C, (long)S, relu, 1);
     return launch_status();
 }
 extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,

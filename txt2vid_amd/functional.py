@@ -1724,26 +1724,73 @@ def upsample2x(x):
     return Upsample2x.apply(x)
 
 
-class BatchNormAct(Function):
-    """BatchNorm2d (+ optional fused ReLU). Training: batch statistics, running stats updated in place
-    (momentum 0.1, unbiased variance); eval: running statistics (no grad support needed)."""
+class UpsampleAdd(Function):
+    """upsample2x(s) + h in one launch (UpBlock's residual add with the identity path's up-sampling folded in)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter=None):
+    def forward(ctx, s, h):
+        s, h = _c(s), _c(h)
+        H, W = s.shape[-2], s.shape[-1]
+        if tuple(h.shape) != tuple(s.shape[:-2]) + (2 * H, 2 * W):
+            raise ValueError('upsample_add: %s vs %s' % (tuple(s.shape), tuple(h.shape)))
+        y = torch.empty_like(h)
+        check(lib().t2v_upsample2x_add(_p(s), _p(h), _p(y), s.numel() // (H * W), H, W, _stream()), 't2v_upsample2x_add')
+        ctx.in_shape = tuple(s.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gs = None
+        if ctx.needs_input_grad[0]:
+            g = _c(g)
+            shp = ctx.in_shape
+            H, W = shp[-2], shp[-1]
+            gs = torch.empty(shp, device=g.device, dtype=torch.float32)
+            check(lib().t2v_upsample2x_bwd(_p(g), _p(gs), gs.numel() // (H * W), H, W, _stream()), 't2v_upsample2x_bwd')
+        return gs, (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample_add(s, h):
+    return UpsampleAdd.apply(s, h)
+
+
+class BatchNormAct(Function):
+    """BatchNorm2d (+ optional fused ReLU, + optional fused nearest x2 up-sampling of the result: `up`, 4-D inputs).
+    Training: batch statistics, running stats updated in place (momentum 0.1, unbiased variance); eval: running
+    statistics (no grad support needed)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter=None, up=False):
         x = _c(x)
         N, Cc = x.shape[0], x.shape[1]
         S = x.numel() // (N * Cc)
-        y = torch.empty_like(x)
+        if up and x.dim() != 4:
+            raise ValueError('the fused up-sampling takes [N,C,H,W] inputs')
+        ctx.up = bool(up)
         if training:
             stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
             ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
-            check(lib().t2v_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S, momentum,
-                                         eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd')
+            if up:
+                H, W = x.shape[2], x.shape[3]
+                y = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+                check(lib().t2v_bn_train_fwd_up(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, H, W,
+                                                momentum, eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd_up')
+            else:
+                y = torch.empty_like(x)
+                check(lib().t2v_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S,
+                                             momentum, eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd')
             ctx.save_for_backward(x, y, stats, gamma)
             ctx.relu = relu
         else:
+            y = torch.empty_like(x)
             check(lib().t2v_bn_eval(_p(x), _p(rmean), _p(rvar), _p(gamma), _p(beta), _p(y), N, Cc, S, eps, int(relu), _stream()),
                   't2v_bn_eval')
+            if up:                  # (sampling path: two launches)
+                H, W = x.shape[2], x.shape[3]
+                y2 = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+                check(lib().t2v_upsample2x(_p(y), _p(y2), N * Cc, H, W, _stream()), 't2v_upsample2x')
+                y = y2
         ctx.training = training
         return y
 
@@ -1760,16 +1807,21 @@ class BatchNormAct(Function):
         gg = torch.empty_like(gamma)
         gb = torch.empty_like(gamma)
         ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
-        check(lib().t2v_bn_train_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
-                                     int(ctx.relu), _stream()), 't2v_bn_train_bwd')
-        return gx, gg, gb, None, None, None, None, None, None, None
+        if ctx.up:
+            check(lib().t2v_bn_train_bwd_up(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, x.shape[2],
+                                            x.shape[3], int(ctx.relu), _stream()), 't2v_bn_train_bwd_up')
+        else:
+            check(lib().t2v_bn_train_bwd(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, S,
+                                         int(ctx.relu), _stream()), 't2v_bn_train_bwd')
+        return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, counter=None):
-    """`counter`: the module's int64 `num_batches_tracked` buffer, incremented by the same launch in training mode."""
+def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, counter=None, up=False):
+    """`counter`: the module's int64 `num_batches_tracked` buffer, incremented by the same launch in training mode.
+    `up`: the result goes through a nearest x2 up-sampling in the same launches (UpBlock's BN-ReLU-Up head)."""
     if counter is not None and (counter.dtype != torch.int64 or not counter.is_cuda):
         raise TypeError('num_batches_tracked must be an int64 device tensor')
-    return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter)
+    return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter, up)
 
 
 def _skinny_ok(M, K, N):

@@ -46,11 +46,11 @@ class Linear(nn.Linear):
 class BatchNorm2d(nn.BatchNorm2d):
     """Training-mode batch statistics / eval-mode running statistics, optional fused ReLU."""
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, up=False):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('only the default BatchNorm2d configuration is on the hot path')
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, relu, counter=self.num_batches_tracked if self.training else None)
+                                 self.momentum, self.eps, relu, counter=self.num_batches_tracked if self.training else None, up=up)
 
 
 class ReLU(nn.Module):
@@ -230,11 +230,22 @@ class UpBlock(nn.Module):
 
     def forward(self, x):
         m = self.main.inner_module
-        h = m[0](x, relu=True) if isinstance(m[0], BatchNorm2d) else m[1](m[0](x))     # BN+ReLU fused
-        h = m[3](m[2](h))
+        if isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample):
+            h = m[3](m[0](x, relu=True, up=True))                                      # BN+ReLU+Up fused
+        else:
+            h = m[0](x, relu=True) if isinstance(m[0], BatchNorm2d) else m[1](m[0](x))
+            h = m[3](m[2](h))
         h = m[4](h, relu=True) if isinstance(m[4], BatchNorm2d) else m[5](m[4](h))
         h = m[6](h)
-        x = TF.add(self.main.identity_map(x), h)
+        idm = self.main.identity_map
+        if isinstance(idm, Upsample):
+            x = TF.upsample_add(x, h)                                   # Up(x) + h in one launch
+        elif isinstance(idm, nn.Sequential) and len(idm) == 2 and isinstance(idm[0], Upsample) and isinstance(idm[1], Conv2d) \
+                and tuple(idm[1].kernel_size) == (1, 1):
+            # conv1x1(Up(x)) == Up(conv1x1(x)) value for value (a 1x1 convolution is per-pixel): run it on the small map
+            x = TF.upsample_add(idm[1](x), h)
+        else:
+            x = TF.add(idm(x), h)
         if self.with_non_local:
             x = self.attn(x)
         return x
