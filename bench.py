@@ -162,6 +162,34 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def per_tile_breakdown(path, steps, peak, kind):
+    """Forward / data-gradient GEMM launches of the instrumented iterations grouped by kernel family: launches and GPU ms per
+    iteration, achieved TFLOP/s on the executed FLOPs, fraction of the MFMA peak (from the library's per-launch records)."""
+    import csv
+    names = {0: 'igemm', 1: 'strip', 5: 'strip3'}
+    agg = {}
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if int(r['kind']) != kind:
+                    continue
+                plan = [int(v) for v in r['plan'].split(':')]
+                if plan[0] not in names:
+                    continue
+                key = '%s %dx%d' % (names[plan[0]], plan[1], plan[2])
+                a = agg.setdefault(key, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += float(r['ms'])
+                a[2] += float(r['flops'])
+    except (OSError, KeyError, ValueError):
+        return None
+    out = {}
+    for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[key] = {'launches_per_step': n / steps, 'gpu_ms_per_step': ms / steps, 'achieved': tf, 'frac': tf / peak}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -308,7 +336,20 @@ def main():
         log('instrumented eager pass done: %.1f ms/step' % (prof_dt / prof_steps * 1e3))
     if prof:
         out = (C.c_double * 18)()
+        dump = os.environ.get('T2V_PROF_DUMP')
+        own_dump = dump is None
+        if own_dump:                               # per-launch records (kernel plan, time, FLOPs) for the per-tile breakdown below
+            import tempfile
+            dump = os.path.join(tempfile.gettempdir(), 't2v_prof_%d.csv' % os.getpid())
+            os.environ['T2V_PROF_DUMP'] = dump
         over = lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
+        by_tile = per_tile_breakdown(dump, prof_steps, PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS, 5 if bf16 else 0)
+        if own_dump:
+            os.environ.pop('T2V_PROF_DUMP', None)
+            try:
+                os.remove(dump)
+            except OSError:
+                pass
         conv_flops = out[1] + out[4] + out[10] + out[16]      # fp32 implicit GEMM + weight gradients + thin kernels + bf16 GEMM
         if bf16:                                   # bf16-compute mode: the dominant kernel is the bf16 GEMM, priced against the bf16 peak
             out[0], out[1], out[2] = out[15], out[16], out[17]
@@ -334,6 +375,8 @@ def main():
                     # WHOLE step time: what the step as a whole achieves against the matrix peak (kernel fraction above: the
                     # implicit-GEMM launches alone over their own time)
                     'all_in_frac': conv_flops / prof_steps / (dt / args.steps) / 1e12 / peak,
+                    # the same launches by kernel family (tile): `frac` above is their time-weighted aggregate
+                    'by_tile': by_tile,
                     'executed_conv_tflop_per_step': conv_flops / prof_steps / 1e12,
                     'wgrad': {'achieved': (out[4] / (out[3] * 1e-3) / 1e12) if out[3] > 0 else None,
                               'launches_per_step': out[5] / prof_steps, 'gpu_ms_per_step': out[3] / prof_steps,
