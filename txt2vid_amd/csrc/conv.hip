@@ -551,14 +551,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
 // global gathers and LDS writes per MFMA. Chunk order: (row tap, channel block, dx) with dx fastest; weights are
 // staged per chunk as before. Requires taps in product order with dx fastest (what conv_geom emits) and Cin % BKT == 0.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_CO, int BKT, bool VECB, int KS>
+template <int BM, int BN, int WAVES_CO, int BKT, bool VECB>
 __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ slab,
                                                                const int Cin, const int Cout, const int flags, const int nsplit) {
-    // KS = 2: the four waves are 2 (co) x 1 (m) x 2 (K halves of every chunk): each wave owns a 32 x BM strip with two
-    // independent accumulator chains and 1.5 LDS reads per MFMA (a 32x32 tile per wave has one chain and 2 reads per
-    // MFMA); the two K halves are added through LDS before the epilogue. For the 64 x 64 workgroup tile.
-    constexpr int WAVES_M = 4 / (WAVES_CO * KS);
+    constexpr int WAVES_M = 4 / WAVES_CO;
     constexpr int WCO = BN / WAVES_CO;
     constexpr int WM = BM / WAVES_M;
     constexpr int NCO = WCO / 32, NM = WM / 32;
@@ -571,7 +568,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     constexpr int LBV = NV >= 256 ? NV / 256 : 1;
     constexpr int KSBV = 1024 / BN;
     static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LB >= 1 && 2 * BKT <= 256, "tile");
-    static_assert(KS == 1 || (KS == 2 && WAVES_CO == 2 && 128 * (NCO * NM * 16 + 1) <= 2 * BKT * AP), "K-split waves");
 
     __shared__ __attribute__((aligned(16))) float As[2 * BKT * AP];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BKT * BN];
@@ -579,7 +575,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wk = wave / (WAVES_CO * WAVES_M);          // K half of the chunk this wave multiplies (0 when KS == 1)
     const int wco = wave % WAVES_CO, wm = (wave / WAVES_CO) % WAVES_M;
 
     const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
@@ -749,9 +744,9 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
         for (int j = 0; j < NM; ++j) keep[j] = dx_now < 0 ? can_l[j] : (dx_now > 0 ? can_r[j] : true);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int k2 = 0; k2 < BKT / 2 / KS; ++k2) {
+        for (int k2 = 0; k2 < BKT / 2; ++k2) {
             float a[NCO], b[NM];
-            const int krow = (wk * (BKT / 2 / KS) + k2) * 2 + hi;
+            const int krow = k2 * 2 + hi;
 #pragma unroll
             for (int i = 0; i < NCO; ++i) a[i] = bs[krow * BN + i * 32];
 #pragma unroll
@@ -775,29 +770,6 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
         bcur ^= 1;
         if (next_a) acur ^= 1;
         dx_now = dx_next;
-    }
-    if (KS == 2) {
-        // (the loop's last barrier is behind us: As is free.) Waves of the upper K half hand their partial tiles over.
-        float* scratch = As + (wco * 64 + lane) * (NCO * NM * 16 + 1);
-        if (wk == 1) {
-#pragma unroll
-            for (int i = 0; i < NCO; ++i)
-#pragma unroll
-                for (int j = 0; j < NM; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) scratch[(i * NM + j) * 16 + r] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (wk == 1) return;
-        f32x16 tot[NCO][NM];
-#pragma unroll
-        for (int i = 0; i < NCO; ++i)
-#pragma unroll
-            for (int j = 0; j < NM; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[i][j][r] = acc[i][j][r] + scratch[(i * NM + j) * 16 + r];
-        igemm_epilogue<NCO, NM, WCO, WM>(tot, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
-        return;
     }
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
@@ -1723,9 +1695,8 @@ static bool strip_fits32(const GroupTable& tab, int Cin) {
 static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
 
 // Which instantiation a (tile, chunk) choice ends up in: the strip variant (three dx taps from one staged strip) when the
-// members carry their taps in (row, dx) order, and for the 64x64x32 strip tile the K-split wave layout (KS = 2: two
-// accumulator chains per wave cost a VGPR occupancy step, 3 instead of 4 waves per SIMD: worth it only for launches that
-// cannot put 4 workgroups on every CU anyway). Shared by the launcher and by t2v_conv_fwd_plan.
+// members carry their taps in (row, dx) order. Shared by the launcher and by t2v_conv_fwd_plan. (`ks`: K-split wave layout of
+// the plan query's out[6]; always 1 — the two-chains-per-wave form was dropped for the three-taps-per-round kernel.)
 struct ConvVariant { bool strip; int ks; bool s3; };
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
     ConvVariant v{false, 1, false};
@@ -1795,8 +1766,8 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
     }
     if (v.strip) {
         if constexpr (BN == 32) {
-            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
-            else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false, 1>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            if (p.vecb) T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+            else T2V_LAUNCH_PROF((conv_igemm_strip_kernel<BM, BN, WAVES_CO, BKT, false>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
         }
         return;
     }
