@@ -5,12 +5,13 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/r02
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/r02_bench_default.json && echo "bench ok" &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_d_roofline --no_extra > $O/trace.log 2>&1 && echo "trace ok" &&
 cd $R &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/conv_micro.py both 3 > $O/pmc_fetch.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/conv_micro.py both 3 > $O/pmc_write.log 2>&1 &&
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/r02_pmc_traffic.json && echo "traffic ok" &&
+cp $O/r02_pmc_traffic.json profiles/r02_pmc_traffic.json &&      # the default bench line quotes it (same conv.hip: same sha1)
+python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/r02_bench_default.json && echo "bench ok" &&
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq -- python3 tools/conv_micro.py both 3 > $O/pmc_sq.log 2>&1 &&
 python3 tools/pmc_sq.py $O/pmc_sq > $O/r02_pmc_sq.json && echo "sq ok" &&
 python3 bench.py --size 128 --channels 3 --cond --batch 16 --bf16 --no_cpu_baseline --no_extra --no_d_roofline > $O/cfg4_bf16.log 2>&1 && tail -1 $O/cfg4_bf16.log > $O/r02_bench_cfg4_shape_bf16.json &&
