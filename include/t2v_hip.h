@@ -345,9 +345,11 @@ int t2v_argmax_rows(const float* x, int32_t* idx, int64_t rows, int V, void* str
  *   T2V_MJ_BMM              out[b] = op(a[b]) @ op(b[b])                n = batch, d0 = M, d1 = N, d2 = K, f0 = ta, f1 = tb
  *   T2V_MJ_RELU_MASK        out = b > 0 ? a : 0                         n = elements (ReLU adjoint over several tensors)
  *   T2V_MJ_ROWSUM           out[row] = sum_s a[row][s]                  n = rows, d0 = S (resnet3d.py:48 over all levels)
- *   T2V_MJ_ROWBCAST         out[row][s] = a[row]                        its adjoint */
+ *   T2V_MJ_ROWBCAST         out[row][s] = a[row]                        its adjoint
+ *   T2V_MJ_ADD              out = a + b (+ c when c != NULL)            n = elements (gradient sums where an activation feeds
+ *                                                                       several consumers: one launch for all pyramid levels) */
 enum { T2V_MJ_SCALE = 1, T2V_MJ_SCALE_ADD, T2V_MJ_DOT, T2V_MJ_MAXPOOL, T2V_MJ_MAXSCATTER, T2V_MJ_MAXGATHER, T2V_MJ_SOFTMAX,
-       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST };
+       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST, T2V_MJ_ADD };
 typedef struct t2v_multi_job {
     const void* a; const void* b; const void* c; void* out; void* out2;
     int64_t n;

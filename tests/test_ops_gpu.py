@@ -505,6 +505,29 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
+def test_fork_group_sums_gradients_in_one_launch_first_and_second_order():
+    """`fork_group`: two aliases per tensor whose gradients are summed by ONE grouped launch (`T2V_MJ_ADD`) instead of one
+    autograd-engine add per tensor; members that need no gradient pass through; closed under double backward."""
+    from txt2vid_amd import functional as TF
+    xs = [rnd(5 + i, *s).to(dev()).requires_grad_(i != 1) for i, s in enumerate([(2, 3, 4), (3, 5), (1, 7, 2, 2)])]
+    ws = [rnd(15 + i, *x.shape).to(dev()) for i, x in enumerate(xs)]
+    a, b = TF.fork_group(xs)
+    assert a[1] is xs[1] and b[1] is xs[1]                                   # no gradient wanted: untouched
+    assert all(torch.equal(t, x) and torch.equal(u, x) for t, u, x in zip(a, b, xs))
+    # f = sum w * a^2 * b  (= w x^3): df/dx = 3 w x^2 through the two aliases, d/dx of sum (df/dx)^2 = 36 w^2 x^3
+    f = sum((w * t * t * u).sum() for w, t, u in zip(ws, a, b))
+    live = [xs[0], xs[2]]
+    g = torch.autograd.grad(f, live, create_graph=True)
+    for gi, x, w in zip(g, live, [ws[0], ws[2]]):
+        close(gi, 3 * w * x.detach() ** 2, rtol=1e-5, atol=1e-5)
+    gg = torch.autograd.grad(sum((gi * gi).sum() for gi in g), live)
+    for ggi, x, w in zip(gg, live, [ws[0], ws[2]]):
+        close(ggi, 36 * w * w * x.detach() ** 3, rtol=1e-4, atol=1e-4)
+    with torch.no_grad():
+        a, b = TF.fork_group(xs)
+        assert all(t is x and u is x for t, u, x in zip(a, b, xs))
+
+
 @pytest.mark.parametrize('cin,cout', [(16, 16), (32, 16)])
 def test_upblock_identity_path_on_the_small_map(cin, cout):
     """UpBlock (layers.py:152-195): the identity path Up [-> conv1x1] is evaluated as conv1x1 on the small map and one

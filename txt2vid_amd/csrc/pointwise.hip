@@ -1513,6 +1513,15 @@ __global__ __launch_bounds__(256) void mj_relu_mask_k(const MultiBatch tb) {
     const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
     for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) o[i] = x[i] > 0.f ? g[i] : 0.f;
 }
+// out = a + b (+ c): the gradient sums of a grouped fork (one launch for all members instead of one ATen add per member)
+__global__ __launch_bounds__(256) void mj_add_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b; const float* c = (const float*)q.c;
+    float* o = (float*)q.out;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) o[i] = c ? (a[i] + b[i]) + c[i] : a[i] + b[i];
+}
 // row sums (one wave per row): out[row] = sum_s a[row][s], n = rows, d0 = S;  mode 1: broadcast out[row][s] = a[row]
 __global__ __launch_bounds__(256) void mj_rowsum_k(const MultiBatch tb, const int bcast) {
     const int ji = mj_find(tb);
@@ -1695,6 +1704,9 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
             case T2V_MJ_RELU_MASK:
                 if (!q.b || !q.out) return T2V_EINVAL;
                 nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_ADD:
+                if (!q.b || !q.out) return T2V_EINVAL;
+                nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
             case T2V_MJ_ROWSUM:
                 if (!q.out || q.d0 < 1) return T2V_EINVAL;
                 nb = (q.n + 3) / 4; break;
@@ -1730,6 +1742,7 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
         case T2V_MJ_SOFTMAX_BWD_BWD_Y: T2V_LAUNCH(mj_softmax_k, grid, blk, 0, S_(st), tb, 2); break;
         case T2V_MJ_BMM: T2V_LAUNCH(mj_bmm_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_RELU_MASK: T2V_LAUNCH(mj_relu_mask_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_ADD: T2V_LAUNCH(mj_add_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_ROWSUM: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 0); break;
         case T2V_MJ_ROWBCAST: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 1); break;
     }

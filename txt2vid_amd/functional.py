@@ -974,11 +974,17 @@ class AvgPool3dG(Function):
         n = len(cfgs)
         live = [i for i, g in enumerate(gs) if g is not None]
         gxs = [None] * n
+        g_add = gs
+        if has_add and torch.is_grad_enabled():      # recorded backward (gradient penalty): dL/dy feeds the pooling adjoint AND the
+            gs, g_add = _fork_some(gs)               # addend; a grouped fork sums their second-order gradients in one launch
         if live:
             res = AvgPool3dBwdG.apply(tuple(cfgs[i] for i in live), tuple(in_sps[i] for i in live), *[gs[i] for i in live])
             for i, r in zip(live, res):
                 gxs[i] = r
-        return (None, None, None) + tuple(gxs) + (tuple(gxs) if has2 else ()) + (tuple(gs) if has_add else ())
+        gx2s = gxs
+        if has2 and torch.is_grad_enabled():         # likewise the one gradient that goes to both pooled inputs
+            gxs, gx2s = _fork_some(gxs)
+        return (None, None, None) + tuple(gxs) + (tuple(gx2s) if has2 else ()) + (tuple(g_add) if has_add else ())
 
 
 class AvgPool3dBwdG(Function):
@@ -1306,7 +1312,7 @@ def scale_add(gamma, o, x):
 # members that receive no gradient (None) are left out of the backward launches.
 # ------------------------------------------------------------------------------------------------
 (MJ_SCALE, MJ_SCALE_ADD, MJ_DOT, MJ_MAXPOOL, MJ_MAXSCATTER, MJ_MAXGATHER, MJ_SOFTMAX, MJ_SOFTMAX_BWD, MJ_SOFTMAX_BWD_BWD_Y, MJ_BMM,
- MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST) = range(1, 14)
+ MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD) = range(1, 15)
 
 
 def _mj(op, jobs, scalar=None, dot_out=None):
@@ -1331,6 +1337,74 @@ def _mj(op, jobs, scalar=None, dot_out=None):
 
 def _live(gs):
     return [i for i, g in enumerate(gs) if g is not None]
+
+
+class AddG(Function):
+    """ys[i] = as[i] + bs[i] for n pairs of same-shaped tensors in ONE launch (args: a_0..a_{n-1}, b_0..b_{n-1})."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        n = len(ts) // 2
+        a, b = [_c(t) for t in ts[:n]], [_c(t) for t in ts[n:]]
+        ys = [torch.empty_like(t) for t in a]
+        _mj(MJ_ADD, [dict(a=x, b=y, out=o, n=x.numel()) for x, y, o in zip(a, b, ys)])
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return tuple(gs) + tuple(gs)
+
+
+class ForkG(Function):
+    """Two autograd aliases of each of n tensors: `xs -> (xs', xs'')` for an activation list that feeds two consumers. The
+    values are views (no kernel); the adjoint adds the two gradients of ALL members in one launch (`AddG`) — without the
+    fork the autograd engine accumulates them with one ATen add per member. Closed under differentiation (AddG's adjoint
+    hands its gradient to both summands)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs) + tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = len(gs) // 2
+        out = [None] * n
+        both = [i for i in range(n) if gs[i] is not None and gs[n + i] is not None]
+        for i in range(n):
+            if i not in both:
+                out[i] = gs[i] if gs[i] is not None else gs[n + i]
+        if both:
+            sums = AddG.apply(*([gs[i] for i in both] + [gs[n + i] for i in both]))
+            for i, t in zip(both, sums):
+                out[i] = t
+        return tuple(out)
+
+
+def fork_group(xs):
+    """(xs', xs''): two aliases of every tensor of `xs` whose gradients are summed in one launch. Tensors that need no
+    gradient are passed through as they are (a fork of them would only mark their aliases as requiring one)."""
+    xs = list(xs)
+    live = [i for i, x in enumerate(xs) if x.requires_grad]
+    if not live or not torch.is_grad_enabled():
+        return xs, xs
+    res = ForkG.apply(*[xs[i] for i in live])
+    a, b = list(xs), list(xs)
+    for k, i in enumerate(live):
+        a[i], b[i] = res[k], res[len(live) + k]
+    return a, b
+
+
+def _fork_some(ts):
+    """`fork_group` over a list that may hold None entries (members without a gradient)."""
+    idx = [i for i, t in enumerate(ts) if t is not None]
+    a, b = list(ts), list(ts)
+    if idx:
+        fa, fb = fork_group([ts[i] for i in idx])
+        for k, i in enumerate(idx):
+            a[i], b[i] = fa[k], fb[k]
+    return a, b
 
 
 class MaxPool2x2G(Function):

@@ -116,6 +116,7 @@ def nonlocal_levels(att, xs):
     levels together (layers.py:52-68)."""
     if len(xs) > 8:
         raise ValueError('at most 8 tensors per grouped non-local block')
+    xs, xs_res = TF.fork_group(xs)           # projections + residual: their gradients are summed in one launch for all levels
     thetas, phis, gs = TF.conv_multi_group(xs, [(att.theta.weight, None, False), (att.phi.weight, None, False),
                                                 (att.g.weight, None, False)])
     phis = TF.max_pool2x2_group(phis)
@@ -128,7 +129,7 @@ def nonlocal_levels(att, xs):
     os_ = TF.bmm_group(gs, betas, False, True)
     os_ = [o.reshape((b, att.ch // 2) + tuple(x.shape[2:])) for o, b, x in zip(os_, bs, xs)]
     os_ = TF.conv_group(os_, att.o.weight, None)
-    return TF.scale_add_group(att.gamma, os_, xs)
+    return TF.scale_add_group(att.gamma, os_, xs_res)
 
 
 class Attention(nn.Module):

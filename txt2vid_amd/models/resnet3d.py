@@ -49,15 +49,18 @@ class Resnet3D(nn.Module):
         launch over the levels (same results as level-by-level `forward`, resnet3d.py:38-57)."""
         m = self.res_block.inner_module
         idm = self.res_block.identity_map
+        # the clips feed the residual path and the skip path: a grouped fork sums their two gradients (generator step, gradient
+        # penalty) in one launch for all levels instead of one autograd-engine add per level
+        xs, xs_skip = TF.fork_group(xs)
         hs = TF.conv_group(xs, m[0].weight, m[0].bias)
         hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
         if isinstance(m[3], AvgPool3d) and isinstance(idm[0], AvgPool3d):
             cfg_h = [(m[3].kernel_size, m[3].stride, m[3].padding)] * len(xs)
             cfg_x = [(idm[0].kernel_size, idm[0].stride, idm[0].padding)] * len(xs)
-            ss = TF.conv_group(TF.avg_pool3d_group(xs, cfg_x), idm[1].weight, idm[1].bias)
+            ss = TF.conv_group(TF.avg_pool3d_group(xs_skip, cfg_x), idm[1].weight, idm[1].bias)
             hs = TF.avg_pool3d_group(hs, cfg_h, adds=ss)                       # pool + residual add, all levels, one launch
         else:
-            ss = TF.conv_group([idm[0](x) for x in xs], idm[1].weight, idm[1].bias)
+            ss = TF.conv_group([idm[0](x) for x in xs_skip], idm[1].weight, idm[1].bias)
             hs = [TF.add(s_, m[3](h)) for s_, h in zip(ss, hs)]
         for d in self.down:
             if isinstance(d, DownBlock):
