@@ -1515,6 +1515,9 @@ class BmmG(Function):
         dAs, dBs = [None] * n, [None] * n
         la = [i for i in _live(Gs) if ctx.needs_input_grad[2 + i]]
         lb = [i for i in _live(Gs) if ctx.needs_input_grad[2 + n + i]]
+        Gb = Gs
+        if la and lb and torch.is_grad_enabled():     # recorded backward: dL/dC feeds both products — grouped fork
+            Gs, Gb = _fork_some(list(Gs))
         if la:        # dA = G @ B'^T (ta = 0)  |  B' @ G^T (ta = 1)
             X = [Gs[i] if not cfgs[i][0] else Bs[i] for i in la]
             Y = [Bs[i] if not cfgs[i][0] else Gs[i] for i in la]
@@ -1522,8 +1525,8 @@ class BmmG(Function):
             for i, r in zip(la, BmmG.apply(c, len(la), *(X + Y))):
                 dAs[i] = r
         if lb:        # dB = A'^T @ G (tb = 0)  |  G^T @ A' (tb = 1)
-            X = [As[i] if not cfgs[i][1] else Gs[i] for i in lb]
-            Y = [Gs[i] if not cfgs[i][1] else As[i] for i in lb]
+            X = [As[i] if not cfgs[i][1] else Gb[i] for i in lb]
+            Y = [Gb[i] if not cfgs[i][1] else As[i] for i in lb]
             c = tuple((not cfgs[i][0], False) if not cfgs[i][1] else (True, cfgs[i][0]) for i in lb)
             for i, r in zip(lb, BmmG.apply(c, len(lb), *(X + Y))):
                 dBs[i] = r
@@ -1605,9 +1608,11 @@ class ScaleG(Function):
         live = _live(gs)
         d_s, d_as = None, [None] * len(as_)
         if live:
-            lg = [gs[i] for i in live]
+            lg = lg2 = [gs[i] for i in live]
+            if ctx.needs_input_grad[0] and torch.is_grad_enabled():      # recorded backward: the gradients feed the dot and the scale
+                lg, lg2 = fork_group(lg)
             if ctx.needs_input_grad[0]:
-                d_s = DotG.apply(len(live), *(lg + [as_[i] for i in live]))
+                d_s = DotG.apply(len(live), *(lg2 + [as_[i] for i in live]))
             for i, r in zip(live, ScaleG.apply(s, *lg)):
                 d_as[i] = r
         return (d_s,) + tuple(d_as)
