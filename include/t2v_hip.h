@@ -347,9 +347,12 @@ int t2v_argmax_rows(const float* x, int32_t* idx, int64_t rows, int V, void* str
  *   T2V_MJ_ROWSUM           out[row] = sum_s a[row][s]                  n = rows, d0 = S (resnet3d.py:48 over all levels)
  *   T2V_MJ_ROWBCAST         out[row][s] = a[row]                        its adjoint
  *   T2V_MJ_ADD              out = a + b (+ c when c != NULL)            n = elements (gradient sums where an activation feeds
- *                                                                       several consumers: one launch for all pyramid levels) */
+ *                                                                       several consumers: one launch for all pyramid levels)
+ *   T2V_MJ_CATLERP          out = [a; b] (cat along the batch), out2 (optional) = c[row] * a + (1 - c[row]) * b
+ *                                                                       n = elements of a, d0 = elements per row (cond_gan.py:121-154 +
+ *                                                                       losses.py:146: the D step's real||fake batch and x-hat per level) */
 enum { T2V_MJ_SCALE = 1, T2V_MJ_SCALE_ADD, T2V_MJ_DOT, T2V_MJ_MAXPOOL, T2V_MJ_MAXSCATTER, T2V_MJ_MAXGATHER, T2V_MJ_SOFTMAX,
-       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST, T2V_MJ_ADD };
+       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST, T2V_MJ_ADD, T2V_MJ_CATLERP };
 typedef struct t2v_multi_job {
     const void* a; const void* b; const void* c; void* out; void* out2;
     int64_t n;
@@ -362,6 +365,12 @@ int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const float* scalar_
 /* RSGAN (losses.py:79-85): loss = mean softplus(-(a-b)) ; ga = -sigmoid(-(a-b))/n * gscale, gb = -ga. */
 int t2v_rsgan(const float* a, const float* b, float* loss, int n, void* stream);
 int t2v_rsgan_bwd(const float* a, const float* b, const float* gloss, float* ga, float* gb, int n, void* stream);
+/* mean over up to 8 pyramid levels of the relativistic loss (cond_gan.py:121-154: RSGANLoss per level, then the mean) in ONE
+   launch, and one for its gradient. jobs[i]: a, b = the two logit vectors of level i (n elements); backward: out / out2 = the
+   gradients w.r.t. a / b (either may be NULL), gl = dL/dloss (device scalar). Same arithmetic order as t2v_rsgan per level +
+   t2v_scalar_combine with weights 1/L. */
+int t2v_rsgan_mean_multi(const t2v_multi_job* jobs, int njobs, float* loss, void* stream);
+int t2v_rsgan_mean_multi_bwd(const t2v_multi_job* jobs, int njobs, const float* gl, void* stream);
 /* The rest of the loss zoo on D's logits (losses.py:19-68,87-133). kind: 1 VanillaGanLoss (BCE, labels wired as
    losses.py:27-28: fake->1, real->0), 2 HingeGanLoss(margin), 3 WassersteinGanLoss, 4 RaSGANLoss, 5 RaLSGANLoss;
    side 0 = discrim_loss, 1 = gen_loss. `real` may be NULL where the loss ignores it (gen side of kinds 1-3).

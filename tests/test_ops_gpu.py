@@ -505,6 +505,40 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
+def test_rsgan_mean_over_levels_is_the_per_level_loss_and_mean_bit_for_bit():
+    """`t2v_rsgan_mean_multi[_bwd]`: RSGANLoss of every pyramid level and their mean (cond_gan.py:121-154) in one launch each
+    way; the same numbers, bit for bit, as `rsgan` per level + `scalar_mean`, and torch's BCEWithLogits within rounding."""
+    from txt2vid_amd import functional as TF
+    ns = [64, 32, 16, 7]
+    a = [rnd(40 + i, n, 1).to(dev()).requires_grad_(True) for i, n in enumerate(ns)]
+    b = [rnd(50 + i, n, 1).to(dev()).requires_grad_(i != 2) for i, n in enumerate(ns)]
+    one = TF.rsgan_mean_levels(a, b)
+    ref = TF.scalar_mean([TF.rsgan(x, y) for x, y in zip(a, b)])
+    assert torch.equal(one, ref)
+    live = a + [t for t in b if t.requires_grad]
+    g1 = torch.autograd.grad(one * 1.7, live)
+    g2 = torch.autograd.grad(ref * 1.7, live)
+    assert all(torch.equal(u, v) for u, v in zip(g1, g2))
+    tref = sum(F.binary_cross_entropy_with_logits(x.detach().cpu() - y.detach().cpu(), torch.ones(n, 1)) for x, y, n in zip(a, b, ns)) / len(ns)
+    close(one, tref, rtol=1e-6, atol=1e-6)
+
+
+def test_cat_lerp_group_builds_the_d_step_inputs_in_one_launch():
+    """`T2V_MJ_CATLERP`: torch.cat((real, fake)) and alpha*real + (1-alpha)*fake (losses.py:146) for every pyramid level."""
+    from txt2vid_amd import functional as TF
+    shapes = [(4, 1, 8, 8, 8), (2, 1, 4, 16, 16), (1, 3, 2, 5, 7)]
+    reals = [rnd(20 + i, *s) for i, s in enumerate(shapes)]
+    fakes = [rnd(30 + i, *s) for i, s in enumerate(shapes)]
+    alphas = [torch.rand(s[0]) for s in shapes]
+    rfs, xhs = TF.cat_lerp_group([t.to(dev()) for t in reals], [t.to(dev()) for t in fakes], [a.to(dev()) for a in alphas])
+    for r, f, a, rf, xh in zip(reals, fakes, alphas, rfs, xhs):
+        assert torch.equal(rf.cpu(), torch.cat((r, f)))
+        av = a.view(-1, *([1] * (r.dim() - 1)))
+        close(xh, av * r + (1 - av) * f, rtol=1e-6, atol=1e-6)
+    rfs, xhs = TF.cat_lerp_group([t.to(dev()) for t in reals], [t.to(dev()) for t in fakes])
+    assert xhs is None and all(torch.equal(rf.cpu(), torch.cat((r, f))) for r, f, rf in zip(reals, fakes, rfs))
+
+
 def test_fork_group_sums_gradients_in_one_launch_first_and_second_order():
     """`fork_group`: two aliases per tensor whose gradients are summed by ONE grouped launch (`T2V_MJ_ADD`) instead of one
     autograd-engine add per tensor; members that need no gradient pass through; closed under double backward."""

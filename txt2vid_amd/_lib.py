@@ -131,6 +131,8 @@ SIGNATURES = {
     't2v_upsample2x': [_P, _P, _L, _I, _I, _P],
     't2v_upsample2x_bwd': [_P, _P, _L, _I, _I, _P],
     't2v_upsample2x_add': [_P, _P, _P, _L, _I, _I, _P],
+    't2v_rsgan_mean_multi': [_P, _I, _P, _P],
+    't2v_rsgan_mean_multi_bwd': [_P, _I, _P, _P],
     't2v_bn_ws_floats': [_I, _I, _L],
     't2v_bn_stats': [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
     't2v_bn_apply': [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],

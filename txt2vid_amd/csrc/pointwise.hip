@@ -1513,6 +1513,23 @@ __global__ __launch_bounds__(256) void mj_relu_mask_k(const MultiBatch tb) {
     const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
     for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) o[i] = x[i] > 0.f ? g[i] : 0.f;
 }
+// the discriminator step's inputs of one pyramid level in one pass over the real and the generated clips:
+// out = [a; b] (torch.cat along the batch) and, when out2 != NULL, out2 = alpha * a + (1 - alpha) * b with alpha = c[row]
+// (the gradient penalty's interpolates, losses.py:146; same expression as lerp_rows_k). n = elements of a, d0 = elements per row
+__global__ __launch_bounds__(256) void mj_catlerp_k(const MultiBatch tb) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b; const float* al = (const float*)q.c;
+    float* o = (float*)q.out; float* o2 = (float*)q.out2;
+    const long S = q.d0 > 0 ? q.d0 : 1;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) {
+        const float rv = a[i], fv = b[i];
+        o[i] = rv;
+        o[q.n + i] = fv;
+        if (o2) { const float w = al[i / S]; o2[i] = w * rv + (1.f - w) * fv; }
+    }
+}
 // out = a + b (+ c): the gradient sums of a grouped fork (one launch for all members instead of one ATen add per member)
 __global__ __launch_bounds__(256) void mj_add_k(const MultiBatch tb) {
     const int ji = mj_find(tb);
@@ -1707,6 +1724,9 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
             case T2V_MJ_ADD:
                 if (!q.b || !q.out) return T2V_EINVAL;
                 nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_CATLERP:
+                if (!q.b || !q.out || (q.out2 && (!q.c || q.d0 < 1))) return T2V_EINVAL;
+                nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
             case T2V_MJ_ROWSUM:
                 if (!q.out || q.d0 < 1) return T2V_EINVAL;
                 nb = (q.n + 3) / 4; break;
@@ -1743,6 +1763,7 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
         case T2V_MJ_BMM: T2V_LAUNCH(mj_bmm_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_RELU_MASK: T2V_LAUNCH(mj_relu_mask_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_ADD: T2V_LAUNCH(mj_add_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_CATLERP: T2V_LAUNCH(mj_catlerp_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_ROWSUM: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 0); break;
         case T2V_MJ_ROWBCAST: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 1); break;
     }
@@ -1776,6 +1797,68 @@ extern "C" int t2v_rsgan(const float* a, const float* b, float* loss, int n, voi
 extern "C" int t2v_rsgan_bwd(const float* a, const float* b, const float* gl, float* ga, float* gb, int n, void* st) {
     if (!a || !b || !gl || n < 1) return T2V_EINVAL;
     T2V_LAUNCH(rsgan_bwd_k, dim3(nblocks(n)), dim3(256), 0, S_(st), a, b, gl, ga, gb, n);
+    return launch_status();
+}
+
+// The mean over the pyramid levels of the relativistic loss (cond_gan.py:121-154: loss per level, then the mean) in one launch
+// and one for its gradient: same arithmetic, in the same order, as rsgan_k per level + scalar_combine_k with weights 1/L.
+__global__ __launch_bounds__(256) void rsgan_mean_multi_k(const MultiBatch tb, float* loss) {
+    __shared__ float red[4];
+    const float w = 1.0f / (float)tb.n;
+    float total = 0.f;
+    for (int l = 0; l < tb.n; ++l) {
+        const float* a = (const float*)tb.j[l].a; const float* b = (const float*)tb.j[l].b;
+        const int n = (int)tb.j[l].n;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) acc += softplus(-(a[i] - b[i]));
+        const float s = block_sum(acc, red);
+        total += w * (s / (float)n);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = total;
+}
+__global__ __launch_bounds__(256) void rsgan_mean_multi_bwd_k(const MultiBatch tb, const float* gl) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b;
+    float* ga = (float*)q.out; float* gb = (float*)q.out2;
+    const float gw = gl[0] * (1.0f / (float)tb.n);          // the mean's share of dL (ScalarCombine's adjoint)
+    const float sc = gw / (float)q.n;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < q.n; i += 256) {
+        const float d = a[i] - b[i];
+        const float g = -sc / (1.f + expf(d));
+        if (ga) ga[i] = g;
+        if (gb) gb[i] = -g;
+    }
+}
+static int rsgan_multi_table(const t2v_multi_job* jobs, int njobs, MultiBatch& tb, long& blocks) {
+    if (!jobs || njobs < 1 || njobs > MJ_MAX) return T2V_EINVAL;
+    blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].a || !jobs[i].b || jobs[i].n < 1 || jobs[i].n > 0x7fffffffL) return T2V_EINVAL;
+        tb.j[i] = jobs[i];
+        tb.begin[i] = (int)blocks;
+        blocks += (jobs[i].n + MJ_CHUNK - 1) / MJ_CHUNK;
+    }
+    for (int i = njobs; i <= MJ_MAX; ++i) tb.begin[i] = (int)blocks;
+    for (int i = njobs; i < MJ_MAX; ++i) tb.j[i] = tb.j[0];
+    tb.n = njobs;
+    return T2V_OK;
+}
+extern "C" int t2v_rsgan_mean_multi(const t2v_multi_job* jobs, int njobs, float* loss, void* st) {
+    MultiBatch tb;
+    long blocks;
+    if (!loss || rsgan_multi_table(jobs, njobs, tb, blocks)) return T2V_EINVAL;
+    T2V_LAUNCH(rsgan_mean_multi_k, dim3(1), dim3(256), 0, S_(st), tb, loss);
+    return launch_status();
+}
+// jobs[i].out / out2: gradients w.r.t. a / b (either may be NULL)
+extern "C" int t2v_rsgan_mean_multi_bwd(const t2v_multi_job* jobs, int njobs, const float* gl, void* st) {
+    MultiBatch tb;
+    long blocks;
+    if (!gl || rsgan_multi_table(jobs, njobs, tb, blocks)) return T2V_EINVAL;
+    T2V_LAUNCH(rsgan_mean_multi_bwd_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb, gl);
     return launch_status();
 }
 

@@ -1312,7 +1312,7 @@ def scale_add(gamma, o, x):
 # members that receive no gradient (None) are left out of the backward launches.
 # ------------------------------------------------------------------------------------------------
 (MJ_SCALE, MJ_SCALE_ADD, MJ_DOT, MJ_MAXPOOL, MJ_MAXSCATTER, MJ_MAXGATHER, MJ_SOFTMAX, MJ_SOFTMAX_BWD, MJ_SOFTMAX_BWD_BWD_Y, MJ_BMM,
- MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD) = range(1, 15)
+ MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD, MJ_CATLERP) = range(1, 16)
 
 
 def _mj(op, jobs, scalar=None, dot_out=None):
@@ -2074,6 +2074,49 @@ def rsgan(a, b):
     return RSGan.apply(a, b)
 
 
+class RSGanMeanG(Function):
+    """mean over n pairs (a_l, b_l) of mean softplus(-(a_l - b_l)): the relativistic loss of every pyramid level and their mean
+    (cond_gan.py:121-154) in one launch; bit-identical to `rsgan` per level + `scalar_mean`. args: n, a_0.., b_0.."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        from ._lib import MultiJob
+        a, b = [_c(t) for t in ts[:n]], [_c(t) for t in ts[n:]]
+        if any(x.numel() != y.numel() for x, y in zip(a, b)):
+            raise ValueError('rsgan_mean_levels: logit vectors of a level differ in size')
+        arr = (MultiJob * n)()
+        for q, x, y in zip(arr, a, b):
+            q.a, q.b, q.n = x.data_ptr(), y.data_ptr(), x.numel()
+        out = torch.empty((), device=a[0].device, dtype=torch.float32)
+        check(lib().t2v_rsgan_mean_multi(arr, n, _p(out), _stream()), 't2v_rsgan_mean_multi')
+        ctx.save_for_backward(*a, *b)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from ._lib import MultiJob
+        n = ctx.n
+        saved = ctx.saved_tensors
+        a, b = saved[:n], saved[n:]
+        g = _c(g)
+        ga = [torch.empty_like(x) if ctx.needs_input_grad[1 + i] else None for i, x in enumerate(a)]
+        gb = [torch.empty_like(y) if ctx.needs_input_grad[1 + n + i] else None for i, y in enumerate(b)]
+        arr = (MultiJob * n)()
+        for q, x, y, u, v in zip(arr, a, b, ga, gb):
+            q.a, q.b, q.n = x.data_ptr(), y.data_ptr(), x.numel()
+            q.out = u.data_ptr() if u is not None else None
+            q.out2 = v.data_ptr() if v is not None else None
+        check(lib().t2v_rsgan_mean_multi_bwd(arr, n, _p(g), _stream()), 't2v_rsgan_mean_multi_bwd')
+        return (None,) + tuple(ga) + tuple(gb)
+
+
+def rsgan_mean_levels(as_, bs):
+    as_, bs = list(as_), list(bs)
+    return RSGanMeanG.apply(len(as_), *(as_ + bs))
+
+
 LOSS_KINDS = {'vanilla': 1, 'hinge': 2, 'wasserstein': 3, 'rasgan': 4, 'ralsgan': 5}
 
 
@@ -2114,6 +2157,25 @@ def lerp_rows(alpha, xr, xf):
     out = torch.empty_like(xr)
     check(lib().t2v_lerp_rows(_p(alpha), _p(xr), _p(xf), _p(out), rows, xr.numel() // rows, _stream()), 't2v_lerp_rows')
     return out
+
+
+def cat_lerp_group(reals, fakes, alphas=None):
+    """The discriminator step's inputs for all pyramid levels in ONE launch: `[torch.cat((r, f)) for r, f in levels]` and,
+    with `alphas` (one [b] tensor per level), the gradient penalty's interpolates `a * r + (1 - a) * f` as well. No autograd:
+    for detached clips only (the D step)."""
+    reals, fakes = [_c(t) for t in reals], [_c(t) for t in fakes]
+    if any(t.requires_grad for t in reals + fakes) and torch.is_grad_enabled():
+        raise ValueError('cat_lerp_group takes detached clips')
+    rfs = [torch.empty((r.shape[0] + f.shape[0],) + tuple(r.shape[1:]), device=r.device, dtype=torch.float32) for r, f in zip(reals, fakes)]
+    xhs = [torch.empty_like(r) for r in reals] if alphas is not None else [None] * len(reals)
+    jobs = []
+    for i, (r, f) in enumerate(zip(reals, fakes)):
+        if r.shape != f.shape:
+            raise ValueError('real / generated clip shapes differ: %s vs %s' % (tuple(r.shape), tuple(f.shape)))
+        jobs.append(dict(a=r, b=f, c=_c(alphas[i]) if alphas is not None else None, out=rfs[i], out2=xhs[i], n=r.numel(),
+                         d0=r.numel() // r.shape[0]))
+    _mj(MJ_CATLERP, jobs)
+    return rfs, (xhs if alphas is not None else None)
 
 
 class RowSqNorm(Function):
@@ -2293,7 +2355,11 @@ def time_to_batch(hs):
 
 
 def frames_to_video(r, T):
-    """[b*T,C,H,W] -> [b,C,T,H,W]  (split_frames + time_first, gen.py:117-118)."""
+    """[b*T,C,H,W] -> [b,C,T,H,W]  (split_frames + time_first, gen.py:117-118). With one channel (or one frame) the two layouts
+    are the same memory: a view, no kernel."""
+    bT, Cc, H, W = r.shape
+    if (Cc == 1 or T == 1) and r.is_contiguous():
+        return r.view(bT // T, Cc, T, H, W)
     return _FramesToVideo.apply(r, T)
 
 

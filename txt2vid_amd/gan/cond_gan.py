@@ -8,6 +8,17 @@ from .. import functional as TF
 from .losses import gradient_penalty
 
 
+
+def _mean_over_levels(loss, fakes, reals):
+    """mean over the pyramid levels of loss(fake, real) (cond_gan.py:121-154). A loss object that offers `<name>_levels`
+    (RSGANLoss) gets all levels in one launch; same value as the per-level calls + `scalar_mean`."""
+    fakes, reals = list(fakes), list(reals)
+    owner = getattr(loss, '__self__', None)
+    fn = getattr(owner, getattr(loss, '__name__', '') + '_levels', None) if owner is not None else None
+    if fn is not None and 1 <= len(fakes) <= TF.MAX_GROUPS:
+        return fn(fakes=fakes, reals=reals)
+    return TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(fakes, reals)])
+
 class CondGan(object):
     def __init__(self, gen=None, discrims=None, cond_encoder=None, discrim_names=None, sample_mapping=None,
                  discrim_lambdas=None, gp_scale=1.0):
@@ -72,14 +83,20 @@ class CondGan(object):
         path above; the GP alphas are drawn from the host generator in the same stream position."""
         n = len(real)
         cond = real_cond is not None and fake_cond is not None
-        rf = [TF.cat_batch(r, f) for r, f in zip(real, fake)]
-        conds = [TF.cat_batch(c, c) for c in real_cond] if cond else None
+        a_dev = [TF.draws.alpha(real[i].size(0), real[i].dim(), real[i].device) for i in range(n)] if gp_lambda > 0 else None
         xhs, chs = [], None
-        if gp_lambda > 0:
-            a_dev = [TF.draws.alpha(real[i].size(0), real[i].dim(), real[i].device) for i in range(n)]
-            xhs = [TF.lerp_rows(a_dev[i], real[i].detach(), fake[i].detach()).requires_grad_(True) for i in range(n)]
-            if cond:
-                chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
+        if not any(t.requires_grad for t in list(real) + list(fake)) and all(r.shape == f.shape for r, f in zip(real, fake)):
+            # detached clips (the D step): the real||fake batches and the interpolates of all levels in ONE launch
+            rf, xh = TF.cat_lerp_group(real, fake, a_dev)
+            if gp_lambda > 0:
+                xhs = [t.requires_grad_(True) for t in xh]
+        else:
+            rf = [TF.cat_batch(r, f) for r, f in zip(real, fake)]
+            if gp_lambda > 0:
+                xhs = [TF.lerp_rows(a_dev[i], real[i].detach(), fake[i].detach()).requires_grad_(True) for i in range(n)]
+        conds = [TF.cat_batch(c, c) for c in real_cond] if cond else None
+        if gp_lambda > 0 and cond:
+            chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
         res = discrim(x=rf + xhs, cond=(conds + chs) if (cond and xhs) else conds, xbar=None)
         both, gp_res = res[:n], res[n:]
         b = [r.size(0) for r in real]
@@ -89,14 +106,14 @@ class CondGan(object):
             # D(real, mismatched captions): second head on the real half's trunk features
             trunk = discrim.sub_discrims
             c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
-            lu = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(u_f, u_r)])
-            l1 = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(c_f, c_r)])
-            l2 = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(c_ic, c_r)])
+            lu = _mean_over_levels(loss, u_f, u_r)
+            l1 = _mean_over_levels(loss, c_f, c_r)
+            l2 = _mean_over_levels(loss, c_ic, c_r)
             l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
             real_pred = [(u_r[i], c_r[i], TF.head_rows(both[i][2], b[i])) for i in range(n)]
             fake_pred = None
         else:
-            l = TF.scalar_mean([loss(fake=f, real=r) for f, r in zip(u_f, u_r)])
+            l = _mean_over_levels(loss, u_f, u_r)
             real_pred, fake_pred = list(u_r), list(u_f)
         if gp_lambda > 0:
             outs = []
@@ -134,10 +151,10 @@ class CondGan(object):
                     p.requires_grad_(True)
             fk, rl = res[:n], res[n:]
             if cond is None:
-                losses.append(TF.scalar_mean([loss(fake=ff[0], real=rr[0].detach()) for ff, rr in zip(fk, rl)]))
+                losses.append(_mean_over_levels(loss, [ff[0] for ff in fk], [rr[0].detach() for rr in rl]))
             else:
-                lu = TF.scalar_mean([loss(fake=ff[0], real=rr[0].detach()) for ff, rr in zip(fk, rl)])
-                lc = TF.scalar_mean([loss(fake=ff[1], real=rr[1].detach()) for ff, rr in zip(fk, rl)])
+                lu = _mean_over_levels(loss, [ff[0] for ff in fk], [rr[0].detach() for rr in rl])
+                lc = _mean_over_levels(loss, [ff[1] for ff in fk], [rr[1].detach() for rr in rl])
                 losses.append(TF.scalar_sum([lc, lu], weights=[0.5, 0.5]))
         return self._discrim_weighted_sum(losses)
 

@@ -38,6 +38,13 @@ class RSGANLoss(object):
     def gen_loss(self, fake=None, real=None):
         return TF.rsgan(fake, real)
 
+    # all pyramid levels at once (cond_gan._mean_over_levels): mean over levels of the per-level loss, one launch
+    def discrim_loss_levels(self, fakes=None, reals=None):
+        return TF.rsgan_mean_levels(reals, fakes)
+
+    def gen_loss_levels(self, fakes=None, reals=None):
+        return TF.rsgan_mean_levels(fakes, reals)
+
 
 class _ZooLoss(object):
     """A loss of the zoo = one `t2v_gan_loss` launch per call (and one for its gradient)."""
