@@ -63,3 +63,55 @@ def test_plan_queries_reject_bad_geometry():
     assert lib().t2v_conv_fwd_plan(arr, 1, 64, 64, 0, out) < 0             # all-zero member
     assert lib().t2v_conv_wgrad_plan(arr, 1, 64, 64, 3, 3, 3, out) < 0
     assert lib().t2v_conv_fwd_plan(arr, 0, 64, 64, 0, out) < 0
+
+
+def _plans_in_child(env):
+    """Forward and weight-gradient plans of three probe shapes in a FRESH process (the tunables are read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import json, sys; sys.path.insert(0, %r); import conv_cases as cc\n"
+        "small = [(2, 4, 16, 16)]                     # M = 2048: 8 tiles of 256\n"
+        "mid = [(12, 8, 16, 16)]                      # M = 24576: 192 tiles of 128\n"
+        "big = cc.d_step_members(32, 0)               # M = 393216\n"
+        "print(json.dumps({'small': cc.fwd_plan(small, 64, 64, (3, 3, 3)), 'mid': cc.fwd_plan(mid, 64, 64, (3, 3, 3)),\n"
+        "                  'one': cc.fwd_plan([(2, 4, 8, 8)], 256, 64, (1, 1, 1)), 'deep': cc.fwd_plan([(2, 1, 4, 4)], 256, 256, (3, 3, 3)),\n"
+        "                  'wbig': cc.wgrad_plan(big, 64, 64, (3, 3, 3)), 'wgp': cc.wgrad_plan(cc.gp_members(32, 0), 64, 64, (3, 3, 3))}))\n"
+    ) % os.path.dirname(os.path.abspath(__file__))
+    full = dict(os.environ)
+    for k in list(full):
+        if k.startswith('T2V_'):
+            del full[k]
+    full.update(env)
+    out = subprocess.run([sys.executable, '-c', code], env=full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return json.loads(out.stdout.decode().strip().splitlines()[-1])
+
+
+def test_environment_tunables_move_the_plan():
+    """Every plan-visible override of `struct Tunables` (conv.hip) changes the plan the way its comment says, and the defaults
+    are what the benchmark runs on (T2V_NO_OCC_PAD acts at launch time only: the resident-workgroup padding of the 256-voxel
+    tile, covered on the GPU by the benchmark-size parity cases)."""
+    base = _plans_in_child({})
+    assert base['small'][:4] == ['strip3', 64, 64, 32] and base['small'][7] > 1          # 32 tiles: 64-voxel tiles, split K
+    assert base['mid'][:4] == ['strip3', 64, 64, 32] and base['mid'][7] == 1             # 384 tiles of 64: no split
+    assert base['one'][7] == 1                                                          # 1x1x1, K = 8 chunks: never split
+    assert base['deep'][7] > 1
+    assert base['wbig'][0] == 'rows3' and base['wbig'][1] == 256                         # capped by T2V_WGRAD_SCAP
+    assert base['wgp'][5] <= 2048                                                       # 2052 workgroups -> 2043 (quantised)
+    # tile thresholds
+    assert _plans_in_child({'T2V_TILE256_MIN': '1'})['small'][:4] == ['strip3', 256, 64, 16]
+    assert _plans_in_child({'T2V_TILE128_MIN': '1', 'T2V_TILE256_MIN': '100000'})['small'][:4] == ['strip3', 128, 64, 32]
+    # split-K knobs
+    assert _plans_in_child({'T2V_NOSPLIT_CHUNKS': '0'})['one'][7] > 1
+    assert _plans_in_child({'T2V_NOSPLIT_CHUNKS': '1000'})['deep'][7] == 1
+    forced = _plans_in_child({'T2V_FORCE_S': '3'})
+    assert forced['small'][7] == 3 and forced['mid'][7] == 3
+    # strip kernels off: the plain implicit-GEMM instantiation of the same tile
+    assert _plans_in_child({'T2V_NO_STRIP': '1'})['mid'][:4] == ['igemm', 64, 64, 32]
+    # weight-gradient split count
+    assert _plans_in_child({'T2V_WGRAD_SCAP': '64'})['wbig'][1] == 64
+    assert _plans_in_child({'T2V_WGRAD_TARGET': '512'})['wbig'][5] <= 600
+    assert _plans_in_child({'T2V_WGRAD_NOQ': '1'})['wgp'][5] == 2052

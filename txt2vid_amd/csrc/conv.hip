@@ -1590,6 +1590,31 @@ static bool thin_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout
     return (long)nslots * Cin * Cout <= THIN_MAX_W;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Launch-heuristic tunables, in ONE place. The defaults are the measured optima on MI355X. The environment
+// overrides exist for developer sweeps (tools/conv_suite.py) and for tests that force an instantiation onto a small input;
+// tests/test_conv_plan.py::test_environment_tunables_move_the_plan checks every one of them through the plan queries.
+// Read once, at the first launch or plan query of the process.
+// ------------------------------------------------------------------------------------------------
+struct Tunables {
+    long tile128_min;      // T2V_TILE128_MIN   (768)  128-voxel tiles from this many tiles on, else 64
+    long tile256_min;      // T2V_TILE256_MIN   (512)  256-voxel tiles from this many tiles on
+    long nosplit_chunks;   // T2V_NOSPLIT_CHUNKS  (8)  no split-K for reductions of at most this many K chunks
+    long force_splits;     // T2V_FORCE_S         (0)  > 0: this split-K count for every forward / data-gradient launch
+    bool strip;            // T2V_NO_STRIP unset       strip (three-dx-taps-per-row) kernels enabled
+    bool occ_pad;          // T2V_NO_OCC_PAD unset     resident-workgroup choice of the 256-voxel tile (occupancy_pad)
+    long wgrad_target;     // T2V_WGRAD_TARGET    (0)  weight-gradient workgroups to aim at; 0: 3072 for >= 8192 chunks, else 2048
+    long wgrad_scap;       // T2V_WGRAD_SCAP    (256)  upper bound of the weight-gradient k-split count
+    bool wgrad_quantise;   // T2V_WGRAD_NOQ unset      drop a nearly empty last round of weight-gradient workgroups
+};
+static long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+static const Tunables& tun() {
+    static const Tunables t = {env_long("T2V_TILE128_MIN", 768), env_long("T2V_TILE256_MIN", 512), env_long("T2V_NOSPLIT_CHUNKS", 8),
+                               env_long("T2V_FORCE_S", 0), getenv("T2V_NO_STRIP") == nullptr, getenv("T2V_NO_OCC_PAD") == nullptr,
+                               env_long("T2V_WGRAD_TARGET", 0), env_long("T2V_WGRAD_SCAP", 256), getenv("T2V_WGRAD_NOQ") == nullptr};
+    return t;
+}
+
 struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; };
 
 static bool group_ok(const t2v_conv_group& g, bool need_ptrs) {
@@ -1622,12 +1647,10 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     else {
         p.bn = 64;
         const long t128 = ((Mtot + 127) / 128) * ((Cout + 63) / 64);
-        static const long tile128_min = getenv("T2V_TILE128_MIN") ? atol(getenv("T2V_TILE128_MIN")) : 768;
-        p.bm = (t128 >= tile128_min) ? 128 : 64;
+        p.bm = (t128 >= tun().tile128_min) ? 128 : 64;
         // 256 x 64 tiles, K chunks of 16, one wave = 64 co x 64 m (four accumulator chains, one LDS read per MFMA) for the
         // launches big enough to fill the chip with them (+3-6 % over the 128 x 64 tile there)
-        static const long tile256_min = getenv("T2V_TILE256_MIN") ? atol(getenv("T2V_TILE256_MIN")) : 512;
-        if (p.fast && (Cin % 16) == 0 && ((Mtot + 255) / 256) * ((Cout + 63) / 64) >= tile256_min) { p.bm = 256; p.bk = 16; }
+        if (p.fast && (Cin % 16) == 0 && ((Mtot + 255) / 256) * ((Cout + 63) / 64) >= tun().tile256_min) { p.bm = 256; p.bk = 16; }
         if (p.bk > 32 && p.bm != 256) p.bk = 32;   // two LDS stages: 48 KB (128x64) / 32 KB (64x64) per workgroup
     }
     if (!p.fast) p.bk = 16;
@@ -1651,8 +1674,7 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     long S = 1;
     // a reduction of <= 8 chunks (the 1x1 convolutions up to 256 input channels) is not worth a split: the second launch costs
     // more than the idle CUs (measured: -26 launches, -0.07 ms per iteration)
-    static const long nosplit_chunks = getenv("T2V_NOSPLIT_CHUNKS") ? atol(getenv("T2V_NOSPLIT_CHUNKS")) : 8;
-    if (p.tiles < 384 && min_chunks > nosplit_chunks) {
+    if (p.tiles < 384 && min_chunks > tun().nosplit_chunks) {
         S = (768 + p.tiles - 1) / p.tiles;
         long maxS = min_chunks / 2;
         if (S > maxS) S = maxS;
@@ -1660,7 +1682,7 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         while (S > 1 && (double)S * ot * 4.0 > 256e6) --S;   // keep the slab small (L2 / MALL resident)
         if (S < 1) S = 1;
     }
-    static const long force_S = getenv("T2V_FORCE_S") ? atol(getenv("T2V_FORCE_S")) : 0;     // developer knob (tools/conv_suite.py sweeps)
+    const long force_S = tun().force_splits;                                                  // developer knob (tools/conv_suite.py sweeps)
     if (force_S > 0) S = force_S > min_chunks / 2 ? (min_chunks / 2 > 0 ? min_chunks / 2 : 1) : force_S;
     p.S = (int)S;
     return true;
@@ -1692,7 +1714,6 @@ static bool strip_fits32(const GroupTable& tab, int Cin) {
     }
     return true;
 }
-static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
 
 // Which instantiation a (tile, chunk) choice ends up in: the strip variant (three dx taps from one staged strip) when the
 // members carry their taps in (row, dx) order. Shared by the launcher and by t2v_conv_fwd_plan. (`ks`: K-split wave layout of
@@ -1700,7 +1721,7 @@ static bool g_strip_enabled = getenv("T2V_NO_STRIP") == nullptr;
 struct ConvVariant { bool strip; int ks; bool s3; };
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
     ConvVariant v{false, 1, false};
-    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && g_strip_enabled && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
+    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && tun().strip && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
         v.strip = true;
         // tiles with 64 output channels (64 / 128 voxels x 32 channels, 256 voxels x 16 channels): all three dx taps per barrier
         // round (conv_igemm_strip3_kernel; +12-15 % over one dx per round on every one of them); 128 x 32 keeps the per-dx form
@@ -1728,8 +1749,7 @@ static int occupancy_pad(K kernel, OccInfo& info, long nwg) {
             info.occ = n; info.lds = (int)a.sharedSizeBytes; info.cus = cus;
         }
     }
-    static const bool off = getenv("T2V_NO_OCC_PAD") != nullptr;
-    if (info.occ < 3 || off) return 0;
+    if (info.occ < 3 || !tun().occ_pad) return 0;
     long best = -1;
     int pick = info.occ;
     for (int o = info.occ; o >= 2; --o) {                   // ties go to the higher occupancy
@@ -1965,8 +1985,7 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
     {
         ProfScope prof(5, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
-        static const bool strip16 = getenv("T2V_NO_STRIP") == nullptr;
-        if (strip16 && strip_ok(tab)) {
+        if (tun().strip && strip_ok(tab)) {
             if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
         } else if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
@@ -2908,8 +2927,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
     // workgroups to aim at: the kernels run 4 workgroups per CU (1024 resident); two to three "waves" of them balance the
     // uneven members best (measured: 1024 -> 918 us, 1536 -> 831, 2304 -> 734 on the stem layer; 2048 best on the mid-size ones)
-    static const long wg_env = getenv("T2V_WGRAD_TARGET") ? atol(getenv("T2V_WGRAD_TARGET")) : 0;
-    static const long s_cap = getenv("T2V_WGRAD_SCAP") ? atol(getenv("T2V_WGRAD_SCAP")) : 256;
+    const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
     const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : 2048);
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
@@ -2918,7 +2936,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     if (S > s_cap) S = s_cap;
     // wave quantisation: 1024 workgroups are resident at a time; a last round that is under a fifth full (2052 = 2 x 1024 + 4)
     // costs most of a round for little work: give those workgroups' chunks to the full rounds instead
-    static const bool no_q = getenv("T2V_WGRAD_NOQ") != nullptr;
+    const bool no_q = !tun().wgrad_quantise;
     const long rounds = (base * S) / 1024, tail = (base * S) % 1024;
     if (!no_q && rounds >= 1 && tail > 0 && tail * 5 <= 1024 && (rounds * 1024) / base >= 1) S = (rounds * 1024) / base;
     p.cps = (int)((nch + S - 1) / S);
