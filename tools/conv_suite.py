@@ -46,6 +46,9 @@ SUITE = [
     ('D down1 conv2 Gs', 128, 256, (3, 3, 3), cc.gp_members(32, 2) * 2),
     ('D down2 conv2 gp', 256, 512, (3, 3, 3), cc.gp_members(32, 3)),
     ('D down3 conv2 gp', 512, 1024, (3, 3, 3), cc.gp_members(32, 4)),
+    ('G up2a 256->128 8x8', 256, 128, (3, 3), [(512, 1, 8, 8)]),
+    ('G up1a 512->256 4x4', 512, 256, (3, 3), [(512, 1, 4, 4)]),
+    ('G up0a 1024->512 2x2', 1024, 512, (3, 3), [(512, 1, 2, 2)]),
     ('G up2 128x128 8x8', 128, 128, (3, 3), [(512, 1, 8, 8)]),
     ('G up1 256x256 4x4', 256, 256, (3, 3), [(512, 1, 4, 4)]),
     ('G up0 512x512 2x2', 512, 512, (3, 3), [(512, 1, 2, 2)]),

@@ -2928,7 +2928,9 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     // workgroups to aim at: the kernels run 4 workgroups per CU (1024 resident); two to three "waves" of them balance the
     // uneven members best (measured: 1024 -> 918 us, 1536 -> 831, 2304 -> 734 on the stem layer; 2048 best on the mid-size ones)
     const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
-    const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : 2048);
+    // (one uniform member — the generator's layers — balances perfectly in ONE round of resident workgroups: half the slab
+    // bytes and 5-10 % off the kernel against two rounds, measured on the six UpBlock shapes)
+    const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : (ngroups == 1 ? 1024 : 2048));
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
