@@ -1603,7 +1603,7 @@ struct Tunables {
     long force_splits;     // T2V_FORCE_S         (0)  > 0: this split-K count for every forward / data-gradient launch
     bool strip;            // T2V_NO_STRIP unset       strip (three-dx-taps-per-row) kernels enabled
     bool occ_pad;          // T2V_NO_OCC_PAD unset     resident-workgroup choice of the 256-voxel tile (occupancy_pad)
-    long wgrad_target;     // T2V_WGRAD_TARGET    (0)  weight-gradient workgroups to aim at; 0: 3072 for >= 8192 chunks, else 2048
+    long wgrad_target;     // T2V_WGRAD_TARGET    (0)  weight-gradient workgroups to aim at; 0: 1024 = one round of resident workgroups
     long wgrad_scap;       // T2V_WGRAD_SCAP    (256)  upper bound of the weight-gradient k-split count
     bool wgrad_quantise;   // T2V_WGRAD_NOQ unset      drop a nearly empty last round of weight-gradient workgroups
 };
@@ -2925,12 +2925,12 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     const long base = p.rows3 ? (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows
                     : (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
-    // workgroups to aim at: the kernels run 4 workgroups per CU (1024 resident); two to three "waves" of them balance the
-    // uneven members best (measured: 1024 -> 918 us, 1536 -> 831, 2304 -> 734 on the stem layer; 2048 best on the mid-size ones)
+    // workgroups to aim at: the kernels run 4 workgroups per CU, 1024 resident at a time. WHOLE rounds of them are what counts
+    // (measured on the stem layer, 8 ragged members: 1024 -> 732 us, 1536 -> 837, 2048 -> 743, 3072 -> 735; the same picture on the
+    // mid-size and the generator's layers), so ONE round: the fewest k-splits, i.e. the smallest slab (50 instead of 113 MB on the
+    // stem) and half the reduce time, at the same or a better kernel time.
     const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
-    // (one uniform member — the generator's layers — balances perfectly in ONE round of resident workgroups: half the slab
-    // bytes and 5-10 % off the kernel against two rounds, measured on the six UpBlock shapes)
-    const long wg_target = wg_env ? wg_env : (nch >= 8192 ? 3072 : (ngroups == 1 ? 1024 : 2048));
+    const long wg_target = wg_env ? wg_env : 1024;
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     long maxS = (nch + 7) / 8;                    // at least 8 chunks (256 voxels) per split
     if (S > maxS) S = maxS;
