@@ -79,7 +79,7 @@ def run(name, cin, cout, k, members):
             ms, fl, red = out[3] / iters, out[4] / iters, out[6] / iters
             res.append('%s %7.1f us %5.1f TF (+reduce %5.1f us)' % (what, ms * 1e3, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, red * 1e3))
         else:
-            ms, fl, red = out[0] / iters, out[1] / iters, out[12] / iters
+            ms, fl, red = (out[0] + out[15]) / iters, (out[1] + out[16]) / iters, out[12] / iters      # fp32 GEMM or (bf16 mode) the bf16 GEMM
             res.append('%s %7.1f us %5.1f TF%s' % (what, ms * 1e3, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0,
                                                    (' (+splitK %4.1f us)' % (red * 1e3)) if red > 0 else ''))
     M = sum(n * d * h * w for n, d, h, w in members)

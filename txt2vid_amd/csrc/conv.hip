@@ -1318,6 +1318,184 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip_kernel(const GroupT
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
 
+// STRIP3 form of the bf16-compute GEMM (see conv_igemm_strip3_kernel): one barrier round = the staged strip of a (kernel row,
+// 32-channel block) + the weights of its THREE dx taps = 6 (64-voxel tile) / 12 (128) bf16 MFMAs per wave, where the per-dx
+// kernel above ran 2 / 4 between two barriers. Member state and addressing as in the fp32 strip3 kernel: 32-bit byte offsets
+// through buffer loads (host: strip_fits32), lane tables read back with v_readlane, a zero ROW for the row-end lanes.
+// Single LDS stage, two barriers per round; the next round's gathers are issued right after the first.
+template <int BM>
+__global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const GroupTable tab, const __bf16* __restrict__ wpb,
+                                                                     const float* __restrict__ bias, float* __restrict__ slab,
+                                                                     const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int KPT = BKT * BM / 256;          // channels per thread of the strip (16 for BM = 128, 8 for 64)
+    constexpr int HT = BKT / KPT;                // threads that cover the 32 channels of ONE halo voxel
+    constexpr int ZROW = BM + 2;                 // the all-zero row
+    static_assert(NCO == 1 && NM >= 1 && (KPT == 16 || KPT == 8), "tile");
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[(BM + 3) * B16_KP];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * BN * B16_KP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W;
+    const int HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    const int ndx = gd.dx[0] < 0 ? 3 : 1;
+    const int nrow = ntaps / ndx;
+
+    const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
+    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    const int tab_widx = gd.widx[lane_t];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)M * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpb, 0, -1, 0x00020000);
+
+    const int ma_l = tid % BM, kq = tid / BM;
+    const bool halo_thread = tid < 2 * HT;
+    const int he = tid / HT, hq = tid % HT;          // halo: he = 0 left (voxel m0 - 1), 1 right (voxel m0 + BM)
+    uint32_t rowmask = 0, rowmask_h = 0;
+    uint32_t xbase = 0, xbase_h = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {
+            const int n = m_a / DHW, sp = m_a - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
+            }
+        }
+        const int m_h = he ? m0 + BM : m0 - 1;
+        if (halo_thread && m_h >= 0 && m_h < M) {
+            const int n = m_h / DHW, sp = m_h - n * DHW;
+            const int d = sp / HW, r = sp - d * HW;
+            const int h = r / W;
+            xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
+            for (int t = 0; t < nrow; ++t) {
+                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
+            }
+        }
+    }
+    bool can_l[NM], can_r[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int m = m0 + wm * WM + j * 32 + l31;
+        const int w_ = m % W;
+        can_l[j] = w_ > 0;
+        can_r[j] = w_ < W - 1;
+    }
+    const int wc_l = tid >> 2, wk_l = (tid & 3) * 8;
+    const bool w_ok = co0 + wc_l < Cout;
+    const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
+    const uint32_t xoff = (xbase + (uint32_t)(kq * KPT) * (uint32_t)DHW) * 4u, xoff_h = (xbase_h + (uint32_t)(hq * KPT) * (uint32_t)DHW) * 4u;
+    const uint32_t woff = w_ok ? (uint32_t)((co0 + wc_l) * Cin + wk_l) * 2u : 0u;
+
+    f32x16 acc[NCO][NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    float ra[KPT], rh[KPT];
+    bf16x8 rw8[3];
+    const int ncb = Cin / BKT;
+    const int nrounds = nrow * ncb;
+    const int rps = (nrounds + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * rps;
+    int q1 = q0 + rps;
+    if (q1 > nrounds) q1 = nrounds;
+    bool pend_av = false, pend_hv = false;
+
+    auto load_round = [&](int q) {
+        const int r_cur = q / ncb, cb = q - r_cur * ncb;
+        const int c0 = cb * BKT;
+        const int roff = __builtin_amdgcn_readlane(tab_roff, r_cur);
+        const int sx = c0 * DHW * 4;
+        pend_av = (rowmask >> r_cur) & 1u;
+        const uint32_t vo = xoff + (pend_av ? (uint32_t)roff : 0u);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, sx + j * 4 * DHW, 0));
+        if (halo_thread) {
+            pend_hv = (rowmask_h >> r_cur) & 1u;
+            const uint32_t vh = xoff_h + (pend_hv ? (uint32_t)roff : 0u);
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) rh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vh, sx + j * 4 * DHW, 0));
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < ndx) {                                        // (uniform)
+                const int sw = (__builtin_amdgcn_readlane(tab_widx, r_cur * ndx + d) * Cout * Cin + c0) * 2;
+                rw8[d] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, sw, 0));
+            }
+        }
+    };
+    auto put_row = [&](__bf16* dst, const float* v, bool ok) {
+#pragma unroll
+        for (int g = 0; g < KPT / 8; ++g) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)(ok ? fmaxf(v[g * 8 + j], relu_floor) : 0.f);
+            *reinterpret_cast<bf16x8*>(dst + g * 8) = o;
+        }
+    };
+    bf16x8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
+    auto stage = [&]() {
+        put_row(Xs + (1 + ma_l) * B16_KP + kq * KPT, ra, pend_av);
+        if (halo_thread) put_row(Xs + (he ? BM + 1 : 0) * B16_KP + hq * KPT, rh, pend_hv);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < ndx) *reinterpret_cast<bf16x8*>(Ws + d * (BN * B16_KP) + wc_l * B16_KP + wk_l) = w_ok ? rw8[d] : zero8;
+    };
+
+    if (tid < 4) *reinterpret_cast<bf16x8*>(Xs + ZROW * B16_KP + tid * 8) = zero8;      // the zero row (staging never writes it)
+    if (q0 < q1) load_round(q0);
+    for (int q = q0; q < q1; ++q) {
+        stage();
+        __syncthreads();
+        if (q + 1 < q1) load_round(q + 1);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d < ndx) {
+                const int dx = ndx == 3 ? d - 1 : 0;
+                const __bf16* ws = Ws + d * (BN * B16_KP) + (wco * WCO + l31) * B16_KP + 8 * hi;
+                const __bf16* xs[NM];
+#pragma unroll
+                for (int j = 0; j < NM; ++j) {
+                    const bool keep = dx < 0 ? can_l[j] : (dx > 0 ? can_r[j] : true);
+                    xs[j] = Xs + (keep ? 1 + dx + wm * WM + j * 32 + l31 : ZROW) * B16_KP + 8 * hi;
+                }
+#pragma unroll
+                for (int ks = 0; ks < BKT / 16; ++ks) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < NM; ++j) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs[j] + ks * 16);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+}
+
 // w[Cout][Cin][T] fp32 -> bf16 wpb[j][rows][K] with K contiguous: mode 0 rows = co, K = ci (forward);
 // mode 1 rows = ci, K = co, mirrored taps (data gradient)
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wpb, int Cout, int Cin, int T,
@@ -1985,7 +2163,12 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
     {
         ProfScope prof(5, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
-        if (tun().strip && strip_ok(tab)) {
+        static const bool strip3_b16 = getenv("T2V_NO_BF16_STRIP3") == nullptr;       // developer A/B switch
+        const long wbytes = 2L * T2V_MAX_TAPS * Cout * Cin;                            // (32-bit byte offsets into the packed weight)
+        if (tun().strip && strip3_b16 && strip_ok(tab) && strip_fits32(tab, Cin) && wbytes < (1L << 31)) {
+            if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+            else T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        } else if (tun().strip && strip_ok(tab)) {
             if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
         } else if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
