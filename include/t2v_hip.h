@@ -350,9 +350,13 @@ int t2v_argmax_rows(const float* x, int32_t* idx, int64_t rows, int V, void* str
  *                                                                       several consumers: one launch for all pyramid levels)
  *   T2V_MJ_CATLERP          out = [a; b] (cat along the batch), out2 (optional) = c[row] * a + (1 - c[row]) * b
  *                                                                       n = elements of a, d0 = elements per row (cond_gan.py:121-154 +
- *                                                                       losses.py:146: the D step's real||fake batch and x-hat per level) */
+ *                                                                       losses.py:146: the D step's real||fake batch and x-hat per level)
+ *   T2V_MJ_CATCOLS          out[r] = [a[r, 0:d0], b[r, 0:d1]]           n = rows (resnet3d.py:53: torch.cat((features, cond), 1), all levels)
+ *   T2V_MJ_SLICECOLS        out[r, 0:d2] = a[r, d1:d1+d2], a is [rows, d0]   its adjoint pieces; T2V_MJ_EMBEDCOLS: out [rows, d0] = 0 except
+ *                                                                       out[r, d1:d1+d2] = a[r, 0:d2] (the adjoint of the slice) */
 enum { T2V_MJ_SCALE = 1, T2V_MJ_SCALE_ADD, T2V_MJ_DOT, T2V_MJ_MAXPOOL, T2V_MJ_MAXSCATTER, T2V_MJ_MAXGATHER, T2V_MJ_SOFTMAX,
-       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST, T2V_MJ_ADD, T2V_MJ_CATLERP };
+       T2V_MJ_SOFTMAX_BWD, T2V_MJ_SOFTMAX_BWD_BWD_Y, T2V_MJ_BMM, T2V_MJ_RELU_MASK, T2V_MJ_ROWSUM, T2V_MJ_ROWBCAST, T2V_MJ_ADD, T2V_MJ_CATLERP, T2V_MJ_CATCOLS,
+       T2V_MJ_SLICECOLS, T2V_MJ_EMBEDCOLS };
 typedef struct t2v_multi_job {
     const void* a; const void* b; const void* c; void* out; void* out2;
     int64_t n;

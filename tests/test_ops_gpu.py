@@ -505,6 +505,33 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
+def test_cat_features_group_first_and_second_order():
+    """`T2V_MJ_CATCOLS / SLICECOLS / EMBEDCOLS`: torch.cat((features, cond), 1) of every level in one launch, closed under
+    differentiation (the conditional heads take part in the gradient penalty's double backward)."""
+    from txt2vid_amd import functional as TF
+    shapes = [(8, 12, 5), (4, 12, 5), (1, 12, 5)]
+    a_h = [rnd(60 + i, r, na) for i, (r, na, nb) in enumerate(shapes)]
+    b_h = [rnd(70 + i, r, nb) for i, (r, na, nb) in enumerate(shapes)]
+    w_h = [rnd(80 + i, r, na + nb) for i, (r, na, nb) in enumerate(shapes)]
+
+    def run(cat, to):
+        a = [t.to(to).requires_grad_(True) for t in a_h]
+        b = [t.to(to).requires_grad_(i != 1) for i, t in enumerate(b_h)]
+        outs = cat(a, b)
+        f = sum((w.to(to) * o * o * o).sum() for w, o in zip(w_h, outs))
+        live = a + [t for t in b if t.requires_grad]
+        g = torch.autograd.grad(f, live, create_graph=True)
+        gg = torch.autograd.grad(sum((x * x).sum() for x in g), live)
+        return [o.detach() for o in outs], [x.detach() for x in g], gg
+
+    ref = run(lambda a, b: [torch.cat((x, y), 1) for x, y in zip(a, b)], 'cpu')
+    got = run(TF.cat_features_group, dev())
+    for r, g in zip(ref[0], got[0]):
+        assert torch.equal(g.cpu(), r)
+    for r, g in zip(ref[1] + list(ref[2]), got[1] + list(got[2])):
+        close(g, r, rtol=1e-4, atol=1e-4)
+
+
 def test_rsgan_mean_over_levels_is_the_per_level_loss_and_mean_bit_for_bit():
     """`t2v_rsgan_mean_multi[_bwd]`: RSGANLoss of every pyramid level and their mean (cond_gan.py:121-154) in one launch each
     way; the same numbers, bit for bit, as `rsgan` per level + `scalar_mean`, and torch's BCEWithLogits within rounding."""

@@ -1530,6 +1530,26 @@ __global__ __launch_bounds__(256) void mj_catlerp_k(const MultiBatch tb) {
         if (o2) { const float w = al[i / S]; o2[i] = w * rv + (1.f - w) * fv; }
     }
 }
+// column glue of the conditional heads over several members at once (resnet3d.py:53 torch.cat((features, cond), 1) per level):
+// mode 0  out[r] = [a[r, 0:d0], b[r, 0:d1]]                       (n = rows)
+// mode 1  out[r, 0:d2] = a[r, d1 : d1 + d2]        of a [rows, d0] (slice;  adjoint of mode 0 / of mode 2)
+// mode 2  out[r, :] = 0 except out[r, d1 : d1 + d2] = a[r, 0:d2]   out is [rows, d0] (embed; adjoint of mode 1)
+__global__ __launch_bounds__(256) void mj_cols_k(const MultiBatch tb, const int mode) {
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const float* a = (const float*)q.a; const float* b = (const float*)q.b; float* o = (float*)q.out;
+    const long wo = mode == 0 ? (long)q.d0 + q.d1 : (mode == 1 ? (long)q.d2 : (long)q.d0);
+    const long total = q.n * wo;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * MJ_CHUNK;
+    for (long i = base + threadIdx.x; i < base + MJ_CHUNK && i < total; i += 256) {
+        const long r = i / wo, c = i - r * wo;
+        float v;
+        if (mode == 0) v = c < q.d0 ? a[r * q.d0 + c] : b[r * q.d1 + (c - q.d0)];
+        else if (mode == 1) v = a[r * q.d0 + q.d1 + c];
+        else v = (c >= q.d1 && c < q.d1 + q.d2) ? a[r * q.d2 + (c - q.d1)] : 0.f;
+        o[i] = v;
+    }
+}
 // out = a + b (+ c): the gradient sums of a grouped fork (one launch for all members instead of one ATen add per member)
 __global__ __launch_bounds__(256) void mj_add_k(const MultiBatch tb) {
     const int ji = mj_find(tb);
@@ -1727,6 +1747,15 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
             case T2V_MJ_CATLERP:
                 if (!q.b || !q.out || (q.out2 && (!q.c || q.d0 < 1))) return T2V_EINVAL;
                 nb = (q.n + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_CATCOLS:
+                if (!q.b || !q.out || q.d0 < 1 || q.d1 < 1) return T2V_EINVAL;
+                nb = (q.n * ((long)q.d0 + q.d1) + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_SLICECOLS:
+                if (!q.out || q.d0 < 1 || q.d1 < 0 || q.d2 < 1 || q.d1 + q.d2 > q.d0) return T2V_EINVAL;
+                nb = (q.n * (long)q.d2 + MJ_CHUNK - 1) / MJ_CHUNK; break;
+            case T2V_MJ_EMBEDCOLS:
+                if (!q.out || q.d0 < 1 || q.d1 < 0 || q.d2 < 1 || q.d1 + q.d2 > q.d0) return T2V_EINVAL;
+                nb = (q.n * (long)q.d0 + MJ_CHUNK - 1) / MJ_CHUNK; break;
             case T2V_MJ_ROWSUM:
                 if (!q.out || q.d0 < 1) return T2V_EINVAL;
                 nb = (q.n + 3) / 4; break;
@@ -1764,6 +1793,9 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
         case T2V_MJ_RELU_MASK: T2V_LAUNCH(mj_relu_mask_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_ADD: T2V_LAUNCH(mj_add_k, grid, blk, 0, S_(st), tb); break;
         case T2V_MJ_CATLERP: T2V_LAUNCH(mj_catlerp_k, grid, blk, 0, S_(st), tb); break;
+        case T2V_MJ_CATCOLS: T2V_LAUNCH(mj_cols_k, grid, blk, 0, S_(st), tb, 0); break;
+        case T2V_MJ_SLICECOLS: T2V_LAUNCH(mj_cols_k, grid, blk, 0, S_(st), tb, 1); break;
+        case T2V_MJ_EMBEDCOLS: T2V_LAUNCH(mj_cols_k, grid, blk, 0, S_(st), tb, 2); break;
         case T2V_MJ_ROWSUM: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 0); break;
         case T2V_MJ_ROWBCAST: T2V_LAUNCH(mj_rowsum_k, grid, blk, 0, S_(st), tb, 1); break;
     }

@@ -13,7 +13,7 @@ from ._ops import lib, check, _c, _p, _stream
 # members that receive no gradient (None) are left out of the backward launches.
 # ------------------------------------------------------------------------------------------------
 (MJ_SCALE, MJ_SCALE_ADD, MJ_DOT, MJ_MAXPOOL, MJ_MAXSCATTER, MJ_MAXGATHER, MJ_SOFTMAX, MJ_SOFTMAX_BWD, MJ_SOFTMAX_BWD_BWD_Y, MJ_BMM,
- MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD, MJ_CATLERP) = range(1, 16)
+ MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD, MJ_CATLERP, MJ_CATCOLS, MJ_SLICECOLS, MJ_EMBEDCOLS) = range(1, 19)
 
 
 def _mj(op, jobs, scalar=None, dot_out=None):
@@ -106,6 +106,87 @@ def _fork_some(ts):
         for k, i in enumerate(idx):
             a[i], b[i] = fa[k], fb[k]
     return a, b
+
+
+class CatColsG(Function):
+    """outs[i] = torch.cat((as[i], bs[i]), 1) for n pairs of 2-D tensors in ONE launch (the conditional heads' feature || caption
+    concatenation of every pyramid level, resnet3d.py:53). args: n, a_0.., b_0..  Closed under differentiation (SliceColsG /
+    EmbedColsG)."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        a, b = [_c(t) for t in ts[:n]], [_c(t) for t in ts[n:]]
+        outs = [torch.empty((x.shape[0], x.shape[1] + y.shape[1]), device=x.device, dtype=torch.float32) for x, y in zip(a, b)]
+        _mj(MJ_CATCOLS, [dict(a=x, b=y, out=o, n=x.shape[0], d0=x.shape[1], d1=y.shape[1]) for x, y, o in zip(a, b, outs)])
+        ctx.cfg = (n, [(x.shape[1], y.shape[1]) for x, y in zip(a, b)])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, widths = ctx.cfg
+        ga, gb = [None] * n, [None] * n
+        la = [i for i in _live(gs) if ctx.needs_input_grad[1 + i]]
+        lb = [i for i in _live(gs) if ctx.needs_input_grad[1 + n + i]]
+        if la:
+            for i, r in zip(la, SliceColsG.apply(tuple((sum(widths[i]), 0, widths[i][0]) for i in la), *[gs[i] for i in la])):
+                ga[i] = r
+        if lb:
+            for i, r in zip(lb, SliceColsG.apply(tuple((sum(widths[i]), widths[i][0], widths[i][1]) for i in lb), *[gs[i] for i in lb])):
+                gb[i] = r
+        return (None,) + tuple(ga) + tuple(gb)
+
+
+class SliceColsG(Function):
+    """outs[i] = xs[i][:, off:off+n] with cfgs[i] = (total, off, n)."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *xs):
+        xs = [_c(x) for x in xs]
+        outs = [torch.empty((x.shape[0], c[2]), device=x.device, dtype=torch.float32) for x, c in zip(xs, cfgs)]
+        _mj(MJ_SLICECOLS, [dict(a=x, out=o, n=x.shape[0], d0=c[0], d1=c[1], d2=c[2]) for x, o, c in zip(xs, outs, cfgs)])
+        ctx.cfg = cfgs
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cfgs = ctx.cfg
+        live = _live(gs)
+        out = [None] * len(cfgs)
+        if live:
+            for i, r in zip(live, EmbedColsG.apply(tuple(cfgs[i] for i in live), *[gs[i] for i in live])):
+                out[i] = r
+        return (None,) + tuple(out)
+
+
+class EmbedColsG(Function):
+    """outs[i] = zeros [rows, total] with gs[i] written at columns off:off+n (the adjoint of SliceColsG)."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *gs):
+        gs = [_c(g) for g in gs]
+        outs = [torch.empty((g.shape[0], c[0]), device=g.device, dtype=torch.float32) for g, c in zip(gs, cfgs)]
+        _mj(MJ_EMBEDCOLS, [dict(a=g, out=o, n=g.shape[0], d0=c[0], d1=c[1], d2=c[2]) for g, o, c in zip(gs, outs, cfgs)])
+        ctx.cfg = cfgs
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *ggs):
+        cfgs = ctx.cfg
+        live = _live(ggs)
+        out = [None] * len(cfgs)
+        if live:
+            for i, r in zip(live, SliceColsG.apply(tuple(cfgs[i] for i in live), *[ggs[i] for i in live])):
+                out[i] = r
+        return (None,) + tuple(out)
+
+
+def cat_features_group(as_, bs):
+    """[torch.cat((a, b), 1) for a, b in zip(as_, bs)] in one launch (2-D tensors, at most 8 pairs per launch)."""
+    as_, bs = list(as_), list(bs)
+    return list(CatColsG.apply(len(as_), *(as_ + bs)))
 
 
 class MaxPool2x2G(Function):

@@ -94,9 +94,16 @@ class CondGan(object):
             rf = [TF.cat_batch(r, f) for r, f in zip(real, fake)]
             if gp_lambda > 0:
                 xhs = [TF.lerp_rows(a_dev[i], real[i].detach(), fake[i].detach()).requires_grad_(True) for i in range(n)]
-        conds = [TF.cat_batch(c, c) for c in real_cond] if cond else None
-        if gp_lambda > 0 and cond:
-            chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
+        conds = None
+        if cond and not any(t.requires_grad for t in list(real_cond) + list(fake_cond)):
+            # detached sentence codes: the doubled captions of all levels in one launch, their interpolates in another
+            conds, _ = TF.cat_lerp_group(real_cond, real_cond)
+            if gp_lambda > 0:
+                _, chs = TF.cat_lerp_group(real_cond, fake_cond, a_dev)
+        elif cond:
+            conds = [TF.cat_batch(c, c) for c in real_cond]
+            if gp_lambda > 0:
+                chs = [TF.lerp_rows(a_dev[i], real_cond[i], fake_cond[i]) for i in range(n)]
         res = discrim(x=rf + xhs, cond=(conds + chs) if (cond and xhs) else conds, xbar=None)
         both, gp_res = res[:n], res[n:]
         b = [r.size(0) for r in real]
@@ -105,7 +112,12 @@ class CondGan(object):
             c_r, c_f = zip(*[TF.split_rows(o[1], b[i]) for i, o in enumerate(both)])
             # D(real, mismatched captions): second head on the real half's trunk features
             trunk = discrim.sub_discrims
-            c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
+            shared = trunk[0].module if hasattr(trunk[0], 'module') and not hasattr(trunk[0], 'cond_heads') else trunk[0]
+            if all(t is trunk[0] for t in trunk) and hasattr(shared, 'cond_heads'):
+                # one shared trunk: the mismatched-caption heads of every level in two launches
+                c_ic = shared.cond_heads([TF.head_rows(both[i][2], b[i]) for i in range(n)], list(fake_cond))
+            else:
+                c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
             lu = _mean_over_levels(loss, u_f, u_r)
             l1 = _mean_over_levels(loss, c_f, c_r)
             l2 = _mean_over_levels(loss, c_ic, c_r)

@@ -70,13 +70,19 @@ class Resnet3D(nn.Module):
         feats = TF.sum_spatial_group(hs)                                      # torch.sum(x, [2,3,4]) of every level: one launch
         w5 = self.fc_uncond.weight.view(self.fc_uncond.weight.shape + (1, 1, 1))
         us = TF.conv_group([f.view(f.shape + (1, 1, 1)) for f in feats], w5, self.fc_uncond.bias)   # all heads: one launch
-        out = []
-        for i, (feat, u) in enumerate(zip(feats, us)):
-            c = None
-            if conds is not None:
-                c = self.fc(TF.cat_features(feat, conds[i]))
-            out.append((u.view(u.shape[0], u.shape[1]), c, feat))
-        return out
+        cs = self.cond_heads(feats, conds) if conds is not None else [None] * len(feats)
+        return [(u.view(u.shape[0], u.shape[1]), c, feat) for feat, u, c in zip(feats, us, cs)]
+
+    def cond_heads(self, feats, conds):
+        """`self.fc(torch.cat((features, cond), 1))` (resnet3d.py:53-55) for several levels / members at once: one launch for
+        all concatenations, one for all heads (instead of two copies + one linear per member)."""
+        feats, conds = list(feats), list(conds)
+        if not (1 <= len(feats) <= TF.MAX_GROUPS) or not feats[0].is_cuda:
+            return [self.fc(TF.cat_features(f, c)) for f, c in zip(feats, conds)]
+        cats = TF.cat_features_group(feats, conds)
+        w5 = self.fc.weight.view(self.fc.weight.shape + (1, 1, 1))
+        cs = TF.conv_group([c.view(c.shape + (1, 1, 1)) for c in cats], w5, self.fc.bias)
+        return [c.view(c.shape[0], c.shape[1]) for c in cs]
 
     def forward(self, x=None, cond=None, xbar=None, computed_features=None):
         uncond = None
