@@ -24,6 +24,14 @@ class MixedGanLoss(object):
     def gen_loss(self, fake=None, real=None):
         return self.g_loss.gen_loss(fake=fake, real=real)
 
+    def __getattr__(self, name):
+        # the all-levels-in-one-launch forms (cond_gan._mean_over_levels) exist exactly when the wrapped loss offers them
+        if name == 'discrim_loss_levels':
+            return getattr(self.__dict__['d_loss'], name)
+        if name == 'gen_loss_levels':
+            return getattr(self.__dict__['g_loss'], name)
+        raise AttributeError(name)
+
 
 class RSGANLoss(object):
     """Relativistic standard GAN: BCEWithLogits(real - fake, 1) / BCEWithLogits(fake - real, 1)."""
