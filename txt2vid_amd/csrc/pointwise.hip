@@ -1169,9 +1169,15 @@ __global__ __launch_bounds__(256) void nonlocal_bwd_k_k(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ lse,
                                                         const float* __restrict__ go, const float* __restrict__ dsum,
                                                         float* __restrict__ dphi, float* __restrict__ dg, int N, int Nk) {
+    // A workgroup owns NL_KPW = 64 keys of one sample; its four waves split the queries of every staged tile (query i of the
+    // tile goes to wave i % 4) and their partial sums are added in wave order at the end (fixed order). One key per THREAD with
+    // 256 keys per workgroup left a 32-sample, 256-key block (the generator's 32x32 maps) on 32 workgroups: 240 us.
     constexpr int QW = C8 + C2 + 2;                 // per query: theta, do, lse, D
+    constexpr int KPW = 64, CW = C8 + C2;
+    static_assert(3 * CW * KPW <= NL_TILE * QW, "reduction buffer aliases the query tile");
     __shared__ float sq[NL_TILE * QW];
-    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int b = blockIdx.y, j = blockIdx.x * KPW + lane;
     const bool kv = j < Nk;
     float p_[C8], g_[C2], dp[C8], dgv[C2];
 #pragma unroll
@@ -1190,7 +1196,7 @@ __global__ __launch_bounds__(256) void nonlocal_bwd_k_k(const float* __restrict_
             sq[i * QW + C8 + C2 + 1] = dsum[(size_t)b * N + i0 + i];
         }
         __syncthreads();
-        for (int i = 0; i < ni; ++i) {
+        for (int i = sl; i < ni; i += 4) {
             const float* r = &sq[i * QW];
             float sc = 0.f, db = 0.f;
 #pragma unroll
@@ -1205,7 +1211,24 @@ __global__ __launch_bounds__(256) void nonlocal_bwd_k_k(const float* __restrict_
             for (int c = 0; c < C2; ++c) dgv[c] += p * r[C8 + c];
         }
     }
-    if (kv) {
+    __syncthreads();
+    if (sl > 0) {
+        float* red = sq + (size_t)(sl - 1) * CW * KPW;
+#pragma unroll
+        for (int k = 0; k < C8; ++k) red[k * KPW + lane] = dp[k];
+#pragma unroll
+        for (int c = 0; c < C2; ++c) red[(C8 + c) * KPW + lane] = dgv[c];
+    }
+    __syncthreads();
+    if (sl == 0 && kv) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float* red = sq + (size_t)w * CW * KPW;
+#pragma unroll
+            for (int k = 0; k < C8; ++k) dp[k] += red[k * KPW + lane];
+#pragma unroll
+            for (int c = 0; c < C2; ++c) dgv[c] += red[(C8 + c) * KPW + lane];
+        }
 #pragma unroll
         for (int k = 0; k < C8; ++k) dphi[((size_t)b * C8 + k) * Nk + j] = dp[k];
 #pragma unroll
@@ -1229,7 +1252,7 @@ extern "C" int t2v_nonlocal_bwd(const float* theta, const float* phi, const floa
                dtheta, ws, N, Nk);
     int rc = launch_status();
     if (rc) return rc;
-    T2V_LAUNCH((nonlocal_bwd_k_k<4, 16>), dim3((unsigned)((Nk + 255) / 256), (unsigned)b), dim3(256), 0, S_(st), theta, phi, g, lse, go, ws,
+    T2V_LAUNCH((nonlocal_bwd_k_k<4, 16>), dim3((unsigned)((Nk + 63) / 64), (unsigned)b), dim3(256), 0, S_(st), theta, phi, g, lse, go, ws,
                dphi, dg, N, Nk);
     return launch_status();
 }
