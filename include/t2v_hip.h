@@ -305,6 +305,10 @@ int t2v_softmax_bwd_bwd_y(const float* y, const float* gy, const float* gg, floa
 int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh_t, const float* h_prev, const float* c_prev,
                       float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B, int H,
                       void* stream);
+/* the forward AND the reverse direction's step of one loop iteration in one launch (they are independent). ptrs: 2 x 7 pointers
+   {xproj_t, w_hh_t, h_prev, c_prev, h_next, c_next, out_t} (forward, then reverse), ts: their two time steps. */
+int t2v_lstm_seq_step2(const void* const* ptrs, const int32_t* ts, int64_t xstride, int64_t ostride, const int32_t* lengths,
+                       int B, int H, void* stream);
 
 /* ---- text-encoder pre-training (txt2vid/train/txt.py:160-178: encode -> greedy / teacher-forced decode -> cross entropy;
  *      models/txt/basic.py:49-101). The nn.LSTM / nn.Embedding / nn.Linear / nn.CrossEntropyLoss calls of the reference map to:

@@ -153,6 +153,7 @@ SIGNATURES = {
     't2v_softmax_bwd': [_P, _P, _P, _L, _I, _P],
     't2v_softmax_bwd_bwd_y': [_P, _P, _P, _P, _L, _I, _P],
     't2v_lstm_seq_step': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _P],
+    't2v_lstm_seq_step2': [_P, _P, _L, _L, _P, _I, _I, _P],
     't2v_lstm_train_step': [_P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P],
     't2v_lstm_train_step_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     't2v_embedding_bwd': [_P, _P, _P, _L, _I, _I, _P],

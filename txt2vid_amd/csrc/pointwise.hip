@@ -1294,6 +1294,41 @@ __global__ __launch_bounds__(1024) void lstm_seq_step_k(const float* __restrict_
     h_next[i] = active ? hh : sh[u];
     out[(size_t)b * ostride + u] = active ? hh : 0.f;
 }
+// Both directions of one layer in ONE launch (blockIdx.y = direction): the forward direction's step and the reverse direction's
+// step of the same loop iteration are independent (models/txt/basic.py:49-70, nn.LSTM(bidirectional=True)).
+struct LstmDirArgs { const float* xproj; const float* whh_t; const float* h_prev; const float* c_prev; float* h_next; float* c_next;
+                     float* out; int t; };
+__global__ __launch_bounds__(1024) void lstm_seq_step2_k(const LstmDirArgs a0, const LstmDirArgs a1, long xstride, long ostride,
+                                                         const int32_t* __restrict__ lengths, int B, int H) {
+    extern __shared__ float sh[];
+    const LstmDirArgs& a = blockIdx.y ? a1 : a0;
+    const int b = blockIdx.x, u = threadIdx.x;
+    lstm_recurrent_pre(a.xproj + (size_t)b * xstride, a.whh_t, a.h_prev + (size_t)b * H, sh, H);
+    if (u >= H) return;
+    const int i = b * H + u;
+    const bool active = a.t < lengths[b];
+    const float gi = sigm(sh[H + u]), gf = sigm(sh[2 * H + u]), gg = tanhf(sh[3 * H + u]), go = sigm(sh[4 * H + u]);
+    const float cc = gf * a.c_prev[i] + gi * gg;
+    const float hh = go * tanhf(cc);
+    a.c_next[i] = active ? cc : a.c_prev[i];
+    a.h_next[i] = active ? hh : sh[u];
+    a.out[(size_t)b * ostride + u] = active ? hh : 0.f;
+}
+// ptrs: 2 x 7 pointers (xproj_t, w_hh_t, h_prev, c_prev, h_next, c_next, out_t) of the forward / reverse direction; ts: their steps
+extern "C" int t2v_lstm_seq_step2(const void* const* ptrs, const int32_t* ts, int64_t xstride, int64_t ostride, const int32_t* lengths,
+                                  int B, int H, void* st) {
+    if (!ptrs || !ts || !lengths || B < 1 || H < 1 || 4 * H > 1024) return T2V_EINVAL;
+    LstmDirArgs a[2];
+    for (int d = 0; d < 2; ++d) {
+        const void* const* q = ptrs + 7 * d;
+        for (int k = 0; k < 7; ++k) if (!q[k]) return T2V_EINVAL;
+        if (ts[d] < 0 || q[2] == q[4] || q[3] == q[5]) return T2V_EINVAL;
+        a[d] = {(const float*)q[0], (const float*)q[1], (const float*)q[2], (const float*)q[3], (float*)q[4], (float*)q[5], (float*)q[6], ts[d]};
+    }
+    T2V_LAUNCH(lstm_seq_step2_k, dim3((unsigned)B, 2u), dim3((unsigned)(4 * H)), (size_t)5 * H * sizeof(float), S_(st), a[0], a[1],
+               (long)xstride, (long)ostride, lengths, B, H);
+    return launch_status();
+}
 extern "C" int t2v_lstm_seq_step(const float* xproj_t, int64_t xstride, const float* w_hh_t, const float* h_prev, const float* c_prev,
                                  float* h_next, float* c_next, float* out_t, int64_t ostride, const int32_t* lengths, int t, int B,
                                  int H, void* st) {

@@ -2114,21 +2114,32 @@ def lstm_encode(tokens, lengths, embed_weight, lstm, hidden_size, num_layers, bi
         inp = x                                                   # [B*L, In]
         for layer in range(num_layers):
             out = torch.empty((B, L, D * H), device=dev, dtype=torch.float32)
+            xprojs, whts, bufss = [], [], []
             for d in range(D):
                 sfx = '_l%d%s' % (layer, '_reverse' if d else '')
                 w_ih, w_hh = getattr(lstm, 'weight_ih' + sfx), getattr(lstm, 'weight_hh' + sfx)     # parameters: packed / transposed once
                 bsum = _ew(lib().t2v_add, 't2v_add', getattr(lstm, 'bias_ih' + sfx).detach(), getattr(lstm, 'bias_hh' + sfx).detach())
-                xproj = conv_fwd_raw(_as5(inp), _as5(w_ih), bsum).view(B, L, 4 * H)      # all time steps: one GEMM
-                w_hh_t = transposed_weight(w_hh)                                          # [H, 4H]: coalesced reads in the step kernel
-                bufs = [(torch.empty_like(zero), torch.empty_like(zero)) for _ in range(2)]      # ping-pong (h, c)
-                for step in range(L):
-                    t = L - 1 - step if d else step
-                    hp, cp = (zero, zero) if step == 0 else bufs[(step - 1) & 1]
-                    hn_, cn_ = (h_n[layer * D + d], c_n[layer * D + d]) if step == L - 1 else bufs[step & 1]
-                    xp = C.c_void_p(xproj.data_ptr() + 4 * t * 4 * H)
-                    op = C.c_void_p(out.data_ptr() + 4 * (t * D * H + d * H))
-                    check(lib().t2v_lstm_seq_step(xp, L * 4 * H, _p(w_hh_t), _p(hp), _p(cp), _p(hn_), _p(cn_), op, L * D * H,
-                                                  _p(len_dev), t, B, H, _stream()), 't2v_lstm_seq_step')
+                xprojs.append(conv_fwd_raw(_as5(inp), _as5(w_ih), bsum).view(B, L, 4 * H))        # all time steps: one GEMM
+                whts.append(transposed_weight(w_hh))                                              # [H, 4H]: coalesced reads in the step kernel
+                bufss.append([(torch.empty_like(zero), torch.empty_like(zero)) for _ in range(2)])     # ping-pong (h, c)
+
+            def step_args(d, step):
+                t = L - 1 - step if d else step
+                hp, cp = (zero, zero) if step == 0 else bufss[d][(step - 1) & 1]
+                hn_, cn_ = (h_n[layer * D + d], c_n[layer * D + d]) if step == L - 1 else bufss[d][step & 1]
+                xp = xprojs[d].data_ptr() + 4 * t * 4 * H
+                op = out.data_ptr() + 4 * (t * D * H + d * H)
+                return t, [xp, whts[d].data_ptr(), hp.data_ptr(), cp.data_ptr(), hn_.data_ptr(), cn_.data_ptr(), op]
+            for step in range(L):
+                if D == 2:            # the two directions of a step are independent: one launch
+                    (t0, p0), (t1, p1) = step_args(0, step), step_args(1, step)
+                    check(lib().t2v_lstm_seq_step2((C.c_void_p * 14)(*(p0 + p1)), (C.c_int32 * 2)(t0, t1), L * 4 * H, L * D * H,
+                                                   _p(len_dev), B, H, _stream()), 't2v_lstm_seq_step2')
+                else:
+                    t, q = step_args(0, step)
+                    check(lib().t2v_lstm_seq_step(C.c_void_p(q[0]), L * 4 * H, C.c_void_p(q[1]), C.c_void_p(q[2]), C.c_void_p(q[3]),
+                                                  C.c_void_p(q[4]), C.c_void_p(q[5]), C.c_void_p(q[6]), L * D * H, _p(len_dev), t, B, H,
+                                                  _stream()), 't2v_lstm_seq_step')
             inp = out.view(B * L, D * H)
         return out, (h_n, c_n)
 
