@@ -1988,7 +1988,7 @@ class ScalarCombine(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) + tuple(ScaleConst.apply(g, w) for w in ctx.weights)
+        return (None,) + tuple(g if w == 1.0 else ScaleConst.apply(g, w) for w in ctx.weights)     # (weight 1: no launch)
 
 
 class ScaleConst(Function):
