@@ -49,6 +49,9 @@ typedef struct {
     const float* mask;   /* T2V_CONV_MASK_OUT: same shape as y; y = mask > 0 ? result : 0  (else NULL) */
     int32_t N, D, H, W;
     int32_t ntaps;
+    int32_t dstride;     /* 0 / 1: every frame; 2 (forward launches on the strip3 kernels only): y holds the EVEN frames only,
+                            [N,Cout,ceil(D/2),H,W] — the stem's conv2 -> AvgPool3d((1,2,2), stride 2) pair (resnet3d.py:12-19) drops the
+                            odd frames of conv2, so they are not computed. Other entry points reject 2. */
     int8_t dz[T2V_MAX_TAPS], dy[T2V_MAX_TAPS], dx[T2V_MAX_TAPS], widx[T2V_MAX_TAPS];
 } t2v_conv_group;
 

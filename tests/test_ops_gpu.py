@@ -505,6 +505,45 @@ def test_batchnorm_tanh_upsample():
     close(ye, F.batch_norm(x, rmr, rvr, gamma, beta, False, 0.1, 1e-5))
 
 
+@pytest.mark.parametrize('members,cin,cout', [
+    ([(2, 4, 16, 16), (1, 5, 8, 8), (3, 2, 4, 4)], 64, 64),         # even, odd and two-frame members (64-voxel strip3 tiles)
+    ([(8, 16, 32, 32)], 64, 96),                                     # M_out = 65536: 256-voxel strip3 tiles, two channel tiles
+])
+def test_conv_even_frames_group(members, cin, cout):
+    """`t2v_conv_group.dstride = 2` (ConvEvenFramesG): ReLU -> conv3^3 evaluated on the EVEN output frames only (what the stem's
+    AvgPool3d((1,2,2), stride 2) keeps): the even frames of the full launch, and the same gradients — first
+    order and through a recorded backward — as torch's conv followed by [:, :, ::2]."""
+    from txt2vid_amd import functional as TF
+    xs_h = [rnd(90 + i, n, cin, d, h, w) for i, (n, d, h, w) in enumerate(members)]
+    w_h, b_h = rnd(7, cout, cin, 3, 3, 3) * 0.05, rnd(8, cout)
+    xs = [t.to(dev()).requires_grad_(True) for t in xs_h]
+    w, b = torch.nn.Parameter(w_h.to(dev())), torch.nn.Parameter(b_h.to(dev()))
+    assert TF.even_frames_ok(xs, w)
+    ys = TF.conv_even_frames_group(xs, w, b, relu_in=True)
+    full = TF.conv_group([t.detach() for t in xs], w.detach(), b.detach(), relu_in=True)
+    for y, f, (n, d, h, wd) in zip(ys, full, members):
+        assert y.shape == (n, cout, (d + 1) // 2, h, wd)
+        close(y.detach(), f[:, :, ::2], rtol=1e-5, atol=1e-5)       # (same GEMM; the full launch may split K, so not bit for bit)
+    gys = [rnd(50 + i, *y.shape) for i, y in enumerate(ys)]
+
+    def second_order(outs, leaves, to):
+        f = sum((o * g.to(to)).sum() for o, g in zip(outs, gys))
+        g1 = torch.autograd.grad(f, leaves, create_graph=True)
+        pen = sum((g * g).sum() for g in g1[:len(outs)])                     # (penalty on the data gradients, like the GP)
+        g2 = torch.autograd.grad(pen, leaves[len(outs):], allow_unused=True)
+        return [g.detach() for g in g1], g2
+
+    got1, got2 = second_order(ys, xs + [w, b], dev())
+    xr = [t.clone().requires_grad_(True) for t in xs_h]
+    wr, br = w_h.clone().requires_grad_(True), b_h.clone().requires_grad_(True)
+    yr = [F.conv3d(F.relu(x), wr, br, padding=1)[:, :, ::2] for x in xr]
+    ref1, ref2 = second_order(yr, xr + [wr, br], 'cpu')
+    for a, r in zip(got1, ref1):
+        close(a, r, rtol=2e-3, atol=2e-3)
+    close(got2[0], ref2[0], rtol=5e-3, atol=5e-3)                           # d penalty / d w through the recorded backward
+    assert got2[1] is None or float(got2[1].abs().max()) == 0.0            # the bias does not enter the data gradient
+
+
 def test_cat_features_group_first_and_second_order():
     """`T2V_MJ_CATCOLS / SLICECOLS / EMBEDCOLS`: torch.cat((features, cond), 1) of every level in one launch, closed under
     differentiation (the conditional heads take part in the gradient penalty's double backward)."""

@@ -816,7 +816,12 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     const t2v_conv_group& gd = tab.g[gi];
     const int D = gd.D, H = gd.H, W = gd.W;
     const int HW = H * W, DHW = D * HW;
-    const int M = gd.N * DHW;
+    // frame-strided output (dstride = 2: the stem's conv2 feeds a pooling that keeps the even frames only): GEMM rows run over
+    // the output voxels [N, Do, H, W]; row (n, do, r) gathers around input frame d = 2 do
+    const int ds = gd.dstride == 2 ? 2 : 1;
+    const int Do = ds == 2 ? (D + 1) / 2 : D;
+    const int DHWo = Do * HW;
+    const int M = gd.N * DHWo;
     const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
     const int ntaps = gd.ntaps;
     const int ndx = gd.dx[0] < 0 ? 3 : 1;           // taps r*ndx + {0,1,2} = dx -1, 0, +1 of row tap r
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
     const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
     const int tab_widx = gd.widx[lane_t];
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)M * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * DHW) * (uint32_t)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
 
     // ---- staging coordinates (as in the per-dx strip kernel)
@@ -837,8 +842,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     {
         const int m_a = m0 + ma_l;
         if (m_a < M) {
-            const int n = m_a / DHW, sp = m_a - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
+            const int n = m_a / DHWo, spo = m_a - n * DHWo;
+            const int d_o = spo / HW, r = spo - d_o * HW;
+            const int d = d_o * ds, sp = d * HW + r;
             const int h = r / W;
             xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
@@ -848,8 +854,9 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
         }
         const int m_h = he ? m0 + BM : m0 - 1;
         if (halo_thread && m_h >= 0 && m_h < M) {
-            const int n = m_h / DHW, sp = m_h - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
+            const int n = m_h / DHWo, spo = m_h - n * DHWo;
+            const int d_o = spo / HW, r = spo - d_o * HW;
+            const int d = d_o * ds, sp = d * HW + r;
             const int h = r / W;
             xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
@@ -981,7 +988,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
-    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1793,10 +1800,12 @@ static const Tunables& tun() {
     return t;
 }
 
-struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; };
+struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; bool dstride2; };
 
+static inline int out_frames(const t2v_conv_group& g) { return g.dstride == 2 ? (g.D + 1) / 2 : g.D; }
 static bool group_ok(const t2v_conv_group& g, bool need_ptrs) {
     if (need_ptrs && (!g.x || !g.y)) return false;
+    if (g.dstride < 0 || g.dstride > 2) return false;
     if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.ntaps < 1 || g.ntaps > T2V_MAX_TAPS) return false;
     for (int t = 0; t < g.ntaps; ++t) {
         if (g.dz[t] < -1 || g.dz[t] > 1 || g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
@@ -1810,10 +1819,13 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
     long Mtot = 0, Mmax = 0;
     int max_chunk_taps = 1;
+    p.dstride2 = false;
     for (int i = 0; i < ngroups; ++i) {
         if (!group_ok(groups[i], need_ptrs)) return false;
-        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
-        if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;     // 32-bit voxel indices
+        const long Min = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        if (Min * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;     // 32-bit voxel indices
+        const long M = (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;      // GEMM rows = output voxels
+        if (groups[i].dstride == 2) p.dstride2 = true;
         Mtot += M;
         if (M > Mmax) Mmax = M;
         if (groups[i].ntaps > max_chunk_taps) max_chunk_taps = groups[i].ntaps;
@@ -1836,7 +1848,7 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     tab.n = ngroups;
     for (int i = 0; i < ngroups; ++i) {
         tab.g[i] = groups[i];
-        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        const long M = (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;
         tab.tile_start[i] = (int32_t)mt;
         tab.out_start[i] = ot;
         mt += (M + p.bm - 1) / p.bm;
@@ -1860,8 +1872,9 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         while (S > 1 && (double)S * ot * 4.0 > 256e6) --S;   // keep the slab small (L2 / MALL resident)
         if (S < 1) S = 1;
     }
+    if (p.dstride2) S = 1;                        // (frame-strided outputs: the split-K reduce pass does not know them)
     const long force_S = tun().force_splits;                                                  // developer knob (tools/conv_suite.py sweeps)
-    if (force_S > 0) S = force_S > min_chunks / 2 ? (min_chunks / 2 > 0 ? min_chunks / 2 : 1) : force_S;
+    if (force_S > 0 && !p.dstride2) S = force_S > min_chunks / 2 ? (min_chunks / 2 > 0 ? min_chunks / 2 : 1) : force_S;
     p.S = (int)S;
     return true;
 }
@@ -2041,13 +2054,20 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     int nslots;
     const bool thin = thin_ok(groups, ngroups, Cin, Cout, nslots);
     if (!thin && p.S > 1 && !ws) return T2V_EINVAL;
+    if (p.dstride2) {                      // frame-strided outputs: the three-taps-per-round strip kernels only
+        if (thin || (flags & (T2V_CONV_MASK_OUT | T2V_CONV_ACCUM))) return T2V_EINVAL;
+        bool s3 = false;
+        if (p.bn == 64 && p.bm == 256) s3 = conv_variant(tab, p, 256, 64, 16, Cin, Cout, flags).s3;
+        else if (p.bn == 64 && p.bk == 32) s3 = conv_variant(tab, p, p.bm, 64, 32, Cin, Cout, flags).s3;
+        if (!s3) return T2V_EINVAL;
+    }
     double flops = 0;
     for (int i = 0; i < ngroups; ++i)
-        flops += 2.0 * (double)groups[i].N * groups[i].D * groups[i].H * groups[i].W * Cout * Cin * groups[i].ntaps;
+        flops += 2.0 * (double)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W * Cout * Cin * groups[i].ntaps;
     long Mtot_ = 0;
     int taps_ = 0;
     for (int i = 0; i < ngroups; ++i) {
-        Mtot_ += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        Mtot_ += (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;
         if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
     }
     int32_t plan_[8];
@@ -2129,7 +2149,7 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
                                          const float* bias, float* ws, int flags, void* stream) {
     GroupTable tab;
     ConvPlan p;
-    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p))
+    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p) || p.dstride2)
         return T2V_EINVAL;
     if (flags & T2V_CONV_MASK_OUT) {
         if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
@@ -2195,7 +2215,7 @@ static bool geom_ok(const t2v_conv_geom* g) {
 static t2v_conv_group group_of(const t2v_conv_geom* g, const float* x, float* y) {
     t2v_conv_group q;
     q.x = x; q.y = y; q.mask = nullptr;
-    q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps;
+    q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps; q.dstride = 0;
     for (int t = 0; t < T2V_MAX_TAPS; ++t) {
         q.dz[t] = t < g->ntaps ? g->dz[t] : 0; q.dy[t] = t < g->ntaps ? g->dy[t] : 0; q.dx[t] = t < g->ntaps ? g->dx[t] : 0;
         q.widx[t] = (int8_t)(t < g->ntaps ? t : 0);
@@ -3081,7 +3101,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     for (int i = 0; i < ngroups; ++i) {
         const t2v_conv_group& g = groups[i];
         if (need_ptrs && (!g.x || !g.y)) return false;
-        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1) return false;
+        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.dstride < 0 || g.dstride > 1) return false;      // (no frame stride here)
         const long M = (long)g.N * g.D * g.H * g.W;
         if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return false;     // the gathers use 32-bit BYTE offsets (buffer loads)
         if (M * (long)(Cin > Cout ? Cin : Cout) > maxMC) maxMC = M * (long)(Cin > Cout ? Cin : Cout);

@@ -2483,10 +2483,11 @@ def _tapset(T, mask):
     return ts
 
 
-def _group_table(ins, outs, geoms, slot_of, masks=None):
+def _group_table(ins, outs, geoms, slot_of, masks=None, dstride=0):
     arr = (ConvGroup * len(ins))()
     for i, (xi, yi, g) in enumerate(zip(ins, outs, geoms)):
         a = arr[i]
+        a.dstride = dstride
         a.x, a.y = xi.data_ptr(), (yi.data_ptr() if yi is not None else 0)
         a.mask = masks[i].data_ptr() if masks is not None else None
         a.N, a.D, a.H, a.W, a.ntaps = g.cg.N, g.cg.D, g.cg.H, g.cg.W, g.cg.ntaps
@@ -2496,7 +2497,7 @@ def _group_table(ins, outs, geoms, slot_of, masks=None):
     return arr
 
 
-def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=None, accum=False):
+def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=None, accum=False, even_frames=False):
     """mode 0: ys[i] = conv(xs[i], w) (+bias); mode 1: data gradient (xs are dL/dy, channels swap roles).
     masks: ys[i] is zeroed where masks[i] <= 0 (the ReLU adjoint, fused into the epilogue)."""
     if len(xs5) > MAX_GROUPS:
@@ -2512,20 +2513,22 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=N
         mask |= g.mask
     ts = _tapset(geoms[0].T, mask)
     slot_of = {t: j for j, t in enumerate(ts.taps)}
-    ys = outs if outs is not None else [torch.empty((t.shape[0], cout) + tuple(t.shape[2:]), device=t.device, dtype=torch.float32)
-                                        for t in xs5]
+    if even_frames and (mode != 0 or masks is not None or accum or outs is not None):
+        raise ValueError('even_frames is a plain forward option')
+    ys = outs if outs is not None else [torch.empty((t.shape[0], cout, (t.shape[2] + 1) // 2 if even_frames else t.shape[2]) + tuple(t.shape[3:]),
+                                                    device=t.device, dtype=torch.float32) for t in xs5]
     if masks is not None:
         masks = [_c(m) for m in masks]
         if any(m.shape != y.shape for m, y in zip(masks, ys)):
             raise ValueError('mask / output shape mismatch')
-    arr = _group_table(xs5, ys, geoms, slot_of, masks)
+    arr = _group_table(xs5, ys, geoms, slot_of, masks, 2 if even_frames else 0)
     n = int(lib().t2v_conv_fwd_grouped_ws_floats(arr, len(xs5), cin, cout))
     if n < 0:
         raise RuntimeError('bad grouped conv geometry')
     ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
     flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0) |
              (FLAG_ACCUM if accum else 0))
-    if CONV_PRECISION == 'bf16' and lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs5), cin, cout):
+    if CONV_PRECISION == 'bf16' and not even_frames and lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs5), cin, cout):
         wpb = packed_weight_bf16(w5, ts, mode)
         check(lib().t2v_conv_fwd_grouped_bf16(arr, len(xs5), cin, cout, _p(wpb), _p(bias), _p(ws), flags, _stream()),
               't2v_conv_fwd_grouped_bf16')
@@ -2665,6 +2668,70 @@ def _group_param_grads(w, b, relu_in, lx, lg, need_w, need_b):
             if not done:
                 gb = ChannelSumG.apply(*lg)
     return gw, gb
+
+
+def even_frames_ok(xs, w):
+    """True when `conv_even_frames_group` can take these members: fp32 mode and the launch lands on the three-taps-per-round
+    strip kernel (the only one that knows frame-strided outputs) — asked of the library's own plan query."""
+    if CONV_PRECISION != 'fp32' or len(xs) > MAX_GROUPS or w.dim() != 5 or not xs[0].is_cuda:
+        return False
+    cout, cin = w.shape[0], w.shape[1]
+    k = tuple(w.shape[2:])
+    geoms = [conv_geom(t.shape[0], cin, t.shape[2], t.shape[3], t.shape[4], cout, k[0], k[1], k[2]) for t in xs]
+    mask = 0
+    for g in geoms:
+        mask |= g.mask
+    ts = _tapset(geoms[0].T, mask)
+    slot_of = {t: j for j, t in enumerate(ts.taps)}
+    arr = _group_table(xs, [None] * len(xs), geoms, slot_of, None, 2)
+    out = (C.c_int32 * 8)()
+    return lib().t2v_conv_fwd_plan(arr, len(xs), cin, cout, FLAG_RELU_IN, out) == 0 and out[0] == 5 and out[7] == 1
+
+
+class ConvEvenFramesG(Function):
+    """ys[i] = conv(relu?(xs[i]), w)[:, :, ::2] (+ b): the stem's second convolution feeds `AvgPool3d((1,2,2), stride 2)`
+    (resnet3d.py:12-19), which keeps the EVEN frames only — the odd output frames are not computed (half the forward GEMM).
+    The adjoint is the plain convolution's, applied to the gradient scattered back to the even frames (zeros elsewhere), i.e.
+    exactly what the pooling adjoint used to hand over; composed of the same differentiable Functions as `ConvG.backward`."""
+
+    @staticmethod
+    def forward(ctx, w, b, relu_in, *xs):
+        ctx.save_for_backward(w, *xs)
+        ctx.set_materialize_grads(False)
+        ctx.has_bias, ctx.relu_in, ctx.bias = b is not None, relu_in, b
+        return tuple(conv_group_raw(xs, w, b, relu_in, 0, even_frames=True))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        saved = ctx.saved_tensors
+        w, xs = saved[0], saved[1:]
+        live = [i for i, g in enumerate(gys) if g is not None]
+        gxs = [None] * len(xs)
+        gw = gb = None
+        if not live:
+            return (None, None, None) + tuple(gxs)
+        # dL/dy on all frames: the even frames carry the gradient, the odd ones zeros (the adjoint of y[:, :, ::2])
+        cfg = ((1, 1, 1), (2, 1, 1), (0, 0, 0))
+        full = AvgPool3dBwdG.apply(tuple(cfg for _ in live), tuple(tuple(xs[i].shape[2:]) for i in live), *[gys[i] for i in live])
+        gfull = [None] * len(xs)
+        for i, g in zip(live, full):
+            gfull[i] = g
+        need = [i for i in live if ctx.needs_input_grad[3 + i]]
+        if need:
+            if ctx.relu_in:
+                res = ConvDgradMaskG.apply(w, len(need), *([gfull[i] for i in need] + [xs[i] for i in need]))
+            else:
+                res = ConvDgradG.apply(w, *[gfull[i] for i in need])
+            for i, r in zip(need, res):
+                gxs[i] = r
+        if _param_grads_enabled:
+            gw, gb = _group_param_grads(w, ctx.bias if ctx.has_bias else None, ctx.relu_in, [xs[i] for i in live],
+                                        [gfull[i] for i in live], ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1])
+        return (gw, gb, None) + tuple(gxs)
+
+
+def conv_even_frames_group(xs, w, b=None, relu_in=False):
+    return list(ConvEvenFramesG.apply(w, b, relu_in, *xs))
 
 
 class ConvMultiG(Function):

@@ -53,9 +53,20 @@ class Resnet3D(nn.Module):
         # penalty) in one launch for all levels instead of one autograd-engine add per level
         xs, xs_skip = TF.fork_group(xs)
         hs = TF.conv_group(xs, m[0].weight, m[0].bias)
-        hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
+        pool_h = None
         if isinstance(m[3], AvgPool3d) and isinstance(idm[0], AvgPool3d):
-            cfg_h = [(m[3].kernel_size, m[3].stride, m[3].padding)] * len(xs)
+            pool_h = (m[3].kernel_size, m[3].stride, m[3].padding)
+            if pool_h[0][0] == 1 and pool_h[1][0] == 2 and pool_h[2][0] == 0 and TF.even_frames_ok(hs, m[2].weight):
+                # AvgPool3d((1,2,2), stride 2) keeps the even frames of conv2 only: compute just those (half the forward GEMM)
+                # and pool what is left with a frame stride of 1
+                hs = TF.conv_even_frames_group(hs, m[2].weight, m[2].bias, relu_in=True)
+                pool_h = (pool_h[0], (1,) + tuple(pool_h[1][1:]), pool_h[2])
+            else:
+                hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
+        else:
+            hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
+        if pool_h is not None:
+            cfg_h = [pool_h] * len(xs)
             cfg_x = [(idm[0].kernel_size, idm[0].stride, idm[0].padding)] * len(xs)
             ss = TF.conv_group(TF.avg_pool3d_group(xs_skip, cfg_x), idm[1].weight, idm[1].bias)
             hs = TF.avg_pool3d_group(hs, cfg_h, adds=ss)                       # pool + residual add, all levels, one launch
