@@ -544,6 +544,30 @@ def test_conv_even_frames_group(members, cin, cout):
     assert got2[1] is None or float(got2[1].abs().max()) == 0.0            # the bias does not enter the data gradient
 
 
+@pytest.mark.parametrize('members,cin,cout', [
+    ([(2, 4, 16, 16), (1, 5, 8, 8), (3, 2, 4, 4)], 64, 64),         # ragged members, odd frame count, non-power-of-two decode
+    ([(4, 16, 16, 16), (2, 8, 32, 32)], 64, 96),                     # power-of-two extents (shift decode), two channel tiles
+])
+def test_weight_gradient_from_even_frame_gradients(members, cin, cout):
+    """`t2v_conv_wgrad_grouped[_bias]` with dstride = 2: dL/dy lives on the even frames only; same dW / db as the full-frame call
+    on the gradient scattered to the even frames (zeros on the odd ones)."""
+    from txt2vid_amd import functional as TF
+    xs = [rnd(30 + i, n, cin, d, h, w).to(dev()) for i, (n, d, h, w) in enumerate(members)]
+    ge = [rnd(40 + i, n, cout, (d + 1) // 2, h, w).to(dev()) for i, (n, d, h, w) in enumerate(members)]
+    gf = []
+    for g, (n, d, h, w) in zip(ge, members):
+        f = torch.zeros(n, cout, d, h, w, device=dev())
+        f[:, :, ::2] = g
+        gf.append(f)
+    shape = (cout, cin, 3, 3, 3)
+    dw_ref, db_ref = torch.empty(shape, device=dev()), torch.empty(cout, device=dev())
+    TF.conv_group_wgrad_raw(xs, gf, shape, True, out=dw_ref, dbias=db_ref)
+    dw, db = torch.full(shape, 3.0, device=dev()), torch.full((cout,), -2.0, device=dev())
+    TF.conv_group_wgrad_raw(xs, ge, shape, True, out=dw, dbias=db, even_frames=True)
+    close(dw, dw_ref, rtol=1e-4, atol=1e-3)
+    close(db, db_ref, rtol=1e-4, atol=1e-3)
+
+
 def test_cat_features_group_first_and_second_order():
     """`T2V_MJ_CATCOLS / SLICECOLS / EMBEDCOLS`: torch.cat((features, cond), 1) of every level in one launch, closed under
     differentiation (the conditional heads take part in the gradient penalty's double backward)."""

@@ -2780,6 +2780,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
     // ---- the member the current chunk range lies in (scalar state, reloaded when q passes g_end)
     int g_i = -1, g_begin = 0, g_end = 0;
     int gD = 1, gH = 1, gW = 1, gHW = 1, gDHW = 1, gM = 0, g_lw = 0, g_lhw = 0, g_shift = 0;
+    int gDHWo = 1, g_ds = 1, g_lo = 0;        // frame-strided dL/dy (dstride = 2): its own frame count / voxel count, log2 of the latter
     bool g_pow2 = false;
     // buffer descriptors of the member's x and dL/dy: 32-bit byte offsets in the gathers (one add, no 64-bit address
     // arithmetic), out-of-range offsets read 0. Built from kernel-argument scalars only (provably wave-uniform).
@@ -2794,51 +2795,59 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
         g_i = gi;
         g_begin = tab.chunk_start[gi];
         g_end = tab.chunk_start[gi + 1];
-        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW; gM = gd.N * gDHW;
-        g_pow2 = ((gD & (gD - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
+        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW;
+        g_ds = gd.dstride == 2 ? 2 : 1;
+        const int Do = g_ds == 2 ? (gD + 1) / 2 : gD;
+        gDHWo = Do * gHW;
+        gM = gd.N * gDHWo;                                          // chunks run over the voxels of dL/dy
+        g_pow2 = ((Do & (Do - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
         g_lw = __builtin_ctz(gW);
         g_lhw = g_lw + __builtin_ctz(gH);
+        g_lo = g_lhw + __builtin_ctz(Do);
         g_shift = dz * gHW + dy * gW;
-        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)gM * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * gDHW) * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
         g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
     };
 
     auto load_chunk = [&](int q) {
         if (q >= g_end || g_i < 0) enter_group(q);                  // (uniform)
-        const int D = gD, H = gH, W = gW, HW = gHW, DHW = gDHW;
-        const int m = (q - g_begin) * WG_BK + ml;
+        const int D = gD, H = gH, W = gW, HW = gHW, DHW = gDHW, DHWo = gDHWo;
+        const int m = (q - g_begin) * WG_BK + ml;                   // voxel of dL/dy: (n, d_o, h, w)
         const bool mv = m < gM;
-        int sp, d, h, w_;
+        int n, spo, d_o, h, w_;
         if (g_pow2) {                                               // (uniform) every extent a power of two: shifts
-            sp = m & (DHW - 1);
-            d = sp >> g_lhw;
-            h = (sp >> g_lw) & (H - 1);
-            w_ = sp & (W - 1);
+            n = m >> g_lo;
+            spo = m & (DHWo - 1);
+            d_o = spo >> g_lhw;
+            h = (spo >> g_lw) & (H - 1);
+            w_ = spo & (W - 1);
         } else {
             const bool small = gM < (1 << 24);
-            const int n = small ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW;
-            sp = m - n * DHW;
-            d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
-            const int r = sp - d * HW;
+            n = small ? fast_div(m, DHWo, 1.0f / (float)DHWo) : m / DHWo;
+            spo = m - n * DHWo;
+            d_o = small ? fast_div(spo, HW, 1.0f / (float)HW) : spo / HW;
+            const int r = spo - d_o * HW;
             h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
             w_ = r - h * W;
         }
+        const int d = d_o * g_ds;                                   // the input frame this dL/dy voxel sits on
+        const int sp = spo + d_o * (g_ds - 1) * HW;                 // ... and its voxel index inside the sample of x
         const bool vc = mv && (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H;
-        // element offsets of (n, channel 0, voxel): n*DHW = m - sp
-        const uint32_t gbase = mv ? (uint32_t)(m - sp) * (uint32_t)Cout + (uint32_t)sp : 0u;
-        const uint32_t xb = vc ? (uint32_t)(m - sp) * (uint32_t)Cin + (uint32_t)(sp + g_shift) : 0u;
+        // element offsets of (n, channel 0, voxel) in dL/dy and in x
+        const uint32_t gbase = mv ? (uint32_t)(n * DHWo) * (uint32_t)Cout + (uint32_t)spo : 0u;
+        const uint32_t xb = vc ? (uint32_t)(n * DHW) * (uint32_t)Cin + (uint32_t)(sp + g_shift) : 0u;
         // wave-uniform validity masks (every wave sees the same 32 voxels in lanes 0-31)
         pm0 = (uint32_t)__ballot(vc && w_ >= 1);
         pm1 = (uint32_t)__ballot(vc);
         pm2 = (uint32_t)__ballot(vc && w_ + 1 < W);
         pend_mv = mv;
-        const uint32_t uDHW = (uint32_t)DHW;
+        const uint32_t uDHW = (uint32_t)DHW, uDHWo = (uint32_t)DHWo;
         if (full) {                                                 // rows rl, rl+8, ...: a constant (scalar) stride apart
-            const uint32_t oa = (gbase + (uint32_t)(co0 + rl) * uDHW) * 4u, ob = (xb + (uint32_t)(ci0 + rl) * uDHW) * 4u;
-            const int st = 32 * DHW;                                // 8 rows, in bytes
+            const uint32_t oa = (gbase + (uint32_t)(co0 + rl) * uDHWo) * 4u, ob = (xb + (uint32_t)(ci0 + rl) * uDHW) * 4u;
+            const int st = 32 * DHW, sty = 32 * DHWo;               // 8 rows, in bytes
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, oa, p * st, 0));
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, oa, p * sty, 0));
                 rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, ob, p * st, 0));
             }
         } else {
@@ -2846,7 +2855,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
             for (int p = 0; p < 8; ++p) {                           // clamped rows (zeroed when staged)
                 const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
                 ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uDHW) * 4u, 0, 0));
+                    g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uDHWo) * 4u, 0, 0));
                 rb[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     g_x, (xb + (uint32_t)(ci < Cin ? ci : Cin - 1) * uDHW) * 4u, 0, 0));
             }
@@ -3096,18 +3105,20 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
     if ((kD != 1 && kD != 3) || (kH != 1 && kH != 3) || (kW != 1 && kW != 3)) return false;
     long nch = 0, maxMC = 0;
+    bool strided = false;
     p.live = 0;
     tab.n = ngroups;
     for (int i = 0; i < ngroups; ++i) {
         const t2v_conv_group& g = groups[i];
         if (need_ptrs && (!g.x || !g.y)) return false;
-        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.dstride < 0 || g.dstride > 1) return false;      // (no frame stride here)
+        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.dstride < 0 || g.dstride > 2) return false;
+        if (g.dstride == 2) strided = true;          // dL/dy lives on the even frames only ([N,Cout,ceil(D/2),H,W]): 3-tap-row kernel only
         const long M = (long)g.N * g.D * g.H * g.W;
         if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return false;     // the gathers use 32-bit BYTE offsets (buffer loads)
         if (M * (long)(Cin > Cout ? Cin : Cout) > maxMC) maxMC = M * (long)(Cin > Cout ? Cin : Cout);
         tab.g[i] = g;
         tab.chunk_start[i] = (int32_t)nch;
-        nch += (M + WG_BK - 1) / WG_BK;
+        nch += ((long)g.N * out_frames(g) * g.H * g.W + WG_BK - 1) / WG_BK;       // chunks run over the voxels of dL/dy
         for (int a = 0; a < kD; ++a) for (int b = 0; b < kH; ++b) for (int c = 0; c < kW; ++c) {
             const int dz = a - kD / 2, dy = b - kH / 2, dx = c - kW / 2;
             if (!((g.D == 1 && dz) || (g.H == 1 && dy) || (g.W == 1 && dx))) p.live |= 1u << ((a * kH + b) * kW + c);
@@ -3120,6 +3131,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     bool anyw = false;
     for (int i = 0; i < ngroups; ++i) anyw = anyw || groups[i].W > 1;
     p.rows3 = (kW == 3) && anyw && Cin >= 64 && maxMC < (1L << 30);   // the 3-tap kernel gathers through 32-bit byte offsets
+    if (strided && !p.rows3) return false;
     p.liverows = 0;
     for (int r = 0; r < kD * kH; ++r)
         if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;
@@ -3246,7 +3258,7 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
             const int dz = a - kD / 2, dy = b - kH / 2, dx = c - kW / 2;
             if (!((groups[i].D == 1 && dz) || (groups[i].H == 1 && dy) || (groups[i].W == 1 && dx))) ++live_g;
         }
-        flops += 2.0 * (double)groups[i].N * groups[i].D * groups[i].H * groups[i].W * Cout * Cin * live_g;
+        flops += 2.0 * (double)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W * Cout * Cin * live_g;
     }
     // grid.y runs over the taps at least one member can touch; the others are written as zeros by the reduce
     {

@@ -239,7 +239,7 @@ def grad_sink_flush():
         _grad_sink.flush()
 
 
-def _to_sink_wb(w, b, xs, gys, relu_in):
+def _to_sink_wb(w, b, xs, gys, relu_in, even_frames=False):
     """Weight AND bias gradient of one (grouped) convolution into their sink slots with ONE weight-gradient launch
     (`t2v_conv_wgrad_grouped_bias`: the 3-tap-row kernel sums the dL/dy tiles it stages anyway). Returns
     (handled, gw, gb) like `_to_sink`."""
@@ -252,13 +252,15 @@ def _to_sink_wb(w, b, xs, gys, relu_in):
     wflat, wacc = _grad_sink.take(wbase, deferred)
     bflat, bacc = _grad_sink.take(b, deferred)
     if deferred:
-        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, b, bflat, bacc)
+        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, b, bflat, bacc,
+                                 even_frames=even_frames)
     else:
-        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
+        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc,
+                             even_frames=even_frames)
     return True, (None if wacc else wflat.view(w.shape)), (None if bacc else bflat.view(b.shape))
 
 
-def _to_sink_w(w, xs, gys, relu_in):
+def _to_sink_w(w, xs, gys, relu_in, even_frames=False):
     """Weight gradient of one (grouped) convolution into its sink slot, deferred when the sink batches its reductions.
     Returns (handled, gw) like `_to_sink`."""
     if _grad_sink is None or w is None or torch.is_grad_enabled():
@@ -268,9 +270,10 @@ def _to_sink_w(w, xs, gys, relu_in):
         return False, None
     wflat, wacc = _grad_sink.take(wbase, _grad_sink.defer)
     if _grad_sink.defer:
-        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, None, None, False)
+        conv_group_wgrad_partial(xs, gys, tuple(w.shape), relu_in, _grad_sink, wbase, wflat.view(w.shape), wacc, None, None, False,
+                                 even_frames=even_frames)
     else:
-        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc)
+        conv_group_wgrad_raw(xs, gys, tuple(w.shape), relu_in, out=wflat.view(w.shape), accum=wacc, even_frames=even_frames)
     return True, (None if wacc else wflat.view(w.shape))
 
 
@@ -2538,12 +2541,12 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=N
     return ys
 
 
-def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False, dbias=None, accum_bias=False):
+def conv_group_wgrad_raw(xs5, gys5, wshape, relu_in=False, out=None, accum=False, dbias=None, accum_bias=False, even_frames=False):
     xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
     Cout, Cin = wshape[0], wshape[1]
     k = tuple(wshape[2:])
     geoms = [conv_geom(t.shape[0], Cin, t.shape[2], t.shape[3], t.shape[4], Cout, k[0], k[1], k[2]) for t in xs5]
-    arr = _group_table(xs5, gys5, geoms, None)
+    arr = _group_table(xs5, gys5, geoms, None, None, 2 if even_frames else 0)        # even_frames: dL/dy on the even frames only
     query = lib().t2v_conv_wgrad_grouped_bias_slab_floats if dbias is not None else lib().t2v_conv_wgrad_grouped_slab_floats
     n = int(query(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
     if n <= 0:
@@ -2566,13 +2569,13 @@ def _wgrad_bias_fused(xs5, wshape):
     return True
 
 
-def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None):
+def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None, even_frames=False):
     """The weight-gradient main kernel alone: returns (WgradSrc describing the k-split partial sums, the slab holding them)."""
     xs5, gys5 = [_c(t) for t in xs5], [_c(t) for t in gys5]
     Cout, Cin = wshape[0], wshape[1]
     k = tuple(wshape[2:])
     geoms = [conv_geom(t.shape[0], Cin, t.shape[2], t.shape[3], t.shape[4], Cout, k[0], k[1], k[2]) for t in xs5]
-    arr = _group_table(xs5, gys5, geoms, None)
+    arr = _group_table(xs5, gys5, geoms, None, None, 2 if even_frames else 0)
     query = lib().t2v_conv_wgrad_grouped_bias_slab_floats if want_bias else lib().t2v_conv_wgrad_grouped_slab_floats
     n = int(query(arr, len(xs5), Cin, Cout, k[0], k[1], k[2]))
     if n <= 0:
@@ -2585,10 +2588,10 @@ def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None):
     return src, slab
 
 
-def conv_group_wgrad_partial(xs5, gys5, wshape, relu_in, sink, wbase, dw, wacc, b, dbias, bacc):
+def conv_group_wgrad_partial(xs5, gys5, wshape, relu_in, sink, wbase, dw, wacc, b, dbias, bacc, even_frames=False):
     """The weight-gradient launch WITHOUT its reduce pass: the k-split partial sums stay in a slab that `sink` keeps alive
     and sums (with every other pending slab) in its one `flush()` launch."""
-    src, slab = _wgrad_partial_launch(xs5, gys5, wshape, relu_in, b is not None, sink)
+    src, slab = _wgrad_partial_launch(xs5, gys5, wshape, relu_in, b is not None, sink, even_frames)
     k = tuple(wshape[2:])
     sink.add_partial(wbase, dw, wacc, b, dbias, bacc, src, slab, k[0] * k[1] * k[2], wshape[0], wshape[0] * wshape[1])
 
@@ -2725,8 +2728,17 @@ class ConvEvenFramesG(Function):
             for i, r in zip(need, res):
                 gxs[i] = r
         if _param_grads_enabled:
-            gw, gb = _group_param_grads(w, ctx.bias if ctx.has_bias else None, ctx.relu_in, [xs[i] for i in live],
-                                        [gfull[i] for i in live], ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1])
+            need_w, need_b = ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1]
+            lx, lg = [xs[i] for i in live], [gys[i] for i in live]
+            done = False
+            if need_w and not torch.is_grad_enabled() and w.shape[1] >= 64 and w.shape[4] == 3 and any(t.shape[4] > 1 for t in lx):
+                # gradient sink armed: the weight-gradient kernel reads dL/dy on the even frames as it is (half the voxels)
+                if need_b:
+                    done, gw, gb = _to_sink_wb(w, ctx.bias, lx, lg, ctx.relu_in, even_frames=True)
+                else:
+                    done, gw = _to_sink_w(w, lx, lg, ctx.relu_in, even_frames=True)
+            if not done:
+                gw, gb = _group_param_grads(w, ctx.bias if ctx.has_bias else None, ctx.relu_in, lx, [gfull[i] for i in live], need_w, need_b)
         return (gw, gb, None) + tuple(gxs)
 
 
