@@ -51,7 +51,13 @@ typedef struct {
     int32_t ntaps;
     int32_t dstride;     /* 0 / 1: every frame; 2 (forward launches on the strip3 kernels only): y holds the EVEN frames only,
                             [N,Cout,ceil(D/2),H,W] — the stem's conv2 -> AvgPool3d((1,2,2), stride 2) pair (resnet3d.py:12-19) drops the
-                            odd frames of conv2, so they are not computed. Other entry points reject 2. */
+                            odd frames of conv2, so they are not computed. The weight-gradient 3-tap-row kernel takes 2 as well (dL/dy
+                            on the even frames only). Other entry points reject it. */
+    int32_t ydstride;    /* 0 / 1: y is dense. 2 (strip3 forward launches, i.e. the data gradient of the pair above): GEMM row
+                            (n, e, h, w) is written to frame 2e + yoff of y [N,Cout,Dy,H,W]; x (dL/dy on the even frames) has D
+                            frames, rows run over e < (Dy + 1 - yoff) / 2. Two launches (yoff = 0 with the dz = 0 taps, yoff = 1 with
+                            the dz = -1 / +1 taps re-based to x frames e, e + 1) write every frame of y exactly once. */
+    int32_t yoff, Dy;
     int8_t dz[T2V_MAX_TAPS], dy[T2V_MAX_TAPS], dx[T2V_MAX_TAPS], widx[T2V_MAX_TAPS];
 } t2v_conv_group;
 

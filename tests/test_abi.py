@@ -51,7 +51,7 @@ def test_geometry_struct_layout_matches_header():
     from txt2vid_amd._lib import ConvGeom
     assert ctypes.sizeof(ConvGeom) == 7 * 4 + 3 * 27 + 3
     from txt2vid_amd._lib import ConvGroup
-    assert ctypes.sizeof(ConvGroup) == 160                             # 3 pointers + 6 int32 (incl. dstride) + 4 x 27 int8 = 156, padded to 8
+    assert ctypes.sizeof(ConvGroup) == 168                             # 3 pointers + 9 int32 (incl. dstride, ydstride, yoff, Dy) + 4 x 27 int8
 
 
 def test_argument_validation_without_gpu(built):

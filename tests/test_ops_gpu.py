@@ -541,6 +541,11 @@ def test_conv_even_frames_group(members, cin, cout):
     for a, r in zip(got1, ref1):
         close(a, r, rtol=2e-3, atol=2e-3)
     close(got2[0], ref2[0], rtol=5e-3, atol=5e-3)                           # d penalty / d w through the recorded backward
+    # first order WITHOUT a recorded graph: the data gradient comes from two strided-output launches on the even-frame gradients
+    ys = TF.conv_even_frames_group(xs, w, b, relu_in=True)
+    plain = torch.autograd.grad(sum((o * g.to(dev())).sum() for o, g in zip(ys, gys)), xs + [w, b])
+    for a, r in zip(plain, ref1):
+        close(a, r, rtol=2e-3, atol=2e-3)
     assert got2[1] is None or float(got2[1].abs().max()) == 0.0            # the bias does not enter the data gradient
 
 

@@ -24,7 +24,7 @@ class ConvGeom(C.Structure):
 class ConvGroup(C.Structure):
     """Mirror of `t2v_conv_group` (include/t2v_hip.h)."""
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('mask', C.c_void_p), ('N', C.c_int32), ('D', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
-                ('ntaps', C.c_int32), ('dstride', C.c_int32),
+                ('ntaps', C.c_int32), ('dstride', C.c_int32), ('ydstride', C.c_int32), ('yoff', C.c_int32), ('Dy', C.c_int32),
                 ('dz', C.c_int8 * MAX_TAPS), ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS), ('widx', C.c_int8 * MAX_TAPS)]
 
 

@@ -290,7 +290,9 @@ template <int NCO, int NM, int WCO, int WM>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[NCO][NM], const GroupTable& tab, const int gi, const t2v_conv_group& gd,
                                                const float* __restrict__ bias, float* __restrict__ slab, const int Cout,
                                                const int flags, const int nsplit, const int m0, const int co0, const int M,
-                                               const int DHW, const int wm, const int wco, const int l31, const int hi) {
+                                               const int DHW, const int wm, const int wco, const int l31, const int hi,
+                                               const int yds = 1, const int yoff = 0, const int DHWy = 0, const int HW = 1) {
+    // yds == 2 (ydstride): row (n, e, r) of the GEMM goes to frame 2e + yoff of a y with DHWy voxels per sample and channel
     const bool split = nsplit > 1;
     const bool has_bias = !split && (flags & T2V_CONV_BIAS) && bias != nullptr;
     const bool accum = !split && (flags & T2V_CONV_ACCUM);
@@ -300,23 +302,30 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[NCO][NM], const Gro
     for (int j = 0; j < NM; ++j) {
         const int m = m0 + wm * WM + j * 32 + l31;
         if (m >= M) continue;
-        const int n = m / DHW, sp = m - n * DHW;
-        float* py = out + (size_t)n * Cout * DHW + sp;
+        const int n = m / DHW;
+        int sp = m - n * DHW;
+        int cs = DHW;                      // channel stride of y
+        if (yds == 2) {
+            const int e = sp / HW;
+            sp += (e + yoff) * HW;         // (2e + yoff) * HW + r
+            cs = DHWy;
+        }
+        float* py = out + (size_t)n * Cout * cs + sp;
         if (mask_out) {                    // ReLU adjoint fused: y = mask > 0 ? result : 0
-            const float* pm = gd.mask + (size_t)n * Cout * DHW + sp;
+            const float* pm = gd.mask + (size_t)n * Cout * cs + sp;
 #pragma unroll
             for (int i = 0; i < NCO; ++i) {
                 float mv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    mv[r] = pm[(size_t)(co < Cout ? co : Cout - 1) * DHW];
+                    mv[r] = pm[(size_t)(co < Cout ? co : Cout - 1) * cs];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const float v = acc[i][j][r] + (has_bias ? bias[co < Cout ? co : 0] : 0.f);
-                    if (co < Cout) py[(size_t)co * DHW] = mv[r] > 0.f ? v : 0.f;
+                    if (co < Cout) py[(size_t)co * cs] = mv[r] > 0.f ? v : 0.f;
                 }
             }
         } else if (!accum) {               // (block-uniform) plain stores: no load, no wait in the store tail
@@ -325,7 +334,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[NCO][NM], const Gro
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < Cout) py[(size_t)co * DHW] = acc[i][j][r] + (has_bias ? bias[co] : 0.f);
+                    if (co < Cout) py[(size_t)co * cs] = acc[i][j][r] + (has_bias ? bias[co] : 0.f);
                 }
             }
         } else {
@@ -334,7 +343,7 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[NCO][NM], const Gro
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wco * WCO + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < Cout) py[(size_t)co * DHW] += acc[i][j][r] + (has_bias ? bias[co] : 0.f);
+                    if (co < Cout) py[(size_t)co * cs] += acc[i][j][r] + (has_bias ? bias[co] : 0.f);
                 }
             }
         }
@@ -819,7 +828,10 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     // frame-strided output (dstride = 2: the stem's conv2 feeds a pooling that keeps the even frames only): GEMM rows run over
     // the output voxels [N, Do, H, W]; row (n, do, r) gathers around input frame d = 2 do
     const int ds = gd.dstride == 2 ? 2 : 1;
-    const int Do = ds == 2 ? (D + 1) / 2 : D;
+    // strided OUTPUT (ydstride = 2: the data gradient of that pair): rows (n, e, r) read x frame e (+ dz) and are written to
+    // frame 2e + yoff of y, rows run over the frames of that parity
+    const int yds = gd.ydstride == 2 ? 2 : 1;
+    const int Do = yds == 2 ? (gd.Dy + 1 - gd.yoff) / 2 : (ds == 2 ? (D + 1) / 2 : D);
     const int DHWo = Do * HW;
     const int M = gd.N * DHWo;
     const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
@@ -988,7 +1000,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
-    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi);
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi, yds, gd.yoff,
+                                     gd.Dy * HW, HW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1802,10 +1815,15 @@ static const Tunables& tun() {
 
 struct ConvPlan { int bm, bn, bk; bool fast, vecb; int S; long tiles; bool dstride2; };
 
-static inline int out_frames(const t2v_conv_group& g) { return g.dstride == 2 ? (g.D + 1) / 2 : g.D; }
+// frames the GEMM rows of a member run over: every frame; the even ones (dstride = 2); one parity of y's frames (ydstride = 2)
+static inline int out_frames(const t2v_conv_group& g) {
+    if (g.ydstride == 2) return (g.Dy + 1 - g.yoff) / 2;
+    return g.dstride == 2 ? (g.D + 1) / 2 : g.D;
+}
 static bool group_ok(const t2v_conv_group& g, bool need_ptrs) {
     if (need_ptrs && (!g.x || !g.y)) return false;
-    if (g.dstride < 0 || g.dstride > 2) return false;
+    if (g.dstride < 0 || g.dstride > 2 || g.ydstride < 0 || g.ydstride > 2) return false;
+    if (g.ydstride == 2 && (g.dstride == 2 || g.yoff < 0 || g.yoff > 1 || g.Dy < 1 || (g.Dy + 1 - g.yoff) / 2 < 1 || g.D < (g.Dy + 1) / 2)) return false;
     if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.ntaps < 1 || g.ntaps > T2V_MAX_TAPS) return false;
     for (int t = 0; t < g.ntaps; ++t) {
         if (g.dz[t] < -1 || g.dz[t] > 1 || g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
@@ -1825,7 +1843,7 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
         const long Min = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
         if (Min * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return false;     // 32-bit voxel indices
         const long M = (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;      // GEMM rows = output voxels
-        if (groups[i].dstride == 2) p.dstride2 = true;
+        if (groups[i].dstride == 2 || groups[i].ydstride == 2) p.dstride2 = true;
         Mtot += M;
         if (M > Mmax) Mmax = M;
         if (groups[i].ntaps > max_chunk_taps) max_chunk_taps = groups[i].ntaps;
@@ -2055,7 +2073,7 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
     const bool thin = thin_ok(groups, ngroups, Cin, Cout, nslots);
     if (!thin && p.S > 1 && !ws) return T2V_EINVAL;
     if (p.dstride2) {                      // frame-strided outputs: the three-taps-per-round strip kernels only
-        if (thin || (flags & (T2V_CONV_MASK_OUT | T2V_CONV_ACCUM))) return T2V_EINVAL;
+        if (thin || (flags & T2V_CONV_ACCUM)) return T2V_EINVAL;
         bool s3 = false;
         if (p.bn == 64 && p.bm == 256) s3 = conv_variant(tab, p, 256, 64, 16, Cin, Cout, flags).s3;
         else if (p.bn == 64 && p.bk == 32) s3 = conv_variant(tab, p, p.bm, 64, 32, Cin, Cout, flags).s3;
@@ -2215,7 +2233,7 @@ static bool geom_ok(const t2v_conv_geom* g) {
 static t2v_conv_group group_of(const t2v_conv_geom* g, const float* x, float* y) {
     t2v_conv_group q;
     q.x = x; q.y = y; q.mask = nullptr;
-    q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps; q.dstride = 0;
+    q.N = g->N; q.D = g->D; q.H = g->H; q.W = g->W; q.ntaps = g->ntaps; q.dstride = 0; q.ydstride = 0; q.yoff = 0; q.Dy = 0;
     for (int t = 0; t < T2V_MAX_TAPS; ++t) {
         q.dz[t] = t < g->ntaps ? g->dz[t] : 0; q.dy[t] = t < g->ntaps ? g->dy[t] : 0; q.dx[t] = t < g->ntaps ? g->dx[t] : 0;
         q.widx[t] = (int8_t)(t < g->ntaps ? t : 0);
@@ -3111,7 +3129,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     for (int i = 0; i < ngroups; ++i) {
         const t2v_conv_group& g = groups[i];
         if (need_ptrs && (!g.x || !g.y)) return false;
-        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.dstride < 0 || g.dstride > 2) return false;
+        if (g.N < 1 || g.D < 1 || g.H < 1 || g.W < 1 || g.dstride < 0 || g.dstride > 2 || g.ydstride > 1 || g.ydstride < 0) return false;
         if (g.dstride == 2) strided = true;          // dL/dy lives on the even frames only ([N,Cout,ceil(D/2),H,W]): 3-tap-row kernel only
         const long M = (long)g.N * g.D * g.H * g.W;
         if (M * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return false;     // the gathers use 32-bit BYTE offsets (buffer loads)

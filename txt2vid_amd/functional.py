@@ -2691,6 +2691,51 @@ def even_frames_ok(xs, w):
     return lib().t2v_conv_fwd_plan(arr, len(xs), cin, cout, FLAG_RELU_IN, out) == 0 and out[0] == 5 and out[7] == 1
 
 
+def _dgrad_even_frames_raw(gys, w5, masks):
+    """Data gradient of `ConvEvenFramesG` straight from dL/dy on the EVEN frames (gys[i]: [N,Cout,ceil(D/2),H,W]): output frame
+    2e only sees the dz = 0 taps (9 of 27), frame 2e + 1 the dz = -1 / +1 taps reading dL/dy frames e / e + 1 (18) — half the
+    MACs of the full-frame data gradient of the zero-stuffed tensor, and no zero-stuffing pass. Two strided-output launches
+    (`t2v_conv_group.ydstride`) write every frame once; `masks` (the conv's input, for the fused ReLU adjoint) or None.
+    Returns the list of gradients [N,Cin,D,H,W], or None when a launch would not land on the strip3 kernel."""
+    gys = [_c(g) for g in gys]
+    Cout, Cin = w5.shape[0], w5.shape[1]
+    if tuple(w5.shape[2:]) != (3, 3, 3) or CONV_PRECISION != 'fp32' or len(gys) > MAX_GROUPS:
+        return None
+    shapes = [tuple(m.shape) for m in masks]
+    if any(sh[3] < 2 or sh[4] < 2 or g.shape[2] != (sh[2] + 1) // 2 for g, sh in zip(gys, shapes)):
+        return None
+    ts = _tapset(27, (1 << 27) - 1)
+    slot_of = {t: j for j, t in enumerate(ts.taps)}
+    outs = [torch.empty(sh, device=g.device, dtype=torch.float32) for g, sh in zip(gys, shapes)]
+    launches = []
+    for yoff, planes in ((0, ((1, 0),)), (1, ((0, 0), (2, 1)))):           # (kernel plane a of the mirrored weight, dL/dy frame offset)
+        mem = [i for i, sh in enumerate(shapes) if (sh[2] + 1 - yoff) // 2 >= 1]
+        if not mem:
+            continue
+        arr = (ConvGroup * len(mem))()
+        for a_, i in zip(arr, mem):
+            g, sh = gys[i], shapes[i]
+            a_.x, a_.y, a_.mask = g.data_ptr(), outs[i].data_ptr(), masks[i].data_ptr()
+            a_.N, a_.D, a_.H, a_.W = g.shape[0], g.shape[2], g.shape[3], g.shape[4]
+            a_.dstride, a_.ydstride, a_.yoff, a_.Dy = 0, 2, yoff, sh[2]
+            j = 0
+            for pa, dzc in planes:
+                for b in range(3):
+                    for c in range(3):
+                        a_.dz[j], a_.dy[j], a_.dx[j] = dzc, b - 1, c - 1
+                        a_.widx[j] = slot_of[(pa * 3 + b) * 3 + c]
+                        j += 1
+            a_.ntaps = j
+        plan = (C.c_int32 * 8)()
+        if lib().t2v_conv_fwd_plan(arr, len(mem), Cout, Cin, FLAG_MASK_OUT, plan) != 0 or plan[0] != 5 or plan[7] != 1:
+            return None
+        launches.append((arr, len(mem)))
+    wp = packed_weight(w5, ts, 1)
+    for arr, n in launches:
+        check(lib().t2v_conv_fwd_grouped(arr, n, Cout, Cin, _p(wp), None, None, FLAG_MASK_OUT, _stream()), 't2v_conv_fwd_grouped')
+    return outs
+
+
 class ConvEvenFramesG(Function):
     """ys[i] = conv(relu?(xs[i]), w)[:, :, ::2] (+ b): the stem's second convolution feeds `AvgPool3d((1,2,2), stride 2)`
     (resnet3d.py:12-19), which keeps the EVEN frames only — the odd output frames are not computed (half the forward GEMM).
@@ -2713,14 +2758,26 @@ class ConvEvenFramesG(Function):
         gw = gb = None
         if not live:
             return (None, None, None) + tuple(gxs)
-        # dL/dy on all frames: the even frames carry the gradient, the odd ones zeros (the adjoint of y[:, :, ::2])
-        cfg = ((1, 1, 1), (2, 1, 1), (0, 0, 0))
-        full = AvgPool3dBwdG.apply(tuple(cfg for _ in live), tuple(tuple(xs[i].shape[2:]) for i in live), *[gys[i] for i in live])
-        gfull = [None] * len(xs)
-        for i, g in zip(live, full):
-            gfull[i] = g
         need = [i for i in live if ctx.needs_input_grad[3 + i]]
-        if need:
+        fast = None
+        if need and ctx.relu_in and not torch.is_grad_enabled():
+            # no graph is being recorded: the data gradient straight from the even-frame gradients (two strided-output launches)
+            fast = _dgrad_even_frames_raw([gys[i] for i in need], w, [xs[i] for i in need])
+            if fast is not None:
+                for i, r in zip(need, fast):
+                    gxs[i] = r
+        gfull = [None] * len(xs)
+
+        def full_frames():
+            # dL/dy on all frames: the even frames carry the gradient, the odd ones zeros (the adjoint of y[:, :, ::2])
+            if all(gfull[i] is None for i in live):
+                cfg = ((1, 1, 1), (2, 1, 1), (0, 0, 0))
+                full = AvgPool3dBwdG.apply(tuple(cfg for _ in live), tuple(tuple(xs[i].shape[2:]) for i in live), *[gys[i] for i in live])
+                for i, g in zip(live, full):
+                    gfull[i] = g
+            return gfull
+        if need and fast is None:
+            full_frames()
             if ctx.relu_in:
                 res = ConvDgradMaskG.apply(w, len(need), *([gfull[i] for i in need] + [xs[i] for i in need]))
             else:
@@ -2738,6 +2795,7 @@ class ConvEvenFramesG(Function):
                 else:
                     done, gw = _to_sink_w(w, lx, lg, ctx.relu_in, even_frames=True)
             if not done:
+                full_frames()
                 gw, gb = _group_param_grads(w, ctx.bias if ctx.has_bias else None, ctx.relu_in, lx, [gfull[i] for i in live], need_w, need_b)
         return (gw, gb, None) + tuple(gxs)
 
