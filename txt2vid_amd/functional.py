@@ -2691,12 +2691,13 @@ def even_frames_ok(xs, w):
     return lib().t2v_conv_fwd_plan(arr, len(xs), cin, cout, FLAG_RELU_IN, out) == 0 and out[0] == 5 and out[7] == 1
 
 
-def _dgrad_even_frames_raw(gys, w5, masks):
+def _dgrad_even_frames_raw(gys, w5, masks, plan_only=False):
     """Data gradient of `ConvEvenFramesG` straight from dL/dy on the EVEN frames (gys[i]: [N,Cout,ceil(D/2),H,W]): output frame
     2e only sees the dz = 0 taps (9 of 27), frame 2e + 1 the dz = -1 / +1 taps reading dL/dy frames e / e + 1 (18) — half the
     MACs of the full-frame data gradient of the zero-stuffed tensor, and no zero-stuffing pass. Two strided-output launches
     (`t2v_conv_group.ydstride`) write every frame once; `masks` (the conv's input, for the fused ReLU adjoint) or None.
-    Returns the list of gradients [N,Cin,D,H,W], or None when a launch would not land on the strip3 kernel."""
+    Returns the list of gradients [N,Cin,D,H,W], or None when a launch would not land on the strip3 kernel (`plan_only`: True /
+    None without launching anything)."""
     gys = [_c(g) for g in gys]
     Cout, Cin = w5.shape[0], w5.shape[1]
     if tuple(w5.shape[2:]) != (3, 3, 3) or CONV_PRECISION != 'fp32' or len(gys) > MAX_GROUPS:
@@ -2706,7 +2707,7 @@ def _dgrad_even_frames_raw(gys, w5, masks):
         return None
     ts = _tapset(27, (1 << 27) - 1)
     slot_of = {t: j for j, t in enumerate(ts.taps)}
-    outs = [torch.empty(sh, device=g.device, dtype=torch.float32) for g, sh in zip(gys, shapes)]
+    outs = [torch.empty(sh, device=g.device, dtype=torch.float32) if not plan_only else g for g, sh in zip(gys, shapes)]
     launches = []
     for yoff, planes in ((0, ((1, 0),)), (1, ((0, 0), (2, 1)))):           # (kernel plane a of the mirrored weight, dL/dy frame offset)
         mem = [i for i, sh in enumerate(shapes) if (sh[2] + 1 - yoff) // 2 >= 1]
@@ -2730,10 +2731,52 @@ def _dgrad_even_frames_raw(gys, w5, masks):
         if lib().t2v_conv_fwd_plan(arr, len(mem), Cout, Cin, FLAG_MASK_OUT, plan) != 0 or plan[0] != 5 or plan[7] != 1:
             return None
         launches.append((arr, len(mem)))
+    if plan_only:
+        return True
     wp = packed_weight(w5, ts, 1)
     for arr, n in launches:
         check(lib().t2v_conv_fwd_grouped(arr, n, Cout, Cin, _p(wp), None, None, FLAG_MASK_OUT, _stream()), 't2v_conv_fwd_grouped')
     return outs
+
+
+class ConvDgradEvenMaskG(Function):
+    """The recorded (gradient-penalty) form of `_dgrad_even_frames_raw`: gxs[i] = dgrad(zero-stuffed gys[i], w) * [xs[i] > 0] from
+    the even-frame gradients. Its adjoints stay in even-frame form: d/d gys = the even frames of conv(masked ggx, w)
+    (`ConvEvenFramesG`), d/d w = the even-frame weight gradient — conv / dgrad / wgrad stay a closed triple."""
+
+    @staticmethod
+    def forward(ctx, w, n, *gys_xs):
+        gys, xs = gys_xs[:n], gys_xs[n:]
+        ctx.save_for_backward(w, *gys_xs)
+        ctx.set_materialize_grads(False)
+        ctx.n = n
+        out = _dgrad_even_frames_raw(gys, w, xs)
+        if out is None:
+            raise RuntimeError('ConvDgradEvenMaskG: launch plan changed between the check and the launch')
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *ggxs):
+        saved = ctx.saved_tensors
+        n = ctx.n
+        w, gys, xs = saved[0], saved[1:1 + n], saved[1 + n:]
+        live = [i for i, g in enumerate(ggxs) if g is not None]
+        d_w = None
+        d_gys = [None] * n
+        if live:
+            hs = dict(zip(live, ReluMaskG.apply(len(live), *([ggxs[i] for i in live] + [xs[i] for i in live]))))
+            if ctx.needs_input_grad[0] and _param_grads_enabled:
+                lx, lg = [hs[i] for i in live], [gys[i] for i in live]
+                done, d_w = _to_sink_w(w, lx, lg, False, even_frames=True)
+                if not done:          # no sink (or a graph is being recorded): through the zero-stuffed gradient
+                    cfg = ((1, 1, 1), (2, 1, 1), (0, 0, 0))
+                    full = AvgPool3dBwdG.apply(tuple(cfg for _ in live), tuple(tuple(xs[i].shape[2:]) for i in live), *lg)
+                    d_w = ConvWgradG.apply(tuple(w.shape), False, len(live), *(lx + list(full)))
+            need = [i for i in live if ctx.needs_input_grad[2 + i]]
+            if need:
+                for i, r in zip(need, ConvEvenFramesG.apply(w, None, False, *[hs[i] for i in need])):
+                    d_gys[i] = r
+        return (d_w, None) + tuple(d_gys) + (None,) * n
 
 
 class ConvEvenFramesG(Function):
@@ -2776,6 +2819,13 @@ class ConvEvenFramesG(Function):
                 for i, g in zip(live, full):
                     gfull[i] = g
             return gfull
+        if need and fast is None and ctx.relu_in and torch.is_grad_enabled() and \
+                _dgrad_even_frames_raw([gys[i] for i in need], w, [xs[i] for i in need], plan_only=True):
+            # a graph is being recorded (gradient penalty): the same two launches as a differentiable Function
+            res = ConvDgradEvenMaskG.apply(w, len(need), *([gys[i] for i in need] + [xs[i] for i in need]))
+            for i, r in zip(need, res):
+                gxs[i] = r
+            fast = res
         if need and fast is None:
             full_frames()
             if ctx.relu_in:
