@@ -1369,7 +1369,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
     const t2v_conv_group& gd = tab.g[gi];
     const int D = gd.D, H = gd.H, W = gd.W;
     const int HW = H * W, DHW = D * HW;
-    const int M = gd.N * DHW;
+    // frame-strided input rows (dstride = 2) / strided output (ydstride = 2): as in conv_igemm_strip3_kernel
+    const int ds = gd.dstride == 2 ? 2 : 1;
+    const int yds = gd.ydstride == 2 ? 2 : 1;
+    const int Do = yds == 2 ? (gd.Dy + 1 - gd.yoff) / 2 : (ds == 2 ? (D + 1) / 2 : D);
+    const int DHWo = Do * HW;
+    const int M = gd.N * DHWo;
     const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
     const int ntaps = gd.ntaps;
     const int ndx = gd.dx[0] < 0 ? 3 : 1;
@@ -1378,7 +1383,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
     const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
     const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
     const int tab_widx = gd.widx[lane_t];
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)M * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * DHW) * (uint32_t)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpb, 0, -1, 0x00020000);
 
     const int ma_l = tid % BM, kq = tid / BM;
@@ -1389,8 +1394,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
     {
         const int m_a = m0 + ma_l;
         if (m_a < M) {
-            const int n = m_a / DHW, sp = m_a - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
+            const int n = m_a / DHWo, spo = m_a - n * DHWo;
+            const int d_o = spo / HW, r = spo - d_o * HW;
+            const int d = d_o * ds, sp = d * HW + r;
             const int h = r / W;
             xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
@@ -1400,8 +1406,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
         }
         const int m_h = he ? m0 + BM : m0 - 1;
         if (halo_thread && m_h >= 0 && m_h < M) {
-            const int n = m_h / DHW, sp = m_h - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
+            const int n = m_h / DHWo, spo = m_h - n * DHWo;
+            const int d_o = spo / HW, r = spo - d_o * HW;
+            const int d = d_o * ds, sp = d * HW + r;
             const int h = r / W;
             xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
@@ -1513,7 +1520,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
         }
         __syncthreads();
     }
-    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
+    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi, yds, gd.yoff,
+                                     gd.Dy * HW, HW);
 }
 
 // w[Cout][Cin][T] fp32 -> bf16 wpb[j][rows][K] with K contiguous: mode 0 rows = co, K = ci (forward);
@@ -2167,7 +2175,7 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
                                          const float* bias, float* ws, int flags, void* stream) {
     GroupTable tab;
     ConvPlan p;
-    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p) || p.dstride2)
+    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p))
         return T2V_EINVAL;
     if (flags & T2V_CONV_MASK_OUT) {
         if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
@@ -2181,7 +2189,7 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
         p.bn = 64;
         p.bm = 128;
         for (int i = 0; i < ngroups; ++i) {
-            const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+            const long M = (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;
             tab.tile_start[i] = (int32_t)mt;
             mt += (M + p.bm - 1) / p.bm;
         }
@@ -2193,7 +2201,7 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
     long Mtot_ = 0;
     int taps_ = 0;
     for (int i = 0; i < ngroups; ++i) {
-        const long M = (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        const long M = (long)groups[i].N * out_frames(groups[i]) * groups[i].H * groups[i].W;
         flops += 2.0 * (double)M * Cout * Cin * groups[i].ntaps;
         Mtot_ += M;
         if (groups[i].ntaps > taps_) taps_ = groups[i].ntaps;
@@ -2203,7 +2211,9 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
         static const bool strip3_b16 = getenv("T2V_NO_BF16_STRIP3") == nullptr;       // developer A/B switch
         const long wbytes = 2L * T2V_MAX_TAPS * Cout * Cin;                            // (32-bit byte offsets into the packed weight)
-        if (tun().strip && strip3_b16 && strip_ok(tab) && strip_fits32(tab, Cin) && wbytes < (1L << 31)) {
+        const bool s3_b16 = tun().strip && strip3_b16 && strip_ok(tab) && strip_fits32(tab, Cin) && wbytes < (1L << 31);
+        if (p.dstride2 && (!s3_b16 || (flags & T2V_CONV_ACCUM))) return T2V_EINVAL;        // frame-strided members: strip3 form only
+        if (s3_b16) {
             if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
         } else if (tun().strip && strip_ok(tab)) {

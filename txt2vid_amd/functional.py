@@ -2531,7 +2531,7 @@ def conv_group_raw(xs5, w5, bias=None, relu_in=False, mode=0, masks=None, outs=N
     ws = torch.empty((n,), device=xs5[0].device, dtype=torch.float32) if n > 0 else None
     flags = ((FLAG_BIAS if bias is not None else 0) | (FLAG_RELU_IN if relu_in else 0) | (FLAG_MASK_OUT if masks is not None else 0) |
              (FLAG_ACCUM if accum else 0))
-    if CONV_PRECISION == 'bf16' and not even_frames and lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs5), cin, cout):
+    if CONV_PRECISION == 'bf16' and lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs5), cin, cout):
         wpb = packed_weight_bf16(w5, ts, mode)
         check(lib().t2v_conv_fwd_grouped_bf16(arr, len(xs5), cin, cout, _p(wpb), _p(bias), _p(ws), flags, _stream()),
               't2v_conv_fwd_grouped_bf16')
@@ -2676,7 +2676,7 @@ def _group_param_grads(w, b, relu_in, lx, lg, need_w, need_b):
 def even_frames_ok(xs, w):
     """True when `conv_even_frames_group` can take these members: fp32 mode and the launch lands on the three-taps-per-round
     strip kernel (the only one that knows frame-strided outputs) — asked of the library's own plan query."""
-    if CONV_PRECISION != 'fp32' or len(xs) > MAX_GROUPS or w.dim() != 5 or not xs[0].is_cuda:
+    if len(xs) > MAX_GROUPS or w.dim() != 5 or not xs[0].is_cuda:
         return False
     cout, cin = w.shape[0], w.shape[1]
     k = tuple(w.shape[2:])
@@ -2688,7 +2688,10 @@ def even_frames_ok(xs, w):
     slot_of = {t: j for j, t in enumerate(ts.taps)}
     arr = _group_table(xs, [None] * len(xs), geoms, slot_of, None, 2)
     out = (C.c_int32 * 8)()
-    return lib().t2v_conv_fwd_plan(arr, len(xs), cin, cout, FLAG_RELU_IN, out) == 0 and out[0] == 5 and out[7] == 1
+    if lib().t2v_conv_fwd_plan(arr, len(xs), cin, cout, FLAG_RELU_IN, out) != 0 or out[0] != 5 or out[7] != 1:
+        return False
+    # bf16-compute mode: its three-taps-per-round strip kernel knows the frame stride too (same strip conditions)
+    return CONV_PRECISION == 'fp32' or bool(lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(xs), cin, cout))
 
 
 def _dgrad_even_frames_raw(gys, w5, masks, plan_only=False):
@@ -2700,8 +2703,9 @@ def _dgrad_even_frames_raw(gys, w5, masks, plan_only=False):
     None without launching anything)."""
     gys = [_c(g) for g in gys]
     Cout, Cin = w5.shape[0], w5.shape[1]
-    if tuple(w5.shape[2:]) != (3, 3, 3) or CONV_PRECISION != 'fp32' or len(gys) > MAX_GROUPS:
+    if tuple(w5.shape[2:]) != (3, 3, 3) or len(gys) > MAX_GROUPS:
         return None
+    bf16 = CONV_PRECISION == 'bf16'
     shapes = [tuple(m.shape) for m in masks]
     if any(sh[3] < 2 or sh[4] < 2 or g.shape[2] != (sh[2] + 1) // 2 for g, sh in zip(gys, shapes)):
         return None
@@ -2730,9 +2734,16 @@ def _dgrad_even_frames_raw(gys, w5, masks, plan_only=False):
         plan = (C.c_int32 * 8)()
         if lib().t2v_conv_fwd_plan(arr, len(mem), Cout, Cin, FLAG_MASK_OUT, plan) != 0 or plan[0] != 5 or plan[7] != 1:
             return None
+        if bf16 and not lib().t2v_conv_fwd_grouped_bf16_ok(arr, len(mem), Cout, Cin):
+            return None
         launches.append((arr, len(mem)))
     if plan_only:
         return True
+    if bf16:
+        wpb = packed_weight_bf16(w5, ts, 1)
+        for arr, n in launches:
+            check(lib().t2v_conv_fwd_grouped_bf16(arr, n, Cout, Cin, _p(wpb), None, None, FLAG_MASK_OUT, _stream()), 't2v_conv_fwd_grouped_bf16')
+        return outs
     wp = packed_weight(w5, ts, 1)
     for arr, n in launches:
         check(lib().t2v_conv_fwd_grouped(arr, n, Cout, Cin, _p(wp), None, None, FLAG_MASK_OUT, _stream()), 't2v_conv_fwd_grouped')
