@@ -413,6 +413,11 @@ def main():
     if grad_sync is not None:
         res['config']['grad_exchange_mb_per_step'] = sum(a.exchanged_bytes() for a in grad_sync.arenas.values()) / 1e6
     if roof is not None:
+        if gf:
+            # the REFERENCE-executed FLOP of the iteration (what the reference's kernels compute, incl. the ConvLSTM's dead
+            # taps and the stem conv2's odd frames that this implementation does not execute) over the whole step time: the figure
+            # that does not move when work is removed rather than sped up
+            roof['as_written_all_in_frac'] = gf * 1e9 * (gb / world) / (dt / args.steps) / 1e12 / roof['peak']
         res['roofline'] = roof
     if rank == 0 and world == 1 and prof and not args.no_d_roofline and default_shape:
         # the north-star's own target line: D forward+backward on un-subsampled 16x64x64 clips
