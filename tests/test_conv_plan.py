@@ -116,3 +116,40 @@ def test_environment_tunables_move_the_plan():
     assert _plans_in_child({'T2V_WGRAD_TARGET': '512'})['wbig'][5] <= 600
     assert _plans_in_child({'T2V_WGRAD_NOQ': '1'})['wgp'][5] == 1026
     assert _plans_in_child({'T2V_WGRAD_TARGET': '3072'})['wbig'][1] == 256              # capped by T2V_WGRAD_SCAP
+
+
+def test_frame_strided_members_plan_on_the_host():
+    """`t2v_conv_group.dstride / ydstride` (the stem conv2 on the even frames): the plan queries count the GEMM rows over
+    the frames that are computed, never split K for such launches, and the weight gradient takes dL/dy on the even frames on the
+    3-tap-row kernel only (host arithmetic, no GPU)."""
+    import ctypes as C
+    from txt2vid_amd._lib import lib
+    members = cc.d_step_members(32, 0)                       # the benchmark's 8 stem members, M = 393 216
+    k = (3, 3, 3)
+    arr = cc._group_array(members, 64, 64, k)
+    out = (C.c_int32 * 8)()
+    assert lib().t2v_conv_fwd_plan(arr, len(members), 64, 64, 0, out) == 0 and out[0] == 5 and out[1] == 256
+    for a in arr:
+        a.dstride = 2
+    assert lib().t2v_conv_fwd_plan(arr, len(members), 64, 64, 0, out) == 0
+    assert (out[0], out[1], out[7]) == (5, 256, 1)           # strip3, 196 608 rows = 768 tiles of 256, no split-K
+    w = (C.c_int32 * 6)()
+    assert lib().t2v_conv_wgrad_plan(arr, len(members), 64, 64, 3, 3, 3, w) == 0 and w[0] == 2      # rows3 kernel
+    full = (C.c_int32 * 6)()
+    for a in arr:
+        a.dstride = 0
+    assert lib().t2v_conv_wgrad_plan(arr, len(members), 64, 64, 3, 3, 3, full) == 0
+    assert w[1] * w[2] * 2 <= full[1] * full[2] * 1.1 + 64   # about half the 32-voxel chunks (splits x chunks per split)
+    # narrow inputs run on the (tap, ci) column kernel, which does not know the frame stride: rejected
+    arr1 = cc._group_array(members, 1, 64, k)
+    for a in arr1:
+        a.dstride = 2
+    assert lib().t2v_conv_wgrad_plan(arr1, len(members), 1, 64, 3, 3, 3, w) < 0
+    # strided OUTPUT: one parity of the frames of y, x (dL/dy on the even frames) has ceil(Dy / 2) frames
+    half = [(n, (d + 1) // 2, h, wd) for n, d, h, wd in members]
+    arr2 = cc._group_array(half, 64, 64, k)
+    for a, (n, d, h, wd) in zip(arr2, members):
+        a.ydstride, a.yoff, a.Dy = 2, 1, d
+    assert lib().t2v_conv_fwd_plan(arr2, len(members), 64, 64, 0, out) == 0 and out[0] == 5 and out[7] == 1
+    arr2[0].yoff = 2
+    assert lib().t2v_conv_fwd_plan(arr2, len(members), 64, 64, 0, out) < 0
