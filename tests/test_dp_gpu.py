@@ -59,3 +59,32 @@ def test_bench_starts_its_own_ranks():
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 16 and res['scaling'] == 'weak'
     assert res['config']['grad_exchange_mb_per_step'] > 100          # D 116 MB + G's live 76 MB
     assert res['value'] > 0 and res['steps'] == 2
+
+
+def test_arena_gather_copies_dense_gradients_into_tap_major_slots():
+    """`GradArena.gather()` on the GPU copy path. A tap-major master weight (ConvLSTM) whose gradient did NOT come
+    through the sink arrives dense [Cout,Cin,kh,kw]; it must land in the arena's [kh][kw][Cout][Cin] memory order (the flat copy
+    kernel alone would scramble it), and the live-tap rows the exchange packs must be the right taps."""
+    import torch
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.dist import GradArena
+    dev = 'cuda:0'
+    w = torch.nn.Parameter(TF.tap_major(torch.zeros(8, 6, 3, 3, device=dev)))
+    b = torch.nn.Parameter(torch.zeros(5, device=dev))
+    d = torch.nn.Parameter(torch.zeros(3, 2, 3, 3, device=dev))                 # ordinary dense weight
+    arena = GradArena([b, w, d], TF.copy_into, live_taps={w: [4]})
+    g = torch.arange(8 * 6 * 9, dtype=torch.float32, device=dev).view(8, 6, 3, 3)
+    w.grad, b.grad, d.grad = g.clone(), torch.ones(5, device=dev), torch.full((3, 2, 3, 3), 2.0, device=dev)
+    arena.gather()
+    torch.cuda.synchronize()
+    views = dict(zip([id(p) for p in arena.params], arena.views()))
+    assert torch.equal(views[id(w)], g) and views[id(w)].stride() == w.stride()
+    assert torch.equal(views[id(d)], d.grad) and torch.equal(views[id(b)], b.grad)
+    arena._taps(True)                                                           # pack the live tap as the exchange does
+    torch.cuda.synchronize()
+    assert torch.equal(arena.compact.view(8, 6), g[:, :, 1, 1])
+    # a tap-major gradient (same strides, other memory) takes the stride-aware path too
+    w.grad = TF.tap_major(g * 3)
+    arena.gather()
+    torch.cuda.synchronize()
+    assert torch.equal(arena.views()[arena.params.index(w)], g * 3)

@@ -302,3 +302,103 @@ def test_sample_grid_writer_pixel_level(tmp_path):
         assert np.array_equal(img, want)
     save_frames(x, str(tmp_path / 'grid.jpg'))                                   # the sampling path's extension: PIL writes JPEG
     assert Image.open(tmp_path / 'grid.jpg').format == 'JPEG'
+
+
+def test_adam_refuses_state_with_foreign_strides():
+    """A moment assigned straight into `opt.state` with stride-0 (or any non-parameter) strides would be walked as a dense array
+    by the kernel (the round-2 GPU fault): `step()` raises before launching anything; `load_state_dict` re-materialises instead."""
+    from txt2vid_amd.optim import Adam, SGD
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    p.grad = torch.ones(4, 3)
+    opt = Adam([p], lr=1e-3)
+    opt.state[p] = {'step': 1, 'exp_avg': torch.zeros(1, 1).expand(4, 3), 'exp_avg_sq': torch.zeros(4, 3)}
+    with pytest.raises(ValueError, match='strides'):
+        opt.step()
+    assert opt.state[p]['step'] == 1                       # nothing advanced
+    opt.state[p]['exp_avg'] = torch.zeros(4, 3, dtype=torch.float64)
+    with pytest.raises(ValueError, match='does not match'):
+        opt.step()
+    opt.state[p]['exp_avg'] = torch.zeros(8, 3)[::2]       # right shape, a strided slice of somebody else's buffer
+    with pytest.raises(ValueError, match='strides'):
+        opt.step()
+    sgd = SGD([p], lr=1e-3, momentum=0.5)
+    sgd.state[p] = {'momentum_buffer': torch.zeros(1, 1).expand(4, 3)}
+    with pytest.raises(ValueError, match='strides'):
+        sgd.step()
+    # the supported way in: load_state_dict densifies
+    opt2 = Adam([p], lr=1e-3)
+    sd = {'state': {0: {'step': 1, 'exp_avg': torch.zeros(1, 1).expand(4, 3), 'exp_avg_sq': torch.zeros(1, 1).expand(4, 3)}},
+          'param_groups': opt2.state_dict()['param_groups']}
+    opt2.load_state_dict(sd)
+    assert opt2.state[p]['exp_avg'].stride() == p.stride() and opt2.state[p]['exp_avg'].is_contiguous()
+
+
+def test_rng_state_round_trip_continues_the_draw_sequence():
+    """Checkpoints carry the three host generators' states (`rng_state`): restoring them continues the sequence of z / phase /
+    alpha (torch), caption permutation (numpy) and `random` draws exactly where the saving run stood."""
+    import io
+    from txt2vid_amd.train.setup import get_rng_state, set_rng_state, set_seed
+    set_seed(77)
+    torch.randn(5), np.random.permutation(7), random.random()
+    blob = io.BytesIO()
+    torch.save({'rng_state': get_rng_state(), 'iteration': 3}, blob)          # through the pickle the checkpoint uses
+    want = (torch.randn(4), torch.randint(2, (3,)), np.random.permutation(9), random.random())
+    set_seed(5)
+    blob.seek(0)
+    set_rng_state(torch.load(blob, weights_only=False)['rng_state'])
+    got = (torch.randn(4), torch.randint(2, (3,)), np.random.permutation(9), random.random())
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]) and (want[2] == got[2]).all() and want[3] == got[3]
+    set_rng_state(None)                                                        # reference-written files: no key, nothing happens
+    set_rng_state({})
+
+
+def test_grad_sink_overflow_keeps_the_first_bias_writer_a_store():
+    """when a destination overflows its source list (or meets another bias) it is flushed; the incoming producer must
+    keep `accumulate = False` for a bias nobody wrote yet this step, and the frozen sink refuses to grow / recycle."""
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd._lib import WgradSrc, WGRAD_MAX_SRC
+    sink = TF.GradSink([])
+    flushed = []
+
+    def fake_flush(dests):
+        for d in dests:
+            flushed.append((d.wid, d.bid, d.accum, d.accum_bias, len(d.srcs)))
+            sink.pending.pop(d.wid, None)
+            if d.bid is not None:
+                sink.pending_bias.pop(d.bid, None)
+    sink._flush = fake_flush
+    w, b = torch.zeros(8), torch.zeros(2)
+    for _ in range(WGRAD_MAX_SRC):                          # bias-less producers fill the source list
+        sink.add_partial(w, w, False, None, None, False, WgradSrc(), None, 1, 2, 4)
+    sink.add_partial(w, w, True, b, b, False, WgradSrc(), None, 1, 2, 4)     # first producer WITH the bias: overflow -> flush
+    assert flushed == [(id(w), None, 0, 0, WGRAD_MAX_SRC)]
+    d = sink.pending[id(w)]
+    assert d.accum == 1 and d.accum_bias == 0              # weight slot was written by the flush; the bias slot was not
+    # same bias on both sides of an overflow: now the flushed table did write it
+    sink.pending.clear(), sink.pending_bias.clear(), flushed.clear()
+    for _ in range(WGRAD_MAX_SRC):
+        sink.add_partial(w, w, False, b, b, False, WgradSrc(), None, 1, 2, 4)
+    sink.add_partial(w, w, True, b, b, False, WgradSrc(), None, 1, 2, 4)
+    assert sink.pending[id(w)].accum_bias == 1
+    # frozen: a captured graph reads the workspace
+    sink.pending.clear(), sink.pending_bias.clear()
+    sink.frozen, sink.ws_used = 1, 128
+    with pytest.raises(RuntimeError, match='captured HIP graph'):
+        sink.reset()
+
+
+def test_arena_gather_is_stride_aware_for_tap_major_slots():
+    """a dense gradient for a tap-major master weight must land in [kh][kw][Cout][Cin] memory order inside the arena
+    (CPU path; the GPU copy path has its own test in test_dp_gpu.py)."""
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.dist import GradArena
+    w = torch.nn.Parameter(TF.tap_major(torch.zeros(4, 3, 3, 3)))
+    b = torch.nn.Parameter(torch.zeros(5))
+    arena = GradArena([b, w], live_taps={w: [4]})
+    g = torch.arange(4 * 3 * 9, dtype=torch.float32).view(4, 3, 3, 3)
+    w.grad, b.grad = g.clone(), torch.ones(5)              # dense gradient (it bypassed the sink)
+    arena.gather()
+    v = arena.views()[1]
+    assert torch.equal(v, g) and v.stride() == w.stride()
+    off = arena.offsets[1]
+    assert torch.equal(arena.flat[off + 4 * 12:off + 5 * 12].view(4, 3), g[:, :, 1, 1])          # tap 4 is one contiguous row

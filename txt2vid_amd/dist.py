@@ -76,6 +76,12 @@ def sync_replicas(modules, src=0):
     return n
 
 
+def _is_tap_major_view(v):
+    """True when the memory behind a conv-weight-shaped view is laid out [*k][Cout][Cin] (functional.tap_major)."""
+    nd = v.dim()
+    return nd >= 3 and not v.is_contiguous() and v.permute(*(tuple(range(2, nd)) + (0, 1))).is_contiguous()
+
+
 class GradArena(object):
     """Flat gradient buffer of one model + the per-step exchange.
 
@@ -119,16 +125,30 @@ class GradArena(object):
                 for o, p in zip(self.offsets, self.params)]
 
     def gather(self):
-        """p.grad -> arena slice (missing grads count as zero)."""
+        """p.grad -> arena slice (missing grads count as zero). `copy_fn` is a FLAT copy (dense source -> the destination's
+        memory in order), so it only takes pairs whose memory orders agree; a dense gradient for a tap-major slot (a ConvLSTM
+        weight whose gradient bypassed the sink: --end2end, T2V_NO_DEFERRED_REDUCE, one-step sequences) goes tap row by tap row."""
+        if self.flat.is_cuda:
+            from . import functional as TF
+            TF.grad_sink_flush()              # pending k-split partial sums belong in the arena before anyone reads it
         for v, p in zip(self.views(), self.params):
-            if p.grad is None:
+            g = p.grad
+            if g is None:
                 v.zero_()
-            elif p.grad.data_ptr() == v.data_ptr():
+            elif g.data_ptr() == v.data_ptr() and g.stride() == v.stride():
                 continue                      # the producing kernel already wrote it here (functional.GradSink)
-            elif self.copy_fn is not None and p.grad.is_cuda:
-                self.copy_fn(p.grad, v)
+            elif self.copy_fn is not None and g.is_cuda and g.is_contiguous() and v.is_contiguous():
+                self.copy_fn(g, v)
+            elif self.copy_fn is not None and g.is_cuda and g.is_contiguous() and v.dim() >= 3 and _is_tap_major_view(v):
+                from . import functional as TF
+                T = 1
+                for d in v.shape[2:]:
+                    T *= int(d)
+                rows = v.numel() // T         # arena memory [T][Cout*Cin] <- gradient memory [Cout*Cin][T]
+                for t in range(T):
+                    TF._copy2d(g, t, T, v, t * rows, 1, rows, 1)
             else:
-                v.copy_(p.grad)
+                v.copy_(g)                    # stride-aware (any other layout pair; CPU)
 
     def _taps(self, pack):
         """live taps: arena -> compact (pack) or compact -> arena (unpack); strided column copies."""

@@ -114,14 +114,22 @@ class GradSink(object):
         # k-split slabs come from one bump-allocated workspace sized by the first iteration: every later iteration — eager,
         # captured or replayed — hands each launch the same address, so the destination tables repeat and are uploaded once
         self.ws, self.ws_off, self.ws_used = None, 0, 0
+        # captured HIP graphs bake in the slab addresses and the table slots they met: while one is alive (`frozen` > 0, set by
+        # GraphedTrainStep) the workspace must not be re-allocated and the table slots must not be recycled
+        self.frozen = 0
 
     def reset(self):
         self.flush()
         self.count.clear()
-        if self.ws_used > (self.ws.numel() if self.ws is not None else 0) and not torch.cuda.is_current_stream_capturing():
+        grow = self.ws_used > (self.ws.numel() if self.ws is not None else 0)
+        if grow and self.frozen:
+            raise RuntimeError('the gradient sink would have to grow its slab workspace (%d -> %d floats) while a captured HIP graph '
+                               'still reads the current one: release that graph first (GraphedTrainStep.release)'
+                               % (self.ws.numel() if self.ws is not None else 0, self.ws_used))
+        if grow and not torch.cuda.is_current_stream_capturing():
             self.ws = None                                # (release before growing)
             self.ws = torch.empty(self.ws_used + (self.ws_used >> 3), dtype=torch.float32, device=self.tab_dev.device)
-            torch.cuda.current_stream().synchronize()      # (first iterations only) pending table uploads are done with their slots
+            torch.cuda.synchronize()                       # (first iterations only) pending table uploads — on any stream — are done with their slots
             self.tables.clear()
         self.ws_off = self.ws_used = 0
 
@@ -155,7 +163,10 @@ class GradSink(object):
         d = self.pending.get(id(wbase))
         if d is not None and (len(d.srcs) >= WGRAD_MAX_SRC or (d.bid is not None and b is not None and d.bid != id(b))):
             self._flush([d])
-            d, wacc, bacc = None, True, True
+            # the flushed table wrote the weight slot; the bias slot only if it carried THIS bias (else the incoming producer may
+            # still be the step's first writer of its bias and must overwrite, not add to last step's contents)
+            wacc, bacc = True, bacc or (d.bid is not None and b is not None and d.bid == id(b))
+            d = None
         if d is None:
             d = _PendingDest()
             d.wid, d.bid, d.dw, d.dbias = id(wbase), None, dw.data_ptr(), 0
@@ -199,9 +210,10 @@ class GradSink(object):
             if len(raw) > self.slot_bytes:
                 raise RuntimeError('weight-gradient destination table of %d bytes' % len(raw))
             if len(self.tables) >= self.nslots:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError('out of destination-table slots during graph capture')
-                torch.cuda.current_stream().synchronize()  # (eager, pointers drifting: earlier uploads are done with their slots)
+                if torch.cuda.is_current_stream_capturing() or self.frozen:
+                    raise RuntimeError('out of destination-table slots %s' % ('during graph capture' if not self.frozen else
+                                                                               'while a captured HIP graph still reads them'))
+                torch.cuda.synchronize()                   # (eager, pointers drifting: earlier uploads, on any stream, are done with their slots)
                 self.tables.clear()
             slot = len(self.tables)
             lo = slot * self.slot_bytes

@@ -214,6 +214,22 @@ class GraphedTrainStep(object):
             self.ts.part_end()
         torch.cuda.synchronize()
         self.graphs = (g1, g2, g3)
+        if self.ts.grad_sink is not None:
+            self.ts.grad_sink.frozen += 1        # the graphs bake in the sink's slab addresses and table slots
+
+    def release(self):
+        """Drop the captured graphs (a new batch shape is about to be captured): the gradient sink may grow / recycle again."""
+        if self.graphs is not None:
+            torch.cuda.synchronize()
+            self.graphs = None
+            if self.ts.grad_sink is not None:
+                self.ts.grad_sink.frozen = max(0, self.ts.grad_sink.frozen - 1)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def step(self, x, cond=None):
         """x: [B,C,T,H,W] device (or pinned host) tensor; cond: [B,cond_dim] sentence codes (conditional path). Returns
@@ -378,6 +394,8 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
             if use_graph:
                 key = (tuple(x.shape), None if cond is None else tuple(cond.shape))
                 if graphed is None or key != graphed_key:          # first batch (or a new batch shape): capture again
+                    if graphed is not None:
+                        graphed.release()
                     graphed = GraphedTrainStep(gan, optD, optG, losses, params, device, tuple(x.shape), grad_sync=grad_sync,
                                                warmup=2, cond_dim=0 if cond is None else cond.shape[1])
                     graphed_key = key
@@ -409,7 +427,9 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
             # --save_model_period; the intended flag is used (SURVEY §8a defect 3).
             if writer and ((iteration == 1 and params.save_initial) or (params.save_model_period > 0 and
                                                                         iteration % params.save_model_period == 0)):
-                to_save = {'optG': optG.state_dict(), 'optD': optD.state_dict(), 'iteration': iteration}
+                from ..train.setup import get_rng_state
+                # extra keys next to the reference's layout (its loader ignores them; its files, which lack them, still load here)
+                to_save = {'optG': optG.state_dict(), 'optD': optD.state_dict(), 'iteration': iteration, 'rng_state': get_rng_state()}
                 to_save.update(gan.save_dict())
                 torch.save(to_save, '%s/iter_%d_lossG_%.4f_lossD_%.4f' % (params.out, iteration, gen_loss.get(),
                                                                           discrim_loss.get()))

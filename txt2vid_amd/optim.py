@@ -18,6 +18,30 @@ def _densify_state(opt):
                     st[k] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(v)   # the parameter's layout
 
 
+def _check_state_layout(opt, p, st, keys):
+    """The kernels walk parameter, gradient and state with ONE flat index through raw pointers: a state tensor assigned behind
+    `load_state_dict`'s back (stride-0 expands, slices of a bigger buffer, another dtype / device) would be read out of bounds.
+    Checked once per (parameter, state tensor) identity; raises instead of launching."""
+    seen = opt.__dict__.setdefault('_t2v_layout_ok', {})
+    sig = tuple(id(st.get(k)) for k in keys)
+    if seen.get(id(p)) == sig:
+        return
+    for k in keys:
+        v = st.get(k)
+        if v is None:
+            continue
+        if not isinstance(v, torch.Tensor) or tuple(v.shape) != tuple(p.shape) or v.dtype != p.dtype or v.device != p.device:
+            raise ValueError('optimiser state %r does not match its parameter (shape %s / %s, %s / %s, %s / %s)' % (
+                k, tuple(getattr(v, 'shape', ())), tuple(p.shape), getattr(v, 'dtype', None), p.dtype, getattr(v, 'device', None), p.device))
+        if v.stride() != p.stride():
+            raise ValueError('optimiser state %r has strides %s for a parameter with strides %s: load it through load_state_dict '
+                             '(which re-materialises foreign layouts) or assign a tensor laid out like the parameter' % (k, v.stride(), p.stride()))
+        need = (v.storage_offset() + v.numel()) * v.element_size()
+        if v.untyped_storage().nbytes() < need:
+            raise ValueError('optimiser state %r does not own %d bytes of storage' % (k, need))
+    seen[id(p)] = sig
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if weight_decay != 0:
@@ -60,6 +84,7 @@ class Adam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        TF.grad_sink_flush()                  # (no-op unless a backward pass left k-split partial sums pending)
         if self.step_dev is not None:
             b1, b2 = self.param_groups[0]['betas']
             TF.check(TF.lib().t2v_adam_tick(TF._p(self.step_dev), b1, b2, TF._stream()), 't2v_adam_tick')
@@ -75,6 +100,7 @@ class Adam(torch.optim.Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                _check_state_layout(self, p, st, ('exp_avg', 'exp_avg_sq'))
                 st['step'] = int(st['step']) + 1
                 g = p.grad
                 if g.stride() != p.stride():             # the kernel walks p, g, m, v with one flat index
@@ -118,6 +144,7 @@ class SGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         from ._lib import AdamJob
+        TF.grad_sink_flush()
         touched = []
         for group in self.param_groups:
             mu = float(group['momentum'])
@@ -126,11 +153,14 @@ class SGD(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                g = p.grad
+                if g.stride() != p.stride():             # one flat index over p, g and the momentum buffer
+                    g = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(g)
                 if mu != 0 and 'momentum_buffer' not in st:
                     st['momentum_buffer'] = torch.empty_like(p, memory_format=torch.preserve_format)
                     first.append((p, g, st['momentum_buffer']))
                 else:
+                    _check_state_layout(self, p, st, ('momentum_buffer',))
                     later.append((p, g, st.get('momentum_buffer')))
                 touched.append(p)
             for items, is_first in ((first, 1), (later, 0)):

@@ -88,6 +88,7 @@ def main(args):
     else:
         optD = Adam(D_params, lr=args.D_lr, betas=(args.D_beta1, args.D_beta2))
         optG = Adam(G_params, lr=args.G_lr, betas=(args.G_beta1, args.G_beta2))
+    resumed_rng, resumed_iter = None, 0
     gan = CondGan(gen=gen, discrims=discrims, cond_encoder=txt_encoder, discrim_names=args.D_names,
                   discrim_lambdas=args.D_lambdas, gp_scale=float(world))
     if args.weights is not None:
@@ -97,6 +98,7 @@ def main(args):
             optD.load_state_dict(to_load['optD'])
         if 'optG' in to_load:
             optG.load_state_dict(to_load['optG'])
+        resumed_rng, resumed_iter = to_load.get('rng_state'), int(to_load.get('iteration', 0))
         del to_load
     if world > 1:
         # replicas bit-identical before the first step (whatever each rank's init / checkpoint read produced), then per-rank
@@ -107,7 +109,12 @@ def main(args):
         import random
         import numpy as np
         for seeder in (random.seed, np.random.seed, torch.manual_seed):
-            seeder(seed + rank)
+            seeder(seed + rank + 1000003 * resumed_iter)     # (a resumed run does not replay the first run's draws)
+    if resumed_rng is not None and rank == 0:
+        # checkpoints written by this build carry the writer's (rank 0's) generator states: the resumed run continues the draw
+        # sequence where the saved one stopped (reference-written files have no such key and start from --seed)
+        from .setup import set_rng_state
+        set_rng_state(resumed_rng)
     transform = data.default_transform(frame_size=[args.frame_sizes[-1]], num_channels=args.num_channels)
     dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=transform, size=args.frame_sizes[-1],
                          channels=args.num_channels, seed=(args.seed or 0) + rank)
@@ -120,7 +127,9 @@ def main(args):
     grad_sync = None
     if world > 1:
         from .. import functional as TF
-        arenas = {'D': tdist.model_arena(list(discrims), TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
+        # --end2end: the text encoder sits in BOTH optimisers (train/gan.py:82-85), so its gradients travel with both exchanges
+        shared = [txt_encoder] if (args.end2end and txt_encoder is not None) else []
+        arenas = {'D': tdist.model_arena(list(discrims) + shared, TF.copy_into), 'G': tdist.model_arena([gen] + shared, TF.copy_into)}
         grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
     if args.test:
         test(gan=gan, num_samples=args.num_samples, dataset=dataset, device=device, params=args,

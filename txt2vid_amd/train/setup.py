@@ -37,3 +37,26 @@ def setup(args):
     status('Seed: %d' % seed)
     status('Device set to: %s' % device)
     return seed, device
+
+
+def get_rng_state():
+    """The three host generators every per-iteration draw comes from (z, sub-sample phases, GP alphas: torch; caption
+    permutations: numpy; nothing on the hot path: `random`) as one picklable dict — saved next to the weights so that a resumed
+    run continues the draw sequence (the reference's checkpoints carry no generator state, trainer.py:269-279)."""
+    ns = np.random.get_state()
+    return {'python': random.getstate(), 'numpy': (ns[0], ns[1].tolist(), int(ns[2]), int(ns[3]), float(ns[4])),
+            'torch': torch.get_rng_state().clone()}
+
+
+def set_rng_state(state):
+    """Inverse of `get_rng_state` (a dict missing a generator leaves that generator alone)."""
+    if not state:
+        return
+    if 'python' in state:
+        py = state['python']
+        random.setstate((py[0], tuple(py[1]), py[2]))
+    if 'numpy' in state:
+        n = state['numpy']
+        np.random.set_state((n[0], np.asarray(n[1], dtype=np.uint32), n[2], n[3], n[4]))
+    if 'torch' in state:
+        torch.set_rng_state(torch.as_tensor(state['torch'], dtype=torch.uint8).cpu())
