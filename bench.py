@@ -327,6 +327,7 @@ def main():
         # (on the stream the graphs were captured on: the parameters' AccumulateGrad nodes remember it)
         side = torch.cuda.stream(graphed.side) if graphed is not None else contextlib.nullcontext()
         if graphed is not None:
+            graphed.release()            # the replay is over: the gradient sink may recycle its table slots in the eager pass
             graphed.side.wait_stream(torch.cuda.current_stream())
         with side:
             for i in range(prof_steps):

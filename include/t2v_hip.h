@@ -190,6 +190,11 @@ int t2v_conv_wgrad_grouped_bias(const t2v_conv_group* groups, int ngroups, int C
  * shape (Cin % 32 == 0, Cout > 4); otherwise use the fp32 entry point. Workspace: t2v_conv_fwd_grouped_ws_floats(). */
 int t2v_pack_weight_bf16(const float* w, void* wpb, int Cout, int Cin, int T, const int32_t* taps, int ntaps, int mode, void* stream);
 int t2v_conv_fwd_grouped_bf16_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout);
+/* Launch plan of t2v_conv_fwd_grouped_bf16 (host arithmetic, no launch; t2v_conv_fwd_plan layout): out[0] kind (6
+ * conv_igemm_bf16_kernel, 8 conv_igemm_bf16_strip3_kernel), out[1] BM (128 | 64), out[2] 64, out[3] 32, out[4] 1 for
+ * frame-strided members, out[7] split-K S. T2V_EINVAL where the bf16 entry point refuses the launch. Used by the parity tests to assert
+ * that every compiled bf16 instantiation — and every one the benchmark's bf16 iteration launches — is covered by an op case. */
+int t2v_conv_fwd_bf16_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out);
 int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const void* wpb, const float* bias,
                               float* ws, int flags, void* stream);
 

@@ -164,3 +164,92 @@ def all_checked_wgrad_variants():
         p = wgrad_plan(members, cin, cout, k)
         seen.setdefault((p[0], p[4]), name)
     return seen
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16-compute mode (BASELINE configs 2-4): `t2v_conv_fwd_grouped_bf16` / the T2V_CONV_BF16 weight-gradient kernels.
+# name, Cin, Cout, kernel, members [(N, D, H, W)], relu_in, even — checked by tests/test_ops_gpu.py::test_bf16_cases against the
+# EXACT convolution / data gradient / weight gradient of the bf16-rounded operands. `even`: the stem conv2's frame-strided
+# form (forward on the even output frames `dstride = 2`, data gradient as two `ydstride = 2` launches from even-frame dL/dy,
+# weight gradient from even-frame dL/dy).
+# ------------------------------------------------------------------------------------------------
+BF16_CASES = [
+    ('bf16_stem_conv2_B32_even', 64, 64, (3, 3, 3), d_step_members(32, 0), True, True),       # benchmark size, frame-strided: strip3<128>
+    ('bf16_down0_conv2_B32', 64, 128, (3, 3, 3), d_step_members(32, 1), True, False),         # M=49152: strip3<128> fwd, strip3<64> dgrad
+    ('bf16_down1_conv2_B32', 128, 256, (3, 3, 3), d_step_members(32, 2), True, False),        # M=7680 ragged: strip3<64>, split-K
+    ('bf16_small_even', 64, 64, (3, 3, 3), [(2, 4, 16, 16), (1, 5, 8, 8), (3, 2, 4, 4)], True, True),    # strip3<64>, odd frame counts
+    ('bf16_skip_1x1_B32', 64, 128, (1, 1, 1), d_step_members(32, 1), False, False),           # 1x1x1 at M=49152: igemm<128> / per-tap bf16 wgrad
+    ('bf16_1x1_small', 128, 64, (1, 1, 1), [(2, 4, 8, 8), (5, 1, 1, 1)], False, False),       # igemm<64>
+    ('bf16_cout32', 64, 32, (3, 3, 3), [(2, 4, 16, 16)], True, False),                        # Cout <= 32: re-tiled to 128 x 64
+]
+
+
+def _even_dgrad_arrays(members, cin, cout):
+    """The two `ydstride = 2` launches of functional._dgrad_even_frames_raw as host-side group tables (no pointers): output frame 2e
+    sees the dz = 0 taps, frame 2e + 1 the dz = -1 / +1 taps. Returns [(array, n)]."""
+    from txt2vid_amd._lib import ConvGroup
+    slot_of = {t: t for t in range(27)}
+    out = []
+    for yoff, planes in ((0, ((1, 0),)), (1, ((0, 0), (2, 1)))):
+        mem = [m for m in members if (m[1] + 1 - yoff) // 2 >= 1]
+        if not mem:
+            continue
+        arr = (ConvGroup * len(mem))()
+        for a_, (n, d, h, w) in zip(arr, mem):
+            a_.x = a_.y = a_.mask = None
+            a_.N, a_.D, a_.H, a_.W = n, (d + 1) // 2, h, w
+            a_.dstride, a_.ydstride, a_.yoff, a_.Dy = 0, 2, yoff, d
+            j = 0
+            for pa, dzc in planes:
+                for b in range(3):
+                    for c in range(3):
+                        a_.dz[j], a_.dy[j], a_.dx[j] = dzc, b - 1, c - 1
+                        a_.widx[j] = slot_of[(pa * 3 + b) * 3 + c]
+                        j += 1
+            a_.ntaps = j
+        out.append((arr, len(mem)))
+    return out
+
+
+def bf16_fwd_plan_of(arr, n, cin, cout, flags=0):
+    """('igemm_bf16'|'strip3_bf16', BM, frame-strided) of a bf16 launch, or None where the bf16 entry point refuses it (fp32 runs)."""
+    from txt2vid_amd._lib import lib
+    out = (C.c_int32 * 8)()
+    if lib().t2v_conv_fwd_bf16_plan(arr, n, cin, cout, flags, out) != 0:
+        return None
+    return ({6: 'igemm_bf16', 8: 'strip3_bf16'}[out[0]], out[1], out[4])
+
+
+def bf16_case_plans(case):
+    """Forward / data-gradient bf16 instantiations and the (kernel, bf16, frame-strided) weight-gradient variant of one BF16_CASES entry."""
+    name, cin, cout, k, members, relu_in, even = case
+    kk = k3(k)
+    fwd = set()
+    arr = _group_array(members, cin, cout, kk)
+    if even:
+        for a in arr:
+            a.dstride = 2
+    fwd.add(bf16_fwd_plan_of(arr, len(members), cin, cout))
+    if even:
+        for darr, n in _even_dgrad_arrays(members, cout, cin):
+            fwd.add(bf16_fwd_plan_of(darr, n, cout, cin, 8))          # T2V_CONV_MASK_OUT
+    else:
+        fwd.add(bf16_fwd_plan_of(_group_array(members, cout, cin, kk), len(members), cout, cin))
+    wp = wgrad_plan(members, cin, cout, k)
+    wg = (wp[0], 1 if wp[0] in ('rows3', 'taps') else 0, 1 if even else 0)     # (the Cin < 64 column kernel stays fp32)
+    return fwd - {None}, wg
+
+
+ALL_BF16_FWD = {('igemm_bf16', 128), ('igemm_bf16', 64), ('strip3_bf16', 128), ('strip3_bf16', 64)}       # the compiled instantiations
+ALL_BF16_WGRAD = {('rows3', 1), ('taps', 1)}                                                                # conv_wgrad3_kernel<true>, conv_wgrad_bf16_kernel
+
+
+def all_checked_bf16_variants():
+    """(forward / data-gradient variants incl. the frame-strided flag, weight-gradient variants) reached by BF16_CASES."""
+    fwd, wg = {}, {}
+    for case in BF16_CASES:
+        f, w = bf16_case_plans(case)
+        for v in f:
+            fwd.setdefault(v, case[0])
+        wg.setdefault(w, case[0])
+    return fwd, wg

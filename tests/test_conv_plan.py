@@ -55,6 +55,23 @@ def test_every_weight_gradient_instantiation_is_reached_by_a_parity_case():
     assert set(seen) == ALL_WGRAD, sorted(ALL_WGRAD - set(seen))
 
 
+def test_every_bf16_instantiation_is_reached_by_a_parity_case():
+    """bf16-compute mode (BASELINE configs 2-4): the four compiled `conv_igemm_bf16*` instantiations and the two bf16 weight-gradient
+    kernels are each reached by a case of conv_cases.BF16_CASES — the frame-strided forms (stem conv2 on the even frames:
+    `dstride` forward, the two `ydstride` data-gradient launches, the even-frame 3-tap weight gradient) at the BENCHMARK size."""
+    fwd, wg = cc.all_checked_bf16_variants()
+    assert {v[:2] for v in fwd} == cc.ALL_BF16_FWD, sorted(cc.ALL_BF16_FWD - {v[:2] for v in fwd})
+    assert {v[:2] for v in wg} >= cc.ALL_BF16_WGRAD
+    name, cin, cout, k, members, relu_in, even = cc.BF16_CASES[0]
+    assert name == 'bf16_stem_conv2_B32_even' and even and sum(n * d * h * w for n, d, h, w in members) == 393216
+    f, w = cc.bf16_case_plans(cc.BF16_CASES[0])
+    assert f == {('strip3_bf16', 128, 1)} and w == ('rows3', 1, 1)          # forward AND both strided-output data-gradient launches
+    assert ('strip3_bf16', 64, 1) in fwd                                   # the 64-voxel tile knows the frame stride too
+    # what the bf16 entry point refuses runs in fp32 (and says so): Cin not a multiple of 32, thin outputs
+    assert cc.bf16_fwd_plan_of(cc._group_array([(2, 4, 8, 8)], 48, 64, (3, 3, 3)), 1, 48, 64) is None
+    assert cc.bf16_fwd_plan_of(cc._group_array([(2, 4, 8, 8)], 64, 1, (3, 3, 3)), 1, 64, 1) is None
+
+
 def test_plan_queries_reject_bad_geometry():
     import ctypes as C
     from txt2vid_amd._lib import lib, ConvGroup

@@ -87,4 +87,4 @@ def test_arena_gather_copies_dense_gradients_into_tap_major_slots():
     w.grad = TF.tap_major(g * 3)
     arena.gather()
     torch.cuda.synchronize()
-    assert torch.equal(arena.views()[arena.params.index(w)], g * 3)
+    assert torch.equal(arena.views()[[i for i, q in enumerate(arena.params) if q is w][0]], g * 3)

@@ -694,6 +694,69 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
     print('B=32: %d convolution launches on %d instantiations, all covered by op-level parity cases' % (len(rows), len(launched)))
 
 
+def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeypatch):
+    """BASELINE configs[1] shape at per-GPU batch 32 in bf16-compute mode (what `bench.py --bf16` and the configs[2] extra record
+    run; no oracle pass: cheap): every convolution launch of the iteration is recorded with its launch plan, and every bf16
+    instantiation — forward / data gradient incl. the frame-strided stem forms, and the bf16 weight-gradient kernels incl. the
+    even-frame one — must be one that an op-level case of conv_cases.BF16_CASES checks against the convolution of the
+    bf16-rounded operands; launches the bf16 entry point refuses (Cin % 32, thin outputs) must be covered fp32 instantiations."""
+    import ctypes as C
+    import conv_cases as cc
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd._lib import lib
+    from txt2vid_amd.gan.trainer import train_iteration
+    B = 32
+    gan, optD, optG, losses, prm = _make_uncond()
+    random.seed(12)
+    np.random.seed(12)
+    torch.manual_seed(12)
+    x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+    dump = tmp_path / 'launches_bf16.csv'
+    monkeypatch.setenv('T2V_PROF_DUMP', str(dump))
+    old = TF.set_conv_precision('bf16')
+    try:
+        assert lib().t2v_prof_begin(8192) == 0
+        lD, lG, _, _ = train_iteration(gan, x.to(DEV), None, optD, optG, losses, prm, DEV)
+        torch.cuda.synchronize()
+        out = (C.c_double * 18)()
+        assert lib().t2v_prof_end(out, 6) == 0
+    finally:
+        TF.set_conv_precision(old)
+        monkeypatch.delenv('T2V_PROF_DUMP')
+    assert np.isfinite(float(lD)) and np.isfinite(float(lG)) and 0.3 < float(lD) < 1.5
+    bf_fwd, bf_wg = cc.all_checked_bf16_variants()
+    checked_fwd = set(cc.all_checked_fwd_variants())
+    checked_wgrad = set(cc.all_checked_wgrad_variants())
+    kinds = ('igemm', 'strip', 'thin', 'linear', 'thin2', 'strip3')
+    launched = set()
+    rows = dump.read_text().strip().splitlines()[1:]
+    assert len(rows) > 150
+    for line in rows:
+        f = line.split(',')
+        kind, plan = int(f[0]), [int(v) for v in f[9].split(':')]
+        if plan[0] < 0:
+            continue
+        if kind == 5:                                              # bf16 forward / data-gradient GEMM
+            key = ({6: 'igemm_bf16', 8: 'strip3_bf16'}[plan[0]], plan[1], plan[4])
+            assert key in bf_fwd, ('bf16 launch at B=32 covered by no BF16_CASES entry', key, line)
+        elif kind in (0, 3):                                       # refused by the bf16 entry point: fp32 kernels
+            key = (kinds[plan[0]],) + tuple(plan[1:7])
+            assert key in checked_fwd, key
+        elif kind == 1:
+            name = ('taps', 'cols', 'rows3')[plan[0]]
+            if plan[6] == 1:
+                key = (name, 1, plan[7])
+                assert key in bf_wg, ('bf16 weight-gradient launch covered by no BF16_CASES entry', key, line)
+            else:
+                key = (name, ('reduce', 'reduce_small')[plan[4]])
+                assert key in checked_wgrad, key
+        else:
+            continue
+        launched.add(key)
+    assert ('strip3_bf16', 128, 1) in launched and ('rows3', 1, 1) in launched      # the stem conv2's frame-strided forms did run
+    print('B=32 bf16: %d convolution launches on %d instantiations, all covered' % (len(rows), len(launched)))
+
+
 def test_iteration_bf16_compute_mode_vs_oracle():
     """bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA; BASELINE configs 2-4 "bf16 compute / fp32 master"): one
     full iteration against the fp32 CPU oracle. bf16 operands carry 8 mantissa bits, so this is a LOOSER, separately stated

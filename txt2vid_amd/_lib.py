@@ -101,6 +101,7 @@ SIGNATURES = {
     't2v_conv_wgrad_plan': [_P, _I, _I, _I, _I, _I, _I, _I3],
     't2v_pack_weight_bf16': [_P, _P, _I, _I, _I, _P, _I, _I, _P],
     't2v_conv_fwd_grouped_bf16_ok': [_P, _I, _I, _I],
+    't2v_conv_fwd_bf16_plan': [_P, _I, _I, _I, _I, _I3],
     't2v_conv_fwd_grouped_bf16': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_conv_wgrad_grouped': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     't2v_conv_wgrad_grouped_bias_slab_floats': [_P, _I, _I, _I, _I, _I, _I],

@@ -1147,200 +1147,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const GroupTable t
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
 }
 
-// Strip form of the bf16-compute GEMM (see conv_igemm_strip_kernel): the activation tile of a (kernel row, channel block) is
-// staged once as BM + 2 voxel rows and serves the three dx taps; in the [voxel][k] LDS layout a dx shift is a whole row, so the
-// fragment reads stay 16-byte aligned. Row ends are masked at read time (a vector select per fragment).
-template <int BM>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_strip_kernel(const GroupTable tab, const __bf16* __restrict__ wpb,
-                                                                    const float* __restrict__ bias, float* __restrict__ slab,
-                                                                    const int Cin, const int Cout, const int flags, const int nsplit) {
-    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
-    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
-    constexpr int NCO = WCO / 32, NM = WM / 32;
-    constexpr int KPT = BKT * BM / 256;
-    constexpr int HT = BKT / KPT;                // threads that cover the 32 channels of ONE halo voxel
-    static_assert(NCO == 1 && NM >= 1 && (KPT == 16 || KPT == 8), "tile");
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[2 * (BM + 2) * B16_KP];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[2 * BN * B16_KP];
-    __shared__ int s_roff[T2V_MAX_TAPS];
-    __shared__ int s_widx[T2V_MAX_TAPS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
-    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    int gi = 0;
-#pragma unroll
-    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
-        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
-    const t2v_conv_group& gd = tab.g[gi];
-    const float* __restrict__ x = gd.x;
-    const int D = gd.D, H = gd.H, W = gd.W;
-    const int HW = H * W, DHW = D * HW;
-    const int M = gd.N * DHW;
-    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
-    const int ntaps = gd.ntaps;
-    const int ndx = gd.dx[0] < 0 ? 3 : 1;
-    const int nrow = ntaps / ndx;
-    if (tid < nrow) s_roff[tid] = gd.dz[tid * ndx] * HW + gd.dy[tid * ndx] * W;
-    if (tid < ntaps) s_widx[tid] = gd.widx[tid];
-
-    const int ma_l = tid % BM, kq = tid / BM;
-    const bool halo_thread = tid < 2 * HT;
-    const int he = tid / HT, hq = tid % HT;          // halo: he = 0 left (voxel m0 - 1), 1 right (voxel m0 + BM)
-    uint32_t rowmask = 0, rowmask_h = 0;
-    size_t xbase = 0, xbase_h = 0;
-    {
-        const int m_a = m0 + ma_l;
-        if (m_a < M) {
-            const int n = m_a / DHW, sp = m_a - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
-            const int h = r / W;
-            xbase = (size_t)n * Cin * DHW + sp;
-            for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
-                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
-            }
-        }
-        const int m_h = he ? m0 + BM : m0 - 1;
-        if (halo_thread && m_h >= 0 && m_h < M) {
-            const int n = m_h / DHW, sp = m_h - n * DHW;
-            const int d = sp / HW, r = sp - d * HW;
-            const int h = r / W;
-            xbase_h = (size_t)n * Cin * DHW + sp;
-            for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
-                if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
-            }
-        }
-    }
-    bool can_l[NM], can_r[NM];
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-        const int m = m0 + wm * WM + j * 32 + l31;
-        const int w_ = m % W;
-        can_l[j] = w_ > 0;
-        can_r[j] = w_ < W - 1;
-    }
-    const int wc_l = tid >> 2, wk_l = (tid & 3) * 8;
-    const bool w_ok = co0 + wc_l < Cout;
-    const bool relu_in = flags & T2V_CONV_RELU_IN;
-
-    f32x16 acc[NCO][NM];
-#pragma unroll
-    for (int j = 0; j < NM; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-
-    float ra[KPT], rh[KPT];
-    bf16x8 rw;
-    const int ncb = Cin / BKT;
-    const int nchunks = ntaps * ncb;
-    const int cps = (nchunks + nsplit - 1) / nsplit;
-    const int q0 = blockIdx.z * cps;
-    int q1 = q0 + cps;
-    if (q1 > nchunks) q1 = nchunks;
-    __syncthreads();
-
-    int r_cur = q0 / (ncb * ndx);
-    int cb_cur = (q0 - r_cur * ncb * ndx) / ndx;
-    int d_cur = q0 - (r_cur * ncb + cb_cur) * ndx;
-    auto advance = [&]() {
-        if (++d_cur == ndx) { d_cur = 0; if (++cb_cur == ncb) { cb_cur = 0; ++r_cur; } }
-    };
-    bool pend_has_a = false, pend_av = false, pend_hv = false;
-    int pend_dx = 0;
-    auto load_chunk = [&](bool force_a) {
-        const int c0 = cb_cur * BKT;
-        pend_has_a = force_a || d_cur == 0;
-        pend_dx = ndx == 3 ? d_cur - 1 : 0;
-        if (pend_has_a) {
-            pend_av = (rowmask >> r_cur) & 1u;
-            const float* px = x + xbase + (pend_av ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + kq * KPT) * DHW;
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) ra[j] = px[(size_t)j * DHW];
-            if (halo_thread) {
-                pend_hv = (rowmask_h >> r_cur) & 1u;
-                const float* ph = x + xbase_h + (pend_hv ? (ptrdiff_t)s_roff[r_cur] : 0) + (size_t)(c0 + hq * KPT) * DHW;
-#pragma unroll
-                for (int j = 0; j < KPT; ++j) rh[j] = ph[(size_t)j * DHW];
-            }
-        }
-        const int t = r_cur * ndx + d_cur;
-        const __bf16* pw = wpb + ((size_t)s_widx[t] * Cout + (w_ok ? co0 + wc_l : 0)) * Cin + c0 + wk_l;
-        rw = *reinterpret_cast<const bf16x8*>(pw);
-    };
-    auto put_row = [&](__bf16* dst, const float* v, bool ok) {
-#pragma unroll
-        for (int g = 0; g < KPT / 8; ++g) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = ok ? v[g * 8 + j] : 0.f;
-                if (relu_in) f = fmaxf(f, 0.f);
-                o[j] = (__bf16)f;
-            }
-            *reinterpret_cast<bf16x8*>(dst + g * 8) = o;
-        }
-    };
-    auto stage = [&](int ab, int bb) {
-        if (pend_has_a) {
-            __bf16* xs = Xs + ab * ((BM + 2) * B16_KP);
-            put_row(xs + (1 + ma_l) * B16_KP + kq * KPT, ra, pend_av);
-            if (halo_thread) put_row(xs + (he ? BM + 1 : 0) * B16_KP + hq * KPT, rh, pend_hv);
-        }
-        bf16x8 wv = rw;
-        if (!w_ok) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wv[j] = (__bf16)0.f;
-        }
-        *reinterpret_cast<bf16x8*>(Ws + bb * (BN * B16_KP) + wc_l * B16_KP + wk_l) = wv;
-    };
-
-    int acur = 0, bcur = 0, dx_now = 0;
-    if (q0 < q1) {
-        load_chunk(true);
-        stage(0, 0);
-        dx_now = pend_dx;
-        __syncthreads();
-        if (q0 + 1 < q1) { advance(); load_chunk(false); }
-    }
-    bf16x8 zero8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zero8[j] = (__bf16)0.f;
-    for (int q = q0; q < q1; ++q) {
-        const __bf16* xs = Xs + acur * ((BM + 2) * B16_KP) + (1 + dx_now + wm * WM + l31) * B16_KP + 8 * hi;
-        const __bf16* ws = Ws + bcur * (BN * B16_KP) + (wco * WCO + l31) * B16_KP + 8 * hi;
-        bool keep[NM];
-#pragma unroll
-        for (int j = 0; j < NM; ++j) keep[j] = dx_now < 0 ? can_l[j] : (dx_now > 0 ? can_r[j] : true);
-#pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
-#pragma unroll
-            for (int j = 0; j < NM; ++j) {
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + j * 32 * B16_KP + ks * 16);
-                b = keep[j] ? b : zero8;
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0][j], 0, 0, 0);
-            }
-        }
-        const bool more = q + 1 < q1;
-        const bool next_a = more && pend_has_a;
-        int dx_next = dx_now;
-        if (more) { stage(acur ^ 1, bcur ^ 1); dx_next = pend_dx; }
-        __syncthreads();
-        if (q + 2 < q1) { advance(); load_chunk(false); }
-        bcur ^= 1;
-        if (next_a) acur ^= 1;
-        dx_now = dx_next;
-    }
-    igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHW, wm, wco, l31, hi);
-}
-
 // STRIP3 form of the bf16-compute GEMM (see conv_igemm_strip3_kernel): one barrier round = the staged strip of a (kernel row,
-// 32-channel block) + the weights of its THREE dx taps = 6 (64-voxel tile) / 12 (128) bf16 MFMAs per wave, where the per-dx
-// kernel above ran 2 / 4 between two barriers. Member state and addressing as in the fp32 strip3 kernel: 32-bit byte offsets
+// 32-channel block) + the weights of its THREE dx taps = 6 (64-voxel tile) / 12 (128) bf16 MFMAs per wave, where a per-dx
+// round would run 2 / 4 between two barriers. Member state and addressing as in the fp32 strip3 kernel: 32-bit byte offsets
 // through buffer loads (host: strip_fits32), lane tables read back with v_readlane, a zero ROW for the row-end lanes.
 // Single LDS stage, two barriers per round; the next round's gathers are issued right after the first.
 template <int BM>
@@ -2171,19 +1980,12 @@ extern "C" int t2v_conv_fwd_grouped_bf16_ok(const t2v_conv_group* groups, int ng
     if ((Cin % 32) != 0 || Cout <= 4 || thin_ok(groups, ngroups, Cin, Cout, nslots)) return 0;
     return 1;
 }
-extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const void* wpb,
-                                         const float* bias, float* ws, int flags, void* stream) {
-    GroupTable tab;
-    ConvPlan p;
-    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p))
-        return T2V_EINVAL;
-    if (flags & T2V_CONV_MASK_OUT) {
-        if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
-        for (int i = 0; i < ngroups; ++i)
-            if (!groups[i].mask) return T2V_EINVAL;
-    }
-    // same tiling decisions as the fp32 path, restricted to the tiles the bf16 kernels have (128 x 64, 64 x 64): re-tile when
-    // build_table picked 128 x 32 (Cout <= 32) or 256 x 64
+// Which bf16 instantiation a launch lands on (shared by the launcher and by t2v_conv_fwd_bf16_plan): same tiling decisions as
+// the fp32 path, restricted to the tiles the bf16 kernels have (128 x 64, 64 x 64) — re-tiled when build_table picked 128 x 32
+// (Cout <= 32) or 256 x 64. kind: 6 plain implicit GEMM (1-wide kernels, W = 1 members, tensors beyond 32-bit byte offsets),
+// 8 strip3 (three dx taps per barrier round).
+struct Bf16Variant { int kind; int bm; };
+static bool bf16_variant(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, GroupTable& tab, ConvPlan& p, Bf16Variant& v) {
     if (p.bn != 64 || p.bm == 256) {
         long mt = 0;
         p.bn = 64;
@@ -2195,6 +1997,40 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
         }
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
     }
+    const long wbytes = 2L * T2V_MAX_TAPS * Cout * Cin;                            // (32-bit byte offsets into the packed weight)
+    const bool s3_b16 = tun().strip && strip_ok(tab) && strip_fits32(tab, Cin) && wbytes < (1L << 31);
+    if (p.dstride2 && (!s3_b16 || (flags & T2V_CONV_ACCUM))) return false;        // frame-strided members: strip3 form only
+    v.bm = p.bm == 128 ? 128 : 64;
+    v.kind = s3_b16 ? 8 : 6;
+    return true;
+}
+// Launch-plan query of the bf16-compute entry point (no launch; host arithmetic): out[0] kind (6 conv_igemm_bf16_kernel,
+// 8 conv_igemm_bf16_strip3_kernel), out[1] BM (128 / 64), out[2] BN = 64, out[3] K chunk = 32, out[4] 1 for frame-strided members
+// (dstride / ydstride), out[7] split-K S; the rest 0. T2V_EINVAL where t2v_conv_fwd_grouped_bf16 would refuse the launch (the caller then uses fp32).
+extern "C" int t2v_conv_fwd_bf16_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out) {
+    GroupTable tab;
+    ConvPlan p;
+    Bf16Variant v;
+    if (!out || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, false, tab, p) ||
+        !bf16_variant(groups, ngroups, Cin, Cout, flags, tab, p, v))
+        return T2V_EINVAL;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[0] = v.kind; out[1] = v.bm; out[2] = 64; out[3] = 32; out[4] = p.dstride2 ? 1 : 0; out[7] = p.S;
+    return T2V_OK;
+}
+extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const void* wpb,
+                                         const float* bias, float* ws, int flags, void* stream) {
+    GroupTable tab;
+    ConvPlan p;
+    if (!wpb || !t2v_conv_fwd_grouped_bf16_ok(groups, ngroups, Cin, Cout) || !build_table(groups, ngroups, Cin, Cout, true, tab, p))
+        return T2V_EINVAL;
+    if (flags & T2V_CONV_MASK_OUT) {
+        if (flags & T2V_CONV_ACCUM) return T2V_EINVAL;
+        for (int i = 0; i < ngroups; ++i)
+            if (!groups[i].mask) return T2V_EINVAL;
+    }
+    Bf16Variant v;
+    if (!bf16_variant(groups, ngroups, Cin, Cout, flags, tab, p, v)) return T2V_EINVAL;
     if (p.S > 1 && !ws) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     double flops = 0;
@@ -2208,18 +2044,13 @@ extern "C" int t2v_conv_fwd_grouped_bf16(const t2v_conv_group* groups, int ngrou
     }
     {
         ProfScope prof(5, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);
+        int32_t plan_[8] = {v.kind, v.bm, 64, 32, p.dstride2 ? 1 : 0, 0, 0, p.S};
+        ProfScope::set_plan(plan_, 8);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
-        static const bool strip3_b16 = getenv("T2V_NO_BF16_STRIP3") == nullptr;       // developer A/B switch
-        const long wbytes = 2L * T2V_MAX_TAPS * Cout * Cin;                            // (32-bit byte offsets into the packed weight)
-        const bool s3_b16 = tun().strip && strip3_b16 && strip_ok(tab) && strip_fits32(tab, Cin) && wbytes < (1L << 31);
-        if (p.dstride2 && (!s3_b16 || (flags & T2V_CONV_ACCUM))) return T2V_EINVAL;        // frame-strided members: strip3 form only
-        if (s3_b16) {
-            if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        if (v.kind == 8) {
+            if (v.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
             else T2V_LAUNCH_PROF(conv_igemm_bf16_strip3_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
-        } else if (tun().strip && strip_ok(tab)) {
-            if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
-            else T2V_LAUNCH_PROF(conv_igemm_bf16_strip_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
-        } else if (p.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
+        } else if (v.bm == 128) T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<128>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
         else T2V_LAUNCH_PROF(conv_igemm_bf16_kernel<64>, grid, dim3(256), 0, s, tab, (const __bf16*)wpb, bias, ws, Cin, Cout, flags, p.S);
     }
     int st = launch_status();
@@ -3126,7 +2957,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
     }
 }
 
-struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; };
+struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; bool strided; };
 
 static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, bool need_ptrs,
                          WGroupTable& tab, WgradPlan& p) {
@@ -3160,6 +2991,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     for (int i = 0; i < ngroups; ++i) anyw = anyw || groups[i].W > 1;
     p.rows3 = (kW == 3) && anyw && Cin >= 64 && maxMC < (1L << 30);   // the 3-tap kernel gathers through 32-bit byte offsets
     if (strided && !p.rows3) return false;
+    p.strided = strided;
     p.liverows = 0;
     for (int r = 0; r < kD * kH; ++r)
         if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;
@@ -3293,6 +3125,8 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
         int32_t plan_[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
         fill_wgrad_plan(Cin, Cout, p, plan_);
+        plan_[6] = ((flags & T2V_CONV_BF16) && (p.rows3 || Cin >= 64)) ? 1 : 0;       // conv_wgrad3_kernel<true> / conv_wgrad_bf16_kernel
+        plan_[7] = p.strided ? 1 : 0;                                                  // dL/dy on the even frames (dstride = 2)
         ProfScope::set_plan(plan_, 8);
         if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
