@@ -65,11 +65,13 @@ def build_models(dev, seed=100, cond=False, size=64, channels=1):
 
 def synthetic_batches(batch, n, seed, dev, size=64, channels=1):
     from txt2vid_amd.data import SyntheticMovingDigits
+    from txt2vid_amd import functional as TF
     ds = SyntheticMovingDigits(length=batch * n, seed=seed, size=size, channels=channels)
     out = []
     for i in range(n):
-        vids = torch.stack([ds[i * batch + j][0] for j in range(batch)], 0)          # [B,T,C,H,W]
-        out.append(vids.permute(0, 2, 1, 3, 4).contiguous().to(dev))                # [B,C,T,H,W] in HBM
+        # generated in HBM by t2v_synth_clips (bit-identical to the host items ds[i]: tests/test_data_gpu.py)
+        vids, _, _ = ds.device_batch(range(i * batch, (i + 1) * batch), dev)         # [B,T,C,H,W]
+        out.append(TF.video_to_channel_first(vids))                                   # [B,C,T,H,W]
     return out
 
 

@@ -448,6 +448,18 @@ int t2v_scalar_combine(const void* const* ptrs, const float* weights, int n, flo
 int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* stream);
 
 
+/* ---- input row: synthetic Moving-MNIST-shaped clips + captions generated in HBM -----------------------------
+ * Replaces, for machines without a dataset, the host pipeline in front of the loop (txt2vid/data/__init__.py:201-255 contract;
+ * clip statistics of txt2vid/data/synthetic/generate.py:18-47,136-170): clip b is EXACTLY what the host-side
+ * txt2vid_amd.data.SyntheticMovingDigits(seed=seed, size=S, channels=C, num_frames=T)[index[b]] yields (numpy RandomState
+ * reproduced on the device: MT19937, 53-bit random_sample, masked-rejection randint). index_dev: int64 [B] on the device;
+ * vocab_ids: HOST array of T2V_SYNTH_VOCAB ids in the order <start> digit 0..9 is left and right top bottom <end>;
+ * vids: float [B,T,C,S,S] in [-1,1] (S % 4 == 0, S >= 28, T >= 2); tokens: int64 [B,8]; err_dev: optional int32 the kernel sets
+ * to 1 if a draw sequence ran out (never in practice; the caller zeroes it). */
+#define T2V_SYNTH_VOCAB 19
+int t2v_synth_clips(const int64_t* index_dev, int B, int64_t seed, int T, int C, int S, const int32_t* vocab_ids, float* vids,
+                    int64_t* tokens, int32_t* err_dev, void* stream);
+
 /* ---- optional launch instrumentation for bench.py's roofline line -----------------------------------
  * Between begin and end every conv-GEMM launch is bracketed by a hipEvent pair recorded on the launch
  * stream. end() synchronises and fills out[kind*3+{0,1,2}] = {total ms, executed flops, launches};

@@ -166,3 +166,31 @@ def test_input_pipeline_vs_reference_fixture(golden, tmp_path):
     # the same through the config factory (config/*.json: "class": "txt2vid.data.my_dataset")
     ds2 = D.my_dataset(data=str(tmp_path), vocab=vocab, anno=str(cap_path), transform=transform)
     assert np.array_equal(ds2[1][0].numpy(), g['ds_frames_1'])
+
+
+def test_device_loader_walks_the_clips_in_the_dataloader_order():
+    """`DeviceSyntheticLoader` (clips generated in HBM) visits the samples in the order torch's DataLoader(shuffle=True) does from the
+    same global generator state — host and device input rows are interchangeable mid-experiment (order only: no GPU needed)."""
+    import torch
+    ds = data.SyntheticMovingDigits(length=37, size=32, num_frames=4)
+
+    class Idx(torch.utils.data.Dataset):
+        def __len__(self):
+            return 37
+
+        def __getitem__(self, i):
+            return i
+    for shuffle in (True, False):
+        torch.manual_seed(123)
+        host = [int(i) for b in torch.utils.data.DataLoader(Idx(), batch_size=5, shuffle=shuffle, drop_last=True) for i in b]
+        after_host = torch.get_rng_state()
+        torch.manual_seed(123)
+        loader = data.DeviceSyntheticLoader(ds, 5, 'cuda:0', shuffle=shuffle)
+        order = loader.epoch_order()
+        assert [int(i) for i in order[:len(loader) * 5]] == host and len(loader) == 7
+        assert torch.equal(torch.get_rng_state(), after_host)          # the global generator advanced identically
+    # the factory hands the device loader out only for on_device synthetic clips and a CUDA device
+    on = data.my_dataset(data='synthetic', vocab=None, size=32, channels=1, seed=3, on_device=True)
+    assert isinstance(data.get_loader(dset=on, batch_size=4, device='cuda:0'), data.DeviceSyntheticLoader)
+    assert isinstance(data.get_loader(dset=on, batch_size=4, device='cpu'), torch.utils.data.DataLoader)
+    assert isinstance(data.get_loader(dset=ds, batch_size=4, device='cuda:0'), torch.utils.data.DataLoader)

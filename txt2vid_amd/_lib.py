@@ -182,6 +182,7 @@ SIGNATURES = {
     't2v_pyramid_scatter': [_P, _P, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P],
     't2v_scalar_combine': [_P, C.POINTER(C.c_float), _I, _P, _P],
     't2v_gather_rows': [_P, _P, _P, _L, _L, _I, _P],
+    't2v_synth_clips': [_P, _I, _L, _I, _I, _I, _I3, _P, _P, _P, _P],
     't2v_prof_begin': [_I],
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],

@@ -159,9 +159,10 @@ class SyntheticMovingDigits(torch.utils.data.Dataset):
     `<start> digit N is A and B <end>` (8 tokens). Mirrors the statistics of
     txt2vid/data/synthetic/generate.py:18-47,136-170. Deterministic per (seed, index)."""
 
-    def __init__(self, length=1024, num_frames=16, size=64, channels=1, seed=100, vocab=None):
+    def __init__(self, length=1024, num_frames=16, size=64, channels=1, seed=100, vocab=None, on_device=False):
         self.length, self.num_frames, self.size, self.channels, self.seed = length, num_frames, size, channels, seed
         self.vocab = vocab or Vocab()
+        self.on_device = bool(on_device)       # `get_loader(..., device=cuda)` then generates the batches in HBM (device_batch)
 
     def __len__(self):
         return self.length
@@ -184,6 +185,67 @@ class SyntheticMovingDigits(torch.utils.data.Dataset):
         a, b = MOTIONS[mot]
         cap = ['<start>', 'digit', str(digit), 'is', a, 'and', b, '<end>']
         return torch.from_numpy(vid), torch.tensor([self.vocab(w) for w in cap], dtype=torch.float32)
+
+    def device_batch(self, indices, device, out=None):
+        """The clips `[self[i] for i in indices]` generated STRAIGHT IN HBM by one kernel launch (`t2v_synth_clips`: numpy's
+        RandomState reproduced on the device, so every clip and caption equals the host item bit for bit) and already collated:
+        (videos [B,T,C,S,S] float32, tokens [B,8] int64, lengths [8]*B). No host pixel ever exists; nothing crosses PCIe but the
+        B indices. `indices`: int64 device tensor, or any host sequence; `out`: optional (videos, tokens) buffers to fill."""
+        import ctypes as C
+        from .._lib import lib, check
+        from .._ops import _stream
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise RuntimeError('device_batch generates on the GPU: the HIP path has no CPU fallback (index the dataset instead)')
+        idx = indices if isinstance(indices, torch.Tensor) else torch.as_tensor(list(indices), dtype=torch.int64)
+        idx = idx.to(device=dev, dtype=torch.int64).contiguous()
+        B = int(idx.numel())
+        T, S, Cc = self.num_frames, self.size, self.channels
+        if out is None:
+            vids = torch.empty((B, T, Cc, S, S), device=dev, dtype=torch.float32)
+            toks = torch.empty((B, 8), device=dev, dtype=torch.int64)
+        else:
+            vids, toks = out
+            if tuple(vids.shape) != (B, T, Cc, S, S) or tuple(toks.shape) != (B, 8) or not vids.is_contiguous() or not toks.is_contiguous() \
+                    or vids.dtype != torch.float32 or toks.dtype != torch.int64:
+                raise ValueError('device_batch: output buffers must be dense [B,T,C,S,S] float32 / [B,8] int64')
+        words = ['<start>', 'digit'] + [str(d) for d in range(10)] + ['is', 'left', 'and', 'right', 'top', 'bottom', '<end>']
+        ids = (C.c_int32 * len(words))(*[int(self.vocab(w)) for w in words])
+        if getattr(self, '_err', None) is None or self._err.device != dev:
+            self._err = torch.zeros((1,), device=dev, dtype=torch.int32)
+        check(lib().t2v_synth_clips(C.c_void_p(idx.data_ptr()), B, int(self.seed), T, Cc, S, ids, C.c_void_p(vids.data_ptr()),
+                                    C.c_void_p(toks.data_ptr()), C.c_void_p(self._err.data_ptr()), _stream()), 't2v_synth_clips')
+        return vids, toks, [8] * B
+
+
+class DeviceSyntheticLoader(object):
+    """Stands in for `DataLoader(SyntheticMovingDigits, ...)` when the clips are generated on the GPU: same iteration protocol
+    (len, iter -> (videos, tokens, lengths), drop_last), same sample order — a shuffling epoch draws its permutation exactly as
+    torch's RandomSampler does (a 64-bit seed from the global torch generator, then `randperm` on a private generator), so host
+    and device loaders started from the same generator state walk the same clips. Batches come out on the device."""
+
+    def __init__(self, dset, batch_size, device, shuffle=True):
+        self.dataset, self.batch_size, self.device, self.shuffle = dset, int(batch_size), torch.device(device), shuffle
+        self.sampler = None
+
+    def __len__(self):
+        return len(self.dataset) // self.batch_size
+
+    def epoch_order(self):
+        """The sample order of one epoch, consuming the global torch generator exactly as `iter(DataLoader(shuffle=True))` + its
+        first `next()` do: the iterator's base seed first, then the RandomSampler's seed for `randperm` on a private generator."""
+        n = len(self.dataset)
+        torch.empty((), dtype=torch.int64).random_()                 # (_BaseDataLoaderIter's base seed: drawn, unused here)
+        if not self.shuffle:
+            return torch.arange(n)
+        gen = torch.Generator()
+        gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        return torch.randperm(n, generator=gen)
+
+    def __iter__(self):
+        order = self.epoch_order()
+        for k in range(len(self)):
+            yield self.dataset.device_batch(order[k * self.batch_size:(k + 1) * self.batch_size], self.device)
 
 
 def collate_fn(data):
@@ -214,9 +276,14 @@ def my_dataset(data=None, vocab=None, anno=None, transform=None, random_frames=F
     return SyntheticMovingDigits(num_frames=num_frames, vocab=vocab, **synthetic_args)
 
 
-def get_loader(dset=None, batch_size=64, val=False, num_workers=0, has_captions=True, rank=0, world=1, seed=0):
+def get_loader(dset=None, batch_size=64, val=False, num_workers=0, has_captions=True, rank=0, world=1, seed=0, device=None):
     """data/__init__.py:379-383. With `world` > 1 every rank reads its own 1/world of each epoch's
-    permutation (one process per GPU; the reference's single-process DataParallel split one big batch)."""
+    permutation (one process per GPU; the reference's single-process DataParallel split one big batch).
+    Synthetic clips with `on_device` set (config: `"args": {"data": "synthetic", "on_device": true}`) and a CUDA `device` are
+    generated in HBM by `DeviceSyntheticLoader` instead of on host workers."""
+    if isinstance(dset, SyntheticMovingDigits) and getattr(dset, 'on_device', False) and device is not None and \
+            torch.device(device).type == 'cuda':
+        return DeviceSyntheticLoader(dset, batch_size, device, shuffle=not val)
     sampler = None
     if world > 1 and not isinstance(dset, SyntheticMovingDigits):     # synthetic clips already differ per rank (seed+rank)
         sampler = torch.utils.data.distributed.DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=not val,

@@ -119,7 +119,7 @@ def main(args):
     dset = create_object(args.data, vocab=vocab, anno=args.anno, transform=transform, size=args.frame_sizes[-1],
                          channels=args.num_channels, seed=(args.seed or 0) + rank)
     dataset = data.get_loader(dset=dset, batch_size=args.batch_size, val=False, num_workers=args.workers, rank=rank,
-                              world=world, seed=seed)
+                              world=world, seed=seed, device=device)
     status('GAN has %d parameters' % gan.count_params())
     if args.G_loss is None:
         args.G_loss = args.D_loss
