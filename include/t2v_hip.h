@@ -448,6 +448,46 @@ int t2v_scalar_combine(const void* const* ptrs, const float* weights, int n, flo
 int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t rows, int64_t cols, int inverse, void* stream);
 
 
+/* ---- pooled convolution: the second 3^3 convolution of every discriminator block together with the average pooling behind it
+ * (txt2vid/models/resnet3d.py:12-19 stem: conv -> AvgPool3d((1,2,2), 2); txt2vid/models/layers.py:219-243 DownBlock: conv ->
+ * DownSample). Box filter and convolution commute: pool(conv3(r)) = stride-2 conv3 of the box-summed activation r~ — 27 taps
+ * over the POOLED voxels (4x / 8x fewer MACs), same values up to summation order. Four pieces, closed under differentiation like
+ * conv / dgrad / wgrad:
+ *   t2v_pool_boxsum      r (+ fused ReLU, or a cotangent masked by [mask > 0]) -> r~ on the padded grid [N*C, Dp, H+1, W+2]
+ *   t2v_pool_conv_fwd    y[N,Cout,D',H',W'] = sum_taps wp[tap] . r~[2*pos + tap + 1]   (+ bias; split-K like t2v_conv_fwd_grouped)
+ *   t2v_pool_conv_dgrad  the 8 parity-class planes of the gradient on the padded grid from dL/dy (no zero-stuffed intermediate)
+ *   t2v_pool_unbox       planes -> dL/dr at full resolution, ReLU mask fused (the adjoint of t2v_pool_boxsum)
+ *   t2v_pool_conv_wgrad[_partial]  dW[tap] = sum_pos dL/dy[pos] (x) r~[2*pos + tap + 1] in the k-split slab format of
+ *                        t2v_conv_wgrad_grouped[_partial] (same reduce kernels, same t2v_wgrad_src)
+ * Members are t2v_conv_group with (D, H, W) = the FULL-RESOLUTION extents of r (H, W even >= 2; D == 1 or even) and
+ * dstride = tmode: 0 no time axis (D == 1), 1 time box-summed and strided like H / W (DownSample), 2 time strided without a
+ * box (the stem keeps the even frames). fwd / wgrad: x = r~, y = pooled output / dL/dy, taps in (dz,dy,dx) product order (9 or
+ * 27) with widx = packed slot (mode 0). dgrad: x = dL/dy, y = planes [8][N, C, Dq, H/2+1, W/2+1], widx[f] for the 27 FORWARD
+ * taps f = ((dz+1)*3 + dy+1)*3 + dx+1: the slot of the mode-1 packed weight holding that tap's matrix (ntaps ignored). */
+typedef struct t2v_poolbox_job {
+    const float* in;      /* boxsum: r (or a cotangent); unbox: the 8 class planes                                  */
+    const float* mask;    /* optional: boxsum multiplies `in` by [mask > 0]; unbox zeroes the result where mask <= 0 */
+    float* out;           /* boxsum: r~ [NC, Dp, H+1, W+2]; unbox: [NC, D, H, W]                                     */
+    int32_t NC, D, H, W;  /* full-resolution extents                                                                */
+    int32_t tmode, relu;  /* relu: boxsum clamps its input at 0 first                                               */
+    float scale;          /* 1 / window volume (0.25 or 0.125): folded into r~ and into the adjoint                 */
+    int32_t reserved;
+} t2v_poolbox_job;
+int t2v_pool_boxsum(const t2v_poolbox_job* jobs, int njobs, void* stream);
+int t2v_pool_unbox(const t2v_poolbox_job* jobs, int njobs, void* stream);
+int64_t t2v_pool_conv_fwd_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout);
+int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp, const float* bias, float* ws,
+                      int flags, void* stream);
+int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, const float* wp, void* stream);
+int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int want_bias);
+int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, float* slab, int flags,
+                        void* stream);
+int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* slab, int want_bias, int flags,
+                                t2v_wgrad_src* out_src, void* stream);
+/* Launch plans (host arithmetic): out[0] kind (9 pool forward, 10 pool data gradient, 11 pool weight gradient), out[1] tile
+ * voxels, out[2] 64, out[3] 32, out[5] VECB, out[7] split-K / k-split count S. */
+int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int32_t* out);
+
 /* ---- input row: synthetic Moving-MNIST-shaped clips + captions generated in HBM -----------------------------
  * Replaces, for machines without a dataset, the host pipeline in front of the loop (txt2vid/data/__init__.py:201-255 contract;
  * clip statistics of txt2vid/data/synthetic/generate.py:18-47,136-170): clip b is EXACTLY what the host-side

@@ -253,3 +253,56 @@ def all_checked_bf16_variants():
             fwd.setdefault(v, case[0])
         wg.setdefault(w, case[0])
     return fwd, wg
+
+
+# ------------------------------------------------------------------------------------------------
+# pooled convolution (functional_pool.py: box-sum + stride-2 GEMMs for the conv2 -> pooling pair of every discriminator block):
+# name, Cin, Cout, members, stem — the first two at the benchmark size (tests/test_ops_gpu.py::test_pool_conv_group_at_benchmark_size)
+# ------------------------------------------------------------------------------------------------
+POOL_CASES = [
+    ('pool_stem_conv2_B32', 64, 64, d_step_members(32, 0), True),       # 393 216 voxels -> 49 152 pooled rows
+    ('pool_down0_conv2_B32', 64, 128, d_step_members(32, 1), False),    # 49 152 -> 7 168 rows: split-K forward
+    ('pool_down1_conv2_B32', 128, 256, d_step_members(32, 2), False),
+    ('pool_small', 64, 64, [(2, 4, 16, 16), (1, 2, 8, 8), (3, 1, 4, 4)], True),
+]
+
+
+def pool_plan(what, members, cin, cout, stem):
+    """('pool_fwd'|'pool_dgrad', 64, 64, 32, 1, 1, 1, S) or ('pool_rows3', S, chunks per split, slots, reduce kind, workgroups): the
+    launch plan of the pooled forward (what 0), data gradient (1: cin = channels of dL/dy) or weight gradient (2)."""
+    from txt2vid_amd._lib import lib, ConvGroup
+    from txt2vid_amd.functional_pool import pool_tmode
+    arr = (ConvGroup * len(members))()
+    for a, (n, d, h, w) in zip(arr, members):
+        tm = pool_tmode((n, 0, d, h, w), stem)
+        assert tm is not None
+        a.x = a.y = a.mask = None
+        a.N, a.D, a.H, a.W, a.dstride = n, d, h, w, tm
+        j = 0
+        for dz in ((-1, 0, 1) if tm else (0,)):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    a.dz[j], a.dy[j], a.dx[j], a.widx[j] = dz, dy, dx, j
+                    j += 1
+        a.ntaps = j
+        if what == 1:
+            for f in range(27):
+                a.widx[f] = f
+    out = (C.c_int32 * 8)()
+    rc = lib().t2v_pool_conv_plan(what, arr, len(members), cin, cout, out)
+    assert rc == 0, rc
+    v = list(out)
+    if what == 2:
+        return ('pool_rows3', v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
+    return (('pool_fwd', 'pool_dgrad')[what],) + tuple(v[1:])
+
+
+def all_checked_pool_variants():
+    """(forward / data-gradient keys, weight-gradient keys) the POOL_CASES reach — same key shapes as the un-pooled kernels'."""
+    fwd, wg = {}, {}
+    for name, cin, cout, members, stem in POOL_CASES:
+        fwd.setdefault(variant_key(pool_plan(0, members, cin, cout, stem)), name + ' fwd')
+        fwd.setdefault(variant_key(pool_plan(1, members, cout, cin, stem)), name + ' dgrad')
+        p = pool_plan(2, members, cin, cout, stem)
+        wg.setdefault((p[0], p[4]), name)
+    return fwd, wg

@@ -72,6 +72,33 @@ def test_every_bf16_instantiation_is_reached_by_a_parity_case():
     assert cc.bf16_fwd_plan_of(cc._group_array([(2, 4, 8, 8)], 64, 1, (3, 3, 3)), 1, 64, 1) is None
 
 
+def test_pooled_convolution_plans():
+    """The pooled convolution (functional_pool.py) at the benchmark size: the stem's 393 216 voxels become 49 152 pooled GEMM rows
+    (768 tiles: one round of resident workgroups, no split-K), down0's launch splits K to fill the chip; every pooled kernel and
+    both reduce forms are reached by a POOL_CASES entry; members the pooled form cannot take are refused (the caller then runs
+    the un-pooled path)."""
+    import ctypes as C
+    from txt2vid_amd._lib import lib, ConvGroup
+    name, cin, cout, members, stem = cc.POOL_CASES[0]
+    assert sum(n * d * h * w for n, d, h, w in members) == 393216
+    assert cc.pool_plan(0, members, cin, cout, stem) == ('pool_fwd', 64, 64, 32, 1, 1, 1, 1)
+    assert cc.pool_plan(1, members, cout, cin, stem)[0] == 'pool_dgrad'
+    w = cc.pool_plan(2, members, cin, cout, stem)
+    assert w[0] == 'pool_rows3' and 900 <= w[5] <= 1024                    # one round of weight-gradient workgroups
+    assert cc.pool_plan(0, cc.POOL_CASES[1][3], 64, 128, False)[7] > 1     # down0: 112 tiles x 2 -> split-K
+    fwd, wg = cc.all_checked_pool_variants()
+    assert set(fwd) == {('pool_fwd', 64, 64, 32, 1, 1, 1), ('pool_dgrad', 64, 64, 32, 1, 1, 1)}
+    assert set(wg) == {('pool_rows3', 'reduce'), ('pool_rows3', 'reduce_small')}
+    out = (C.c_int32 * 8)()
+    arr = (ConvGroup * 1)()
+    arr[0].N, arr[0].D, arr[0].H, arr[0].W, arr[0].dstride, arr[0].ntaps = 2, 3, 8, 8, 1, 27        # odd frame count
+    assert lib().t2v_pool_conv_plan(2, arr, 1, 64, 64, out) < 0
+    arr[0].D, arr[0].W = 4, 1                                                                     # one voxel wide
+    assert lib().t2v_pool_conv_plan(2, arr, 1, 64, 64, out) < 0
+    arr[0].W = 8
+    assert lib().t2v_pool_conv_plan(2, arr, 1, 64, 64, out) == 0 and lib().t2v_pool_conv_plan(1, arr, 1, 48, 64, out) < 0   # K % 32
+
+
 def test_plan_queries_reject_bad_geometry():
     import ctypes as C
     from txt2vid_amd._lib import lib, ConvGroup

@@ -671,9 +671,10 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
                 worst = max(worst, e / abs(v))
     print('B=32: worst relative per-parameter gradient-norm deviation %.2e over %d + %d parameters' % (worst, len(d_ref), len(g_ref)))
     # ---- every convolution instantiation this iteration launched is one an op-level parity case covers
-    checked_fwd = set(cc.all_checked_fwd_variants())
-    checked_wgrad = set(cc.all_checked_wgrad_variants())
-    kinds = ('igemm', 'strip', 'thin', 'linear', 'thin2', 'strip3')
+    pool_fwd, pool_wg = cc.all_checked_pool_variants()
+    checked_fwd = set(cc.all_checked_fwd_variants()) | set(pool_fwd)
+    checked_wgrad = set(cc.all_checked_wgrad_variants()) | set(pool_wg)
+    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad'}
     launched = set()
     rows = dump.read_text().strip().splitlines()[1:]
     assert len(rows) > 150
@@ -687,10 +688,12 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
             launched.add(key)
             assert key in checked_fwd, ('launched at B=32 but in no op-level parity case', key, line)
         elif kind == 1:
-            key = (('taps', 'cols', 'rows3')[plan[0]], ('reduce', 'reduce_small')[plan[4]])
+            key = ({0: 'taps', 1: 'cols', 2: 'rows3', 11: 'pool_rows3'}[plan[0]], ('reduce', 'reduce_small')[plan[4]])
             launched.add(key)
             assert key in checked_wgrad, key
-    assert ('strip3', 256, 64, 16, 1, 1, 1) in launched and ('rows3', 'reduce_small') in launched
+    # the stem's second convolution runs in its pooled form (box-sum + stride-2 GEMMs), the other big layers on the strip kernels
+    assert ('pool_fwd', 64, 64, 32, 1, 1, 1) in launched and ('pool_dgrad', 64, 64, 32, 1, 1, 1) in launched
+    assert ('pool_rows3', 'reduce_small') in launched and ('rows3', 'reduce_small') in launched
     print('B=32: %d convolution launches on %d instantiations, all covered by op-level parity cases' % (len(rows), len(launched)))
 
 
@@ -727,7 +730,7 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
     bf_fwd, bf_wg = cc.all_checked_bf16_variants()
     checked_fwd = set(cc.all_checked_fwd_variants())
     checked_wgrad = set(cc.all_checked_wgrad_variants())
-    kinds = ('igemm', 'strip', 'thin', 'linear', 'thin2', 'strip3')
+    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3'}        # (no pooled form in bf16-compute mode)
     launched = set()
     rows = dump.read_text().strip().splitlines()[1:]
     assert len(rows) > 150

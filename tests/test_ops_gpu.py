@@ -891,3 +891,97 @@ def test_bmm_wide_tiles(ta, tb):
         want = torch.bmm(A.transpose(1, 2) if ta else A, B.transpose(1, 2) if tb else B)
         got = TF.bmm(A.to(dev()), B.to(dev()), ta, tb).cpu()
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _pool_ref(x, w, b, stem):
+    """pool(conv3(relu(x), w) + b) as the reference computes it: the stem's AvgPool3d((1,2,2), stride 2) (resnet3d.py:16) or
+    DownSample's pooling by 2 on every extent > 1 (layers.py:202-215)."""
+    y = F.conv3d(F.relu(x), w, b, padding=1)
+    if stem:
+        return F.avg_pool3d(y, (1, 2, 2), 2)
+    k = tuple(2 if n > 1 else 1 for n in y.shape[2:])
+    return F.avg_pool3d(y, k, k)
+
+
+@pytest.mark.parametrize('stem,members,cin,cout', [
+    (True, [(2, 4, 16, 16), (1, 2, 8, 8), (3, 1, 4, 4)], 64, 64),          # stem pooling: even frames, no time box; one member without a time axis
+    (False, [(2, 4, 8, 8), (2, 2, 16, 16), (3, 1, 4, 4)], 64, 96),         # DownSample: (2,2,2) boxes, a (1,2,2) member, two channel tiles
+    (False, [(2, 1, 32, 32), (1, 1, 2, 2)], 32, 64),                       # no member has a time axis: the 9-tap weight set
+    (True, [(3, 6, 10, 6)], 96, 32),                                       # non-power-of-two extents, Cin = 96 (three channel blocks)
+])
+def test_pool_conv_group(stem, members, cin, cout):
+    """`pool_conv_group` (box-sum + stride-2 GEMMs, functional_pool.py) against torch's avg_pool3d(conv3d(relu(x))) on the CPU:
+    values, first-order gradients (data, weight, bias) and — like the gradient penalty — gradients THROUGH a recorded backward
+    (d penalty / d x, d penalty / d w), i.e. all three GEMMs (forward, data gradient, weight gradient) in both of their roles."""
+    from txt2vid_amd import functional as TF
+    xs_h = [rnd(90 + i, n, cin, d, h, w) for i, (n, d, h, w) in enumerate(members)]
+    w_h, b_h = rnd(7, cout, cin, 3, 3, 3) * 0.05, rnd(8, cout)
+    xs = [t.to(dev()).requires_grad_(True) for t in xs_h]
+    w, b = torch.nn.Parameter(w_h.to(dev())), torch.nn.Parameter(b_h.to(dev()))
+    assert TF.pool_conv_ok(xs, w, stem)
+    ys = TF.pool_conv_group(xs, w, b, relu_in=True, stem=stem)
+    xr = [t.clone().requires_grad_(True) for t in xs_h]
+    wr, br = w_h.clone().requires_grad_(True), b_h.clone().requires_grad_(True)
+    yr = [_pool_ref(x, wr, br, stem) for x in xr]
+    for y, r in zip(ys, yr):
+        assert y.shape == r.shape
+        close(y.detach(), r.detach())
+    gys = [rnd(50 + i, *y.shape) for i, y in enumerate(yr)]
+
+    def second_order(outs, leaves, to):
+        f = sum((o * g.to(to)).sum() for o, g in zip(outs, gys))
+        g1 = torch.autograd.grad(f, leaves, create_graph=True)
+        pen = sum((g * g).sum() for g in g1[:len(outs)])                     # (penalty on the data gradients, like the GP)
+        g2 = torch.autograd.grad(pen, leaves, allow_unused=True)
+        return [g.detach() for g in g1], g2
+
+    got1, got2 = second_order(ys, xs + [w, b], dev())
+    ref1, ref2 = second_order(yr, xr + [wr, br], 'cpu')
+    for a, r in zip(got1, ref1):
+        close(a, r, rtol=2e-4, atol=2e-4)
+    n = len(members)
+    close(got2[n], ref2[n], rtol=2e-4, atol=2e-4)                           # d penalty / d w through the recorded data gradient
+    for a, r in zip(got2[:n], ref2[:n]):                                    # d penalty / d x: zero almost everywhere (ReLU'' = 0), both sides
+        assert (a is None or float(a.abs().max()) == 0.0) and (r is None or float(r.abs().max()) == 0.0)
+    # first order WITHOUT a recorded graph (the plain backward of the D / G steps)
+    ys = TF.pool_conv_group(xs, w, b, relu_in=True, stem=stem)
+    plain = torch.autograd.grad(sum((o * g.to(dev())).sum() for o, g in zip(ys, gys)), xs + [w, b])
+    for a, r in zip(plain, ref1):
+        close(a, r, rtol=2e-4, atol=2e-4)
+
+
+def test_pool_conv_group_at_benchmark_size():
+    """The stem's pooled convolution over the 8 discriminator-step members at the benchmark size (M = 393 216 input voxels ->
+    49 152 pooled rows) and down0's over its 8 members: forward, data gradient and weight + bias gradient (raw launches, k-split
+    weight gradient with its reduce) against torch on the CPU."""
+    from txt2vid_amd import functional as TF
+    import conv_cases as cc
+    for name, cin, cout, members, stem in cc.POOL_CASES[:2]:
+        w = rnd(2, cout, cin, 3, 3, 3) * (1.0 / np.sqrt(cin * 27.0))
+        b = rnd(3, cout) * 0.1
+        xs = [rnd(10 + i, n, cin, d, h, wd) for i, (n, d, h, wd) in enumerate(members)]
+        tmodes = [TF.pool_tmode(x.shape, stem) for x in xs]
+        shapes = [tuple(x.shape) for x in xs]
+        wd_, bd_ = w.to(dev()), b.to(dev())
+        xd = [x.to(dev()) for x in xs]
+        rts = TF.boxsum_raw(xd, tmodes, True)
+        ys = TF.pool_fwd_raw(rts, shapes, tmodes, wd_, bd_)
+        gys = [rnd(40 + i, *y.shape) for i, y in enumerate(ys)]
+        gyd = [g.to(dev()) for g in gys]
+        gxs = TF.unbox_raw(TF.pool_dgrad_raw(gyd, shapes, tmodes, wd_), shapes, tmodes, masks=xd)
+        dbias = torch.empty(cout, device=dev())
+        dw = TF.pool_wgrad_raw(rts, gyd, shapes, tmodes, tuple(w.shape), dbias=dbias)
+        torch.cuda.synchronize()
+        dw_ref = torch.zeros(w.shape, dtype=torch.float64)
+        db_ref = torch.zeros(cout, dtype=torch.float64)
+        for i, (x, gy) in enumerate(zip(xs, gys)):
+            xr = x.clone().requires_grad_(True)
+            wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            yr = _pool_ref(xr, wr, br, stem)
+            close(ys[i], yr)
+            (yr * gy).sum().backward()
+            close(gxs[i], xr.grad)
+            dw_ref += wr.grad.double()
+            db_ref += br.grad.double()
+        close(dw, dw_ref, rtol=2e-4, atol=2e-4)
+        close(dbias, db_ref, rtol=2e-4, atol=2e-4)

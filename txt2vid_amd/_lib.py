@@ -40,6 +40,12 @@ class PoolJob(C.Structure):
                 ('p', C.c_int32 * 3)]
 
 
+class PoolBoxJob(C.Structure):
+    """t2v_poolbox_job (include/t2v_hip.h)."""
+    _fields_ = [('in_', C.c_void_p), ('mask', C.c_void_p), ('out', C.c_void_p), ('NC', C.c_int32), ('D', C.c_int32), ('H', C.c_int32),
+                ('W', C.c_int32), ('tmode', C.c_int32), ('relu', C.c_int32), ('scale', C.c_float), ('reserved', C.c_int32)]
+
+
 class MultiJob(C.Structure):
     """t2v_multi_job (include/t2v_hip.h)."""
     _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('out', C.c_void_p), ('out2', C.c_void_p), ('n', C.c_int64),
@@ -182,12 +188,21 @@ SIGNATURES = {
     't2v_pyramid_scatter': [_P, _P, _I, _I, _I, _L, _I, _I, _I, _I, _I, _P],
     't2v_scalar_combine': [_P, C.POINTER(C.c_float), _I, _P, _P],
     't2v_gather_rows': [_P, _P, _P, _L, _L, _I, _P],
+    't2v_pool_boxsum': [_P, _I, _P],
+    't2v_pool_unbox': [_P, _I, _P],
+    't2v_pool_conv_fwd_ws_floats': [_P, _I, _I, _I],
+    't2v_pool_conv_fwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
+    't2v_pool_conv_dgrad': [_P, _I, _I, _I, _P, _P],
+    't2v_pool_conv_wgrad_slab_floats': [_P, _I, _I, _I, _I],
+    't2v_pool_conv_wgrad': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
+    't2v_pool_conv_wgrad_partial': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
+    't2v_pool_conv_plan': [_I, _P, _I, _I, _I, _I3],
     't2v_synth_clips': [_P, _I, _L, _I, _I, _I, _I3, _P, _P, _P, _P],
     't2v_prof_begin': [_I],
     't2v_prof_end': [C.POINTER(C.c_double), _I],
     't2v_version': [],
 }
-_RESTYPE = {'t2v_multi_ws_floats': C.c_int64, 't2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_grouped_bias_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
+_RESTYPE = {'t2v_multi_ws_floats': C.c_int64, 't2v_pool_conv_fwd_ws_floats': C.c_int64, 't2v_pool_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_slab_floats': C.c_int64, 't2v_conv_wgrad_grouped_bias_slab_floats': C.c_int64, 't2v_conv_fwd_grouped_ws_floats': C.c_int64,
             't2v_conv_wgrad_grouped_slab_floats': C.c_int64, 't2v_conv_fwd_ws_floats': C.c_int64, 't2v_channel_sum_ws_floats': C.c_int64, 't2v_channel_sum_grouped_ws_floats': C.c_int64, 't2v_bn_ws_floats': C.c_int64, 't2v_version': C.c_char_p}
 
 _lib = None

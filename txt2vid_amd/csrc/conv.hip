@@ -1005,6 +1005,375 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// POOLED CONVOLUTION (forward): y = stride-2 conv3 of the box-summed activation r~ (pointwise.hip: pool_boxsum_k) — what
+// `AvgPool(conv3(relu(r)))` equals, since box filter and convolution commute: 27 taps over the POOLED voxels instead of 27 taps
+// over all of them. r~ sits on a padded grid [N, Cin, Dp, H+1, W+2] (padded index = position + 1; every tap of every pooled
+// voxel reads real data: no bounds checks, no masks), so this is the strip3 GEMM with a mask-free gather: row m' = (n, e, i, j)
+// of the GEMM reads, for the kernel row (dz, dy), the three values r~[2e+dz+1, 2i+dy+1, 2j + {0,1,2}] — one 8-byte and one 4-byte
+// buffer load per (voxel, channel) — and stages them as three dx planes. One barrier round = 3 taps x 32 channels = 48 MFMAs per
+// wave, exactly as in strip3. Members: t2v_conv_group with x = r~, y = the pooled output, (D, H, W) = the FULL-RESOLUTION extents
+// and dstride = tmode (0: D == 1; 1 / 2: time strided with / without the box sum); taps in (dz, dy, dx) product order.
+// ------------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(256, 3) void conv_pool_fwd_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias, float* __restrict__ slab,
+                                                               const int Cin, const int Cout, const int flags, const int nsplit) {
+    constexpr bool VECB = true;             // (host: Cout % 4 == 0 — the pooled path takes channel counts that are multiples of 32)
+    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
+    constexpr int NCO = WCO / 32, NM = WM / 32;
+    constexpr int AP = BM + 4;
+    constexpr int LA = BKT * BM / 256;
+    constexpr int KSA = 256 / BM;
+    constexpr int NV = BKT * BN / 4;
+    constexpr int LBV = NV / 256;
+    constexpr int KSBV = 1024 / BN;
+    constexpr int LB = BKT * BN / 256;
+    constexpr int KSB = 256 / BN;
+    static_assert(NCO == 1 && NM >= 1 && LA >= 1 && LBV >= 1, "tile");
+
+    __shared__ __attribute__((aligned(16))) float As[3 * BKT * AP];      // [dx][k][voxel]
+    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int tm = gd.dstride;
+    const int Dn = tm ? gd.D / 2 : 1, Hn = gd.H / 2, Wn = gd.W / 2;          // pooled extents
+    const int Hp = gd.H + 1, Wp = gd.W + 2, Dp = tm ? gd.D + 1 : 1;
+    const int Vp = Dp * Hp * Wp;
+    const int HWn = Hn * Wn, DHWn = Dn * HWn;
+    const int M = gd.N * DHWn;
+    const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
+    const int ntaps = gd.ntaps;
+    const int nrow = ntaps / 3;
+
+    const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
+    const int tab_roff = ((tm ? gd.dz[lane_r * 3] + 1 : 0) * Hp + gd.dy[lane_r * 3] + 1) * Wp * 4;
+    const int tab_widx = gd.widx[lane_t];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * Vp) * (uint32_t)Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
+
+    const int ma_l = tid % BM, ka_l = tid / BM;
+    uint32_t xbase = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {                              // (rows past the end gather voxel 0: their columns are never stored)
+            const int n = m_a / DHWn, sp = m_a - n * DHWn;
+            const int e = sp / HWn, r = sp - e * HWn;
+            const int i = r / Wn, j = r - i * Wn;
+            xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)Vp + (uint32_t)(((tm ? 2 * e : 0) * Hp + 2 * i) * Wp + 2 * j);
+        }
+    }
+    const int cob_l = tid % BN, kb_l = tid / BN;
+    const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4);
+    const bool co_ok = VECB ? (co0 + cv_l) < Cout : (co0 + cob_l) < Cout;
+    const uint32_t xoff = (xbase + (uint32_t)ka_l * (uint32_t)Vp) * 4u;
+    const uint32_t woff = co_ok ? (uint32_t)((VECB ? kv_l : kb_l) * Cout + co0 + (VECB ? cv_l : cob_l)) * 4u : 0u;
+
+    f32x16 acc[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    float2 ra2[LA];
+    float ra1[LA];
+    float rb[VECB ? 1 : 3 * LB];
+    float4 rbv[VECB ? 3 * LBV : 1];
+    const int ncb = Cin / BKT;
+    const int nrounds = nrow * ncb;
+    const int rps = (nrounds + nsplit - 1) / nsplit;
+    const int q0 = blockIdx.z * rps;
+    int q1 = q0 + rps;
+    if (q1 > nrounds) q1 = nrounds;
+
+    auto load_round = [&](int q) {
+        const int r_cur = q / ncb, cb = q - r_cur * ncb;
+        const int c0 = cb * BKT;
+        const uint32_t vo = xoff + (uint32_t)__builtin_amdgcn_readlane(tab_roff, r_cur);
+        const int sx = c0 * Vp * 4;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            ra2[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rx, vo, sx + j * (KSA * 4) * Vp, 0));
+            ra1[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo + 8u, sx + j * (KSA * 4) * Vp, 0));
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int sw = (__builtin_amdgcn_readlane(tab_widx, r_cur * 3 + d) * Cin + c0) * Cout * 4;
+            if (VECB) {
+#pragma unroll
+                for (int j = 0; j < LBV; ++j)
+                    rbv[d * LBV + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, sw + j * (KSBV * 4) * Cout, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < LB; ++j)
+                    rb[d * LB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, sw + j * (KSB * 4) * Cout, 0));
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            float* a = As + (ka_l + j * KSA) * AP + ma_l;
+            a[0] = ra2[j].x;
+            a[BKT * AP] = ra2[j].y;
+            a[2 * BKT * AP] = ra1[j];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float* bs = Bs + d * (BKT * BN);
+            if (VECB) {
+#pragma unroll
+                for (int j = 0; j < LBV; ++j)
+                    *reinterpret_cast<float4*>(&bs[(kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rbv[d * LBV + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < LB; ++j) bs[(kb_l + j * KSB) * BN + cob_l] = co_ok ? rb[d * LB + j] : 0.f;
+            }
+        }
+    };
+
+    if (q0 < q1) load_round(q0);
+    for (int q = q0; q < q1; ++q) {
+        stage();
+        __syncthreads();
+        if (q + 1 < q1) load_round(q + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float* bs = Bs + d * (BKT * BN) + wco * WCO + l31;
+            const float* as = As + d * (BKT * AP) + wm * WM + l31;
+#pragma unroll
+            for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                const int krow = k2 * 2 + hi;
+                const float a = bs[krow * BN];
+                float b[NM];
+#pragma unroll
+                for (int j = 0; j < NM; ++j) b[j] = as[krow * AP + j * 32];
+#pragma unroll
+                for (int j = 0; j < NM; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+    f32x16 (&acc2)[1][NM] = reinterpret_cast<f32x16 (&)[1][NM]>(acc);
+    igemm_epilogue<1, NM, WCO, WM>(acc2, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWn, wm, wco, l31, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// POOLED CONVOLUTION (data gradient): g~ = conv^T(subsample^T(dL/dy)) on the padded r~ grid, WITHOUT the zero-stuffed
+// intermediate. A padded index p = 2a + c receives, per axis, from the taps d = -1 (source a) and d = +1 (source a - 1) when
+// its parity c is 0, and from the tap d = 0 (source a) when c is 1: every forward tap feeds exactly one of the 8 parity classes,
+// so the 27 taps are spent once over the POOLED grid. Each class is written as a dense plane over the grid (a_t, a, b) of extents
+// (D/2+1, H/2+1, W/2+1) (pointwise.hip: pool_unbox_k sums the planes back to full resolution and applies the ReLU mask).
+// A workgroup owns a tile of 64 grid voxels x 64 channels of ONE (ct, cy) class pair (blockIdx.y & 3): its kernel rows are the
+// (dz, dy) of that pair, and the three dx taps of a row share one staged strip of dL/dy exactly as in strip3 — dx = -1 and +1
+// accumulate into the cx = 0 plane (reading the strip at b and b - 1), dx = 0 into the cx = 1 plane.
+// Members: x = dL/dy [N, K, D', H', W'], y = the 8 planes, (D, H, W) full-resolution extents, dstride = tmode;
+// widx[f] = packed slot (mode 1: [K][C]) holding forward tap f's matrix, f = ((dz+1)*3 + dy+1)*3 + dx+1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                                 const int K, const int C) {
+    constexpr bool VECB = true;             // (host: C % 4 == 0)
+    constexpr int BM = 64, BN = 64, BKT = 32, WAVES_CO = 2;
+    constexpr int WCO = 32, WM = 32;
+    constexpr int AP = BM + 4;              // [left halo][BM voxels][pad][zero column]
+    constexpr int LA = BKT * BM / 256;
+    constexpr int KSA = 256 / BM;
+    constexpr int LBV = BKT * BN / 4 / 256;
+    constexpr int KSBV = 1024 / BN;
+    constexpr int LB = BKT * BN / 256;
+    constexpr int KSB = 256 / BN;
+
+    __shared__ __attribute__((aligned(16))) float As[BKT * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave % WAVES_CO, wm = wave / WAVES_CO;
+
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int tm = gd.dstride;
+    const int pair = blockIdx.y & 3, ct = pair >> 1, cy = pair & 1;
+    if (tm == 0 && ct) return;                                   // (uniform) members without a time axis have one time class
+    const int co0 = (blockIdx.y >> 2) * BN;
+    const int Dn = tm ? gd.D / 2 : 1, Hn = gd.H / 2, Wn = gd.W / 2;           // extents of dL/dy
+    const int Dq = tm ? Dn + 1 : 1, Hq = Hn + 1, Wq = Wn + 1;                 // the padded-grid planes
+    const int HWn = Hn * Wn, Vn = Dn * HWn;
+    const int HWq = Hq * Wq, Vq = Dq * HWq;
+    const int M = gd.N * Vq;
+    const int m0 = (tile - tab.tile_start[gi]) * BM;
+    // kernel rows of this class pair: dz in {-1,+1} (ct = 0) or {0} (ct = 1; also tmode 0), dy likewise
+    const int ndz = (tm && ct == 0) ? 2 : 1, ndy = cy == 0 ? 2 : 1;
+    const int nrow = ndz * ndy;
+    const int lane_t = lane < 27 ? lane : 0;
+    const int tab_widx = gd.widx[lane_t];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * Vn) * (uint32_t)K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
+
+    // ---- my staged voxel (tid % BM) and, for the first threads, the tile's left halo
+    const int ma_l = tid % BM, ka_l = tid / BM;
+    const int hk = tid % BKT;
+    const bool halo_thread = tid < BKT;
+    int s_at = 0, s_a = 0, s_b = Wn;          // (b = Wn: the padded column, never a valid source)
+    uint32_t s_n = 0;
+    int h_at = 0, h_a = 0, h_b = Wn;
+    uint32_t h_n = 0;
+    {
+        const int m_a = m0 + ma_l;
+        if (m_a < M) {
+            const int n = m_a / Vq, sp = m_a - n * Vq;
+            s_at = sp / HWq;
+            const int r = sp - s_at * HWq;
+            s_a = r / Wq;
+            s_b = r - s_a * Wq;
+            s_n = (uint32_t)n;
+        }
+        if (m0 < M) {                            // left neighbour of the tile's first voxel: same row, b - 1 (only read when b >= 1)
+            const int n = m0 / Vq, sp = m0 - n * Vq;
+            h_at = sp / HWq;
+            const int r = sp - h_at * HWq;
+            h_a = r / Wq;
+            h_b = r - h_a * Wq - 1;
+            h_n = (uint32_t)n;
+            if (h_b < 0) h_b = Wn;               // (row start: no left neighbour)
+        }
+    }
+    bool can_l[1];
+    {
+        const int m = m0 + wm * WM + l31;
+        can_l[0] = (m % Wq) >= 1;
+    }
+    const int cob_l = tid % BN, kb_l = tid / BN;
+    const int cv_l = (tid % (BN / 4)) * 4, kv_l = tid / (BN / 4);
+    const bool co_ok = VECB ? (co0 + cv_l) < C : (co0 + cob_l) < C;
+    const uint32_t woff = co_ok ? (uint32_t)((VECB ? kv_l : kb_l) * C + co0 + (VECB ? cv_l : cob_l)) * 4u : 0u;
+
+    f32x16 acc0, acc1;                       // cx = 0 (dx = -1, +1) and cx = 1 (dx = 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    float ra[LA], rah = 0.f;
+    float rb[VECB ? 1 : 3 * LB];
+    float4 rbv[VECB ? 3 * LBV : 1];
+    const int ncb = K / BKT;
+    const int nrounds = nrow * ncb;
+    bool pend_av = false, pend_hv = false;
+
+    auto load_round = [&](int q) {
+        const int r_cur = q / ncb, cb = q - r_cur * ncb;
+        const int c0 = cb * BKT;
+        const int rz = r_cur / ndy, ry = r_cur - rz * ndy;
+        const int dz = (tm && ct == 0) ? 2 * rz - 1 : 0, dy = cy == 0 ? 2 * ry - 1 : 0;
+        const int st = dz > 0 ? -1 : 0, sy = dy > 0 ? -1 : 0;          // source offsets on the dL/dy grid
+        const int sx = c0 * Vn * 4;
+        {
+            const int at = s_at + st, a = s_a + sy;
+            pend_av = (unsigned)at < (unsigned)Dn && (unsigned)a < (unsigned)Hn && s_b < Wn;
+            const uint32_t vo = pend_av ? ((s_n * (uint32_t)K + (uint32_t)ka_l) * (uint32_t)Vn + (uint32_t)((at * Hn + a) * Wn + s_b)) * 4u : 0u;
+#pragma unroll
+            for (int j = 0; j < LA; ++j)
+                ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, sx + j * (KSA * 4) * Vn, 0));
+        }
+        if (halo_thread) {
+            const int at = h_at + st, a = h_a + sy;
+            pend_hv = (unsigned)at < (unsigned)Dn && (unsigned)a < (unsigned)Hn && h_b < Wn;
+            const uint32_t vo = pend_hv ? ((h_n * (uint32_t)K + (uint32_t)hk) * (uint32_t)Vn + (uint32_t)((at * Hn + a) * Wn + h_b)) * 4u : 0u;
+            rah = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, sx, 0));
+        }
+        const int f0 = ((dz + 1) * 3 + dy + 1) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int sw = (__builtin_amdgcn_readlane(tab_widx, f0 + d) * K + c0) * C * 4;
+            if (VECB) {
+#pragma unroll
+                for (int j = 0; j < LBV; ++j)
+                    rbv[d * LBV + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, sw + j * (KSBV * 4) * C, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < LB; ++j)
+                    rb[d * LB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff, sw + j * (KSB * 4) * C, 0));
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) As[(ka_l + j * KSA) * AP + 1 + ma_l] = pend_av ? ra[j] : 0.f;
+        if (halo_thread) As[hk * AP] = pend_hv ? rah : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float* bs = Bs + d * (BKT * BN);
+            if (VECB) {
+#pragma unroll
+                for (int j = 0; j < LBV; ++j)
+                    *reinterpret_cast<float4*>(&bs[(kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rbv[d * LBV + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < LB; ++j) bs[(kb_l + j * KSB) * BN + cob_l] = co_ok ? rb[d * LB + j] : 0.f;
+            }
+        }
+    };
+
+    if (tid < BKT) As[tid * AP + BM + 3] = 0.f;          // the zero column
+    if (nrounds > 0) load_round(0);
+    for (int q = 0; q < nrounds; ++q) {
+        stage();
+        __syncthreads();
+        if (q + 1 < nrounds) load_round(q + 1);
+        __builtin_amdgcn_s_setprio(1);
+        {
+            const float* a_own = As + 1 + wm * WM + l31;
+            const float* a_left = can_l[0] ? As + wm * WM + l31 : As + (BM + 3);
+            const float* b0 = Bs + 0 * (BKT * BN) + wco * WCO + l31;
+            const float* b1 = Bs + 1 * (BKT * BN) + wco * WCO + l31;
+            const float* b2 = Bs + 2 * (BKT * BN) + wco * WCO + l31;
+#pragma unroll
+            for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                const int krow = k2 * 2 + hi;
+                const float xo = a_own[krow * AP], xl = a_left[krow * AP];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[krow * BN], xo, acc0, 0, 0, 0);      // dx = -1: source b
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[krow * BN], xo, acc1, 0, 0, 0);      // dx =  0: source b
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b2[krow * BN], xl, acc0, 0, 0, 0);      // dx = +1: source b - 1
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+    // ---- epilogue: rows (registers) = channel, columns (lanes) = grid voxel; two class planes
+    const int m = m0 + wm * WM + l31;
+    if (m < M) {
+        const int n = m / Vq, sp = m - n * Vq;
+        const size_t plane = (size_t)gd.N * C * Vq;
+        float* p0 = gd.y + (size_t)((ct * 2 + cy) * 2 + 0) * plane + (size_t)n * C * Vq + sp;
+        float* p1 = p0 + plane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * WCO + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < C) {
+                p0[(size_t)co * Vq] = acc0[r];
+                p1[(size_t)co * Vq] = acc1[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16-compute variant of the implicit GEMM ("bf16 compute / fp32 master", BASELINE configs 2-4): activations and
 // results stay fp32 in HBM; the tiles are rounded to bf16 on their way into LDS and multiplied by
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate) with fp32 accumulation. Weights come pre-packed as bf16
@@ -2845,6 +3214,180 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// POOLED CONVOLUTION (weight gradient): dW[dz,dy,dx] = sum over the POOLED voxels m' of dL/dy[m'] (x) r~[2 m' + tap + 1] — the
+// 3-tap-row kernel above with a mask-free stride-2 gather from the padded box-summed activation (see conv_pool_fwd_kernel): one
+// 8-byte and one 4-byte load per (voxel, channel) give the three dx operands. Same slab layout as conv_wgrad3_kernel (the
+// reduce kernels do not know the difference), same bias side-sum. Chunks of 32 pooled voxels; members without a time axis
+// (tmode 0) contribute to the dz = 0 rows only.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                              const int Cout, const int chunks_per_split, const LiveRows live,
+                                                              float* __restrict__ bias_slab) {
+    constexpr int PA = WG_BK + 1;
+    __shared__ __attribute__((aligned(16))) float As[64 * PA];          // dL/dy tile [co][m]
+    __shared__ __attribute__((aligned(16))) float Bs[3 * 64 * PA];      // r~ [dx][ci][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int nco_t = (Cout + 63) / 64;
+    const int co0 = (blockIdx.x % nco_t) * 64, ci0 = (blockIdx.x / nco_t) * 64;
+    const int lin = xcd_remap((int)(blockIdx.y + blockIdx.z * gridDim.y), (int)(gridDim.y * gridDim.z));
+    const int rslot = lin % (int)gridDim.y;
+    const int split = lin / (int)gridDim.y;
+    const int krow = live.r[rslot];
+    const int dz = krow / 3 - 1, dy = krow % 3 - 1;
+    const int ml = tid & 31, rl = tid >> 5;
+    const bool full = co0 + 64 <= Cout && ci0 + 64 <= Cin;
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+
+    float ra[8], rb1[8];
+    float2 rb2[8];
+    bool pend_mv = false, pend_vc = false;
+    const bool do_bias = bias_slab != nullptr && ci0 == 0 && rslot == 0;
+    float bsum[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bsum[p] = 0.f;
+
+    int g_i = -1, g_begin = 0, g_end = 0;
+    int g_tm = 0, gHn = 1, gWn = 1, gHWn = 1, gVn = 1, gM = 0, gHp = 1, gWp = 2, gVp = 2;
+    __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_y = g_x;
+    auto enter_group = [&](int q) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        g_i = gi;
+        g_begin = tab.chunk_start[gi];
+        g_end = tab.chunk_start[gi + 1];
+        g_tm = gd.dstride;
+        const int Dn = g_tm ? gd.D / 2 : 1;
+        gHn = gd.H / 2; gWn = gd.W / 2; gHWn = gHn * gWn; gVn = Dn * gHWn;
+        gM = gd.N * gVn;
+        gHp = gd.H + 1; gWp = gd.W + 2;
+        gVp = (g_tm ? gd.D + 1 : 1) * gHp * gWp;
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * gVp) * (uint32_t)Cin * 4u), 0x00020000);
+        g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
+    };
+
+    auto load_chunk = [&](int q) {
+        if (q >= g_end || g_i < 0) enter_group(q);                  // (uniform)
+        const int m = (q - g_begin) * WG_BK + ml;                   // pooled voxel (n, e, i, j)
+        const bool mv = m < gM;
+        const bool small = gM < (1 << 24);
+        const int n = small ? fast_div(m, gVn, 1.0f / (float)gVn) : m / gVn;
+        const int sp = m - n * gVn;
+        const int e = small ? fast_div(sp, gHWn, 1.0f / (float)gHWn) : sp / gHWn;
+        const int r = sp - e * gHWn;
+        const int i = small ? fast_div(r, gWn, 1.0f / (float)gWn) : r / gWn;
+        const int j = r - i * gWn;
+        const bool vc = mv && (g_tm != 0 || dz == 0);               // members without a time axis only have the dz = 0 rows
+        const uint32_t gbase = mv ? (uint32_t)(n * gVn) * (uint32_t)Cout + (uint32_t)sp : 0u;
+        const uint32_t xb = vc ? (uint32_t)(n * gVp) * (uint32_t)Cin +
+                                 (uint32_t)(((g_tm ? 2 * e + dz + 1 : 0) * gHp + 2 * i + dy + 1) * gWp + 2 * j) : 0u;
+        pend_mv = mv;
+        pend_vc = vc;
+        const uint32_t uVp = (uint32_t)gVp, uVn = (uint32_t)gVn;
+        if (full) {
+            const uint32_t oa = (gbase + (uint32_t)(co0 + rl) * uVn) * 4u, ob = (xb + (uint32_t)(ci0 + rl) * uVp) * 4u;
+            const int st = 32 * gVp, sty = 32 * gVn;                // 8 rows, in bytes
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, oa, p * sty, 0));
+                rb2[p] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(g_x, ob, p * st, 0));
+                rb1[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, ob + 8u, p * st, 0));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {                           // clamped rows (zeroed when staged)
+                const int co = co0 + rl + p * 8, ci = ci0 + rl + p * 8;
+                ra[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    g_y, (gbase + (uint32_t)(co < Cout ? co : Cout - 1) * uVn) * 4u, 0, 0));
+                const uint32_t ob = (xb + (uint32_t)(ci < Cin ? ci : Cin - 1) * uVp) * 4u;
+                rb2[p] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(g_x, ob, 0, 0));
+                rb1[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, ob + 8u, 0, 0));
+            }
+        }
+    };
+
+    if (q0 < q1) load_chunk(q0);
+    for (int q = q0; q < q1; ++q) {
+        {
+            if (do_bias) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) bsum[p] += pend_mv ? ra[p] : 0.f;
+            }
+            float* pa = &As[rl * PA + ml];
+            float* pb = &Bs[rl * PA + ml];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float a = pend_mv ? ra[p] : 0.f;
+                float v0 = pend_vc ? rb2[p].x : 0.f, v1 = pend_vc ? rb2[p].y : 0.f, v2 = pend_vc ? rb1[p] : 0.f;
+                if (!full) {
+                    const int row = rl + p * 8;
+                    a = (co0 + row < Cout) ? a : 0.f;
+                    const bool ok = ci0 + row < Cin;
+                    v0 = ok ? v0 : 0.f; v1 = ok ? v1 : 0.f; v2 = ok ? v2 : 0.f;
+                }
+                pa[p * 8 * PA] = a;
+                pb[(0 * 64 + p * 8) * PA] = v0;
+                pb[(1 * 64 + p * 8) * PA] = v1;
+                pb[(2 * 64 + p * 8) * PA] = v2;
+            }
+        }
+        __syncthreads();
+        if (q + 1 < q1) load_chunk(q + 1);
+        const float* qa = &As[(wco * 32 + l31) * PA + hi];
+        const float* qb = &Bs[(wci * 32 + l31) * PA + hi];
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
+            const float a = qa[k2 * 2];
+            const float b0 = qb[0 * 64 * PA + k2 * 2];
+            const float b1 = qb[1 * 64 * PA + k2 * 2];
+            const float b2 = qb[2 * 64 * PA + k2 * 2];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float v = bsum[p];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int co = co0 + rl + p * 8;
+            if (ml == 0 && co < Cout) bias_slab[(size_t)split * Cout + co] = v;
+        }
+    }
+    const int ci = ci0 + wci * 32 + l31;
+    if (ci < Cin) {
+        const size_t CoCi = (size_t)Cout * Cin;
+        float* ps = slab + ((size_t)split * (live.n * 3) + (size_t)rslot * 3) * CoCi + ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (co < Cout) {
+                ps[(size_t)co * Cin] = acc0[r];
+                ps[CoCi + (size_t)co * Cin] = acc1[r];
+                ps[2 * CoCi + (size_t)co * Cin] = acc2[r];
+            }
+        }
+    }
+}
+
+
 // one workgroup's share of  dbias[co] = (accum ? dbias[co] : 0) + sum_s bias_slab[s][co]  (fixed order); called by ONE
 // workgroup of the weight-gradient reduce kernels so that the bias needs no launch of its own
 __device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bias_slab, float* __restrict__ dbias, int S, int Cout,
@@ -3193,6 +3736,280 @@ extern "C" int t2v_conv_wgrad_grouped_partial(const t2v_conv_group* groups, int 
     float dummy;                                                    // (non-null marker: the bias side-sums are wanted)
     return wgrad_impl(groups, ngroups, Cin, Cout, kD, kH, kW, nullptr, want_bias ? &dummy : nullptr, slab, flags, stream, out_src);
 }
+// ------------------------------------------------------------------------------------------------
+// Pooled convolution: host side (kernels: conv_pool_fwd_kernel, conv_pool_dgrad_kernel, conv_pool_wgrad_kernel; the
+// pointwise halves t2v_pool_boxsum / t2v_pool_unbox live in pointwise.hip).
+// ------------------------------------------------------------------------------------------------
+struct PoolPlan { int S; long tiles; bool vecb; };
+static bool pool_member_ok(const t2v_conv_group& g, bool need_ptrs) {
+    if (need_ptrs && (!g.x || !g.y)) return false;
+    if (g.N < 1 || g.H < 2 || g.W < 2 || (g.H & 1) || (g.W & 1)) return false;
+    if (g.dstride == 0) return g.D == 1;
+    if (g.dstride != 1 && g.dstride != 2) return false;
+    return g.D >= 2 && !(g.D & 1);
+}
+static inline long pool_rows(const t2v_conv_group& g) { return (long)g.N * (g.dstride ? g.D / 2 : 1) * (g.H / 2) * (g.W / 2); }
+static inline long pool_padded(const t2v_conv_group& g) { return (long)(g.dstride ? g.D + 1 : 1) * (g.H + 1) * (g.W + 2); }
+static inline long pool_grid(const t2v_conv_group& g) { return (long)(g.dstride ? g.D / 2 + 1 : 1) * (g.H / 2 + 1) * (g.W / 2 + 1); }
+
+// forward: rows = pooled voxels, 64-voxel x 64-channel tiles, rounds of (kernel row, 32 channels)
+static bool build_pool_fwd(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, bool need_ptrs, GroupTable& tab, PoolPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 32 || (Cin % 32) || Cout < 4 || (Cout % 4)) return false;
+    long mt = 0, ot = 0;
+    int max_rows = 1;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        const t2v_conv_group& g = groups[i];
+        if (!pool_member_ok(g, need_ptrs)) return false;
+        if ((long)g.N * pool_padded(g) * Cin >= (1L << 29) || pool_rows(g) * Cout >= (1L << 31)) return false;     // 32-bit byte offsets
+        if (g.ntaps != 9 && g.ntaps != 27) return false;
+        if (g.dstride == 0 && g.ntaps != 9) return false;
+        for (int r = 0; r < g.ntaps / 3; ++r)
+            for (int d = 0; d < 3; ++d) {
+                const int t = r * 3 + d;
+                if (g.dx[t] != d - 1 || g.dz[t] != g.dz[r * 3] || g.dy[t] != g.dy[r * 3] || g.dz[t] < -1 || g.dz[t] > 1 || g.dy[t] < -1 ||
+                    g.dy[t] > 1 || g.widx[t] < 0 || g.widx[t] >= T2V_MAX_TAPS)
+                    return false;
+                if (g.dstride == 0 && g.dz[t] != 0) return false;
+            }
+        if (g.ntaps / 3 > max_rows) max_rows = g.ntaps / 3;
+        tab.g[i] = g;
+        tab.tile_start[i] = (int32_t)mt;
+        tab.out_start[i] = ot;
+        mt += (pool_rows(g) + 63) / 64;
+        ot += pool_rows(g) * Cout;
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) { tab.tile_start[i] = (int32_t)mt; tab.out_start[i] = ot; }
+    p.tiles = mt * ((Cout + 63) / 64);
+    p.vecb = (Cout % 4) == 0;
+    const long rounds = (long)max_rows * (Cin / 32);
+    long S = 1;
+    if (p.tiles < 384 && rounds > tun().nosplit_chunks) {          // same rule as build_table: fill ~768 workgroup slots
+        S = (768 + p.tiles - 1) / p.tiles;
+        if (S > rounds / 2) S = rounds / 2;
+        if (S > 64) S = 64;
+        while (S > 1 && (double)S * ot * 4.0 > 256e6) --S;
+        if (S < 1) S = 1;
+    }
+    p.S = (int)S;
+    return true;
+}
+extern "C" int64_t t2v_pool_conv_fwd_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout) {
+    GroupTable tab;
+    PoolPlan p;
+    if (!build_pool_fwd(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    return p.S > 1 ? (int64_t)p.S * tab.out_start[ngroups] : 0;
+}
+extern "C" int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp, const float* bias,
+                                 float* ws, int flags, void* stream) {
+    GroupTable tab;
+    PoolPlan p;
+    if (!wp || !build_pool_fwd(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
+    if (flags & ~(T2V_CONV_BIAS | T2V_CONV_ACCUM)) return T2V_EINVAL;
+    if (p.S > 1 && !ws) return T2V_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    long Mtot = 0;
+    int taps = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        flops += 2.0 * (double)pool_rows(groups[i]) * Cout * Cin * groups[i].ntaps;
+        Mtot += pool_rows(groups[i]);
+        if (groups[i].ntaps > taps) taps = groups[i].ntaps;
+    }
+    {
+        ProfScope prof(0, flops, s, Mtot, Cin, Cout, taps, ngroups, p.S);
+        int32_t plan_[8] = {9, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
+        ProfScope::set_plan(plan_, 8);
+        dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
+        T2V_LAUNCH_PROF(conv_pool_fwd_kernel<64>, grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
+    }
+    int st = launch_status();
+    if (st) return st;
+    if (p.S > 1) {
+        for (int i = 0; i < ngroups; ++i) {                          // the reduce decodes the bias channel from the OUTPUT extents
+            tab.g[i].D = groups[i].dstride ? groups[i].D / 2 : 1;
+            tab.g[i].H = groups[i].H / 2;
+            tab.g[i].W = groups[i].W / 2;
+        }
+        long blocks = (tab.out_start[ngroups] + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        ProfScope prof_r(4, 0.0, s, Mtot, Cin, Cout, taps, ngroups, p.S);
+        T2V_LAUNCH_PROF(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab, ws, bias, p.S, Cout, flags);
+    }
+    return launch_status();
+}
+
+// data gradient: rows = voxels of the padded grid, one (ct, cy) class pair per workgroup (blockIdx.y & 3)
+static bool build_pool_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, bool need_ptrs, GroupTable& tab, PoolPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || K < 32 || (K % 32) || C < 4 || (C % 4)) return false;
+    long mt = 0;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        const t2v_conv_group& g = groups[i];
+        if (!pool_member_ok(g, need_ptrs)) return false;
+        if (pool_rows(g) * K >= (1L << 29) || (long)g.N * pool_grid(g) * C * 8 >= (1L << 31)) return false;
+        for (int f = 0; f < 27; ++f) {
+            const bool live = g.dstride != 0 || (f / 9) == 1;
+            if (live && (g.widx[f] < 0 || g.widx[f] >= T2V_MAX_TAPS)) return false;
+        }
+        tab.g[i] = g;
+        tab.tile_start[i] = (int32_t)mt;
+        tab.out_start[i] = 0;
+        mt += ((long)g.N * pool_grid(g) + 63) / 64;
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) { tab.tile_start[i] = (int32_t)mt; tab.out_start[i] = 0; }
+    p.tiles = mt * 4 * ((C + 63) / 64);
+    p.vecb = (C % 4) == 0;
+    p.S = 1;
+    return true;
+}
+extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, const float* wp, void* stream) {
+    GroupTable tab;
+    PoolPlan p;
+    if (!wp || !build_pool_dgrad(groups, ngroups, K, C, true, tab, p)) return T2V_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    long Mtot = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        flops += 2.0 * (double)pool_rows(groups[i]) * K * C * (groups[i].dstride ? 27 : 9);
+        Mtot += (long)groups[i].N * pool_grid(groups[i]);
+    }
+    ProfScope prof(0, flops, s, Mtot, K, C, 27, ngroups, 1);
+    int32_t plan_[8] = {10, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, 1};
+    ProfScope::set_plan(plan_, 8);
+    dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)(4 * ((C + 63) / 64)), 1u);
+    T2V_LAUNCH_PROF(conv_pool_dgrad_kernel, grid, dim3(256), 0, s, tab, wp, K, C);
+    return launch_status();
+}
+
+// weight gradient: chunks of 32 pooled voxels, one kernel row (dz, dy) per workgroup, k-split like build_wtable
+static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, bool need_ptrs, WGroupTable& tab, WgradPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
+    long nch = 0;
+    bool any_t = false;
+    tab.n = ngroups;
+    for (int i = 0; i < ngroups; ++i) {
+        const t2v_conv_group& g = groups[i];
+        if (!pool_member_ok(g, need_ptrs)) return false;
+        if ((long)g.N * pool_padded(g) * Cin >= (1L << 29) || pool_rows(g) * Cout >= (1L << 29)) return false;
+        any_t = any_t || g.dstride != 0;
+        tab.g[i] = g;
+        tab.chunk_start[i] = (int32_t)nch;
+        nch += (pool_rows(g) + WG_BK - 1) / WG_BK;
+    }
+    for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.chunk_start[i] = (int32_t)nch;
+    p.nchunks = nch;
+    p.rows3 = true;
+    p.strided = false;
+    p.liverows = any_t ? 0x1ffu : 0x038u;            // kernel rows (dz, dy): all nine, or the dz = 0 ones
+    p.nrows = any_t ? 9 : 3;
+    p.live = any_t ? 0x7ffffffu : (0x1ffu << 9);
+    p.nlive = p.nrows * 3;
+    const long base = (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows;
+    const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
+    const long wg_target = wg_env ? wg_env : 1024;
+    long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;
+    long maxS = (nch + 7) / 8;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    if (S > s_cap) S = s_cap;
+    const long rounds = (base * S) / 1024, tail = (base * S) % 1024;
+    if (tun().wgrad_quantise && rounds >= 1 && tail > 0 && tail * 5 <= 1024 && (rounds * 1024) / base >= 1) S = (rounds * 1024) / base;
+    p.cps = (int)((nch + S - 1) / S);
+    p.S = (int)((nch + p.cps - 1) / p.cps);
+    return true;
+}
+extern "C" int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int want_bias) {
+    WGroupTable tab;
+    WgradPlan p;
+    if (!build_pool_wtable(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    return (int64_t)p.S * p.nlive * Cout * Cin + (want_bias ? (int64_t)p.S * Cout : 0);
+}
+static int pool_wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, bool want_bias,
+                           float* slab, int flags, void* stream, t2v_wgrad_src* out_src) {
+    WGroupTable tab;
+    WgradPlan p;
+    if ((!dw && !out_src) || !slab || !build_pool_wtable(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;
+    const int T = 27;
+    TapMap map;
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) map.j[t] = -1;
+    LiveRows lrows;
+    lrows.n = 0;
+    for (int r = 0; r < 9; ++r) lrows.r[r] = 0;
+    for (int r = 0; r < 9; ++r)
+        if ((p.liverows >> r) & 1u) {
+            for (int c = 0; c < 3; ++c) map.j[r * 3 + c] = lrows.n * 3 + c;
+            lrows.r[lrows.n++] = (int8_t)r;
+        }
+    double flops = 0;
+    for (int i = 0; i < ngroups; ++i) flops += 2.0 * (double)pool_rows(groups[i]) * Cout * Cin * (groups[i].dstride ? 27 : 9);
+    {
+        ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, p.nlive, ngroups, p.S);
+        int32_t plan_[8] = {11, p.S, p.cps, p.nlive, ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0,
+                            (int32_t)((long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows * p.S), 0, 0};
+        ProfScope::set_plan(plan_, 8);
+        dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
+        T2V_LAUNCH_PROF(conv_pool_wgrad_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, p.cps, lrows, want_bias ? bias_part : (float*)nullptr);
+    }
+    int st = launch_status();
+    if (st) return st;
+    if (out_src) {
+        out_src->slab = slab;
+        out_src->bias_slab = want_bias ? bias_part : (const float*)nullptr;
+        out_src->ntaps = p.nlive;
+        out_src->S = p.S;
+        out_src->tap_stride = (int64_t)Cout * Cin;
+        out_src->split_stride = (int64_t)p.nlive * Cout * Cin;
+        for (int t = 0; t < T2V_MAX_TAPS; ++t) out_src->map[t] = (int8_t)(t < T ? map.j[t] : -1);
+        return T2V_OK;
+    }
+    const float* bias_in = want_bias ? bias_part : (const float*)nullptr;
+    const int accum_bias = (flags & T2V_CONV_ACCUM_BIAS) ? 1 : 0;
+    const long CoCi = (long)Cout * Cin;
+    ProfScope prof2(2, 0.0, s, CoCi, Cin, Cout, T, p.nlive, p.S);
+    if (CoCi <= 16384 && p.S >= 16)
+        T2V_LAUNCH_PROF(wgrad_reduce_small_kernel, dim3((unsigned)((CoCi + 63) / 64), (unsigned)T), dim3(256), 0, s, slab, dw, CoCi, T,
+                   p.nlive, p.S, map, (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
+    else
+        T2V_LAUNCH_PROF(wgrad_reduce_kernel, dim3((unsigned)((CoCi + 63) / 64)), dim3(256), 0, s, slab, dw, CoCi, T, p.nlive, p.S, map,
+                   (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
+    return launch_status();
+}
+extern "C" int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, float* slab,
+                                   int flags, void* stream) {
+    if (!dw) return T2V_EINVAL;
+    return pool_wgrad_impl(groups, ngroups, Cin, Cout, dw, dbias, dbias != nullptr, slab, flags, stream, nullptr);
+}
+extern "C" int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* slab, int want_bias,
+                                           int flags, t2v_wgrad_src* out_src, void* stream) {
+    if (!out_src) return T2V_EINVAL;
+    return pool_wgrad_impl(groups, ngroups, Cin, Cout, nullptr, nullptr, want_bias != 0, slab, flags, stream, out_src);
+}
+// what: 0 forward, 1 data gradient (Cin = K of dL/dy, Cout = channels of the planes), 2 weight gradient
+extern "C" int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int32_t* out) {
+    if (!out) return T2V_EINVAL;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (what == 0 || what == 1) {
+        GroupTable tab;
+        PoolPlan p;
+        if (!(what == 0 ? build_pool_fwd(groups, ngroups, Cin, Cout, false, tab, p) : build_pool_dgrad(groups, ngroups, Cin, Cout, false, tab, p)))
+            return T2V_EINVAL;
+        out[0] = what == 0 ? 9 : 10; out[1] = 64; out[2] = 64; out[3] = 32; out[4] = 1; out[5] = p.vecb ? 1 : 0; out[6] = 1; out[7] = p.S;
+        return T2V_OK;
+    }
+    if (what == 2) {
+        WGroupTable tab;
+        WgradPlan p;
+        if (!build_pool_wtable(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+        out[0] = 11; out[1] = p.S; out[2] = p.cps; out[3] = p.nlive; out[4] = ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0;
+        out[5] = (int32_t)((long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows * p.S);
+        return T2V_OK;
+    }
+    return T2V_EINVAL;
+}
+
 extern "C" int t2v_wgrad_dest_bytes(void) { return (int)sizeof(t2v_wgrad_dest); }
 
 

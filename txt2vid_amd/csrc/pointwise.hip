@@ -2378,3 +2378,127 @@ extern "C" int t2v_gather_rows(const float* x, const int32_t* perm, float* out, 
 }
 
 extern "C" const char* t2v_version(void) { return "t2v_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+// ------------------------------------------------------------------------------------------------
+// Pooled convolution, pointwise halves (DESIGN §5 "pooled second convolution"). In every discriminator block the second 3^3
+// convolution is consumed only by the average pooling behind it. Box filter and convolution commute, so
+//     pool(conv3(r)) = stride-2 conv3 of the BOX-SUMMED activation  r~[p] = scale * sum_{delta in {0,1}^k} r[p - 1 + delta]
+// — 27 taps over the POOLED voxels instead of 27 taps over all of them (4x fewer MACs for the stem's (1,2,2) pooling, 8x for
+// the DownBlocks' (2,2,2)), at the price of one streaming pass that writes r~. r~ lives on a PADDED grid (index p = position + 1,
+// one extra row / column / frame of real border sums), so the strided GEMM kernels in conv.hip gather it without a single bounds
+// check. t2v_pool_boxsum writes r~; t2v_pool_unbox is its adjoint applied to the data gradient the GEMM leaves on the padded grid
+// (as 8 parity-class planes), with the ReLU mask of the activation fused in.
+//   tmode 0: no time axis (D == 1); 1: time is box-summed and strided like H and W; 2: time is strided WITHOUT a box (the stem:
+//   AvgPool3d((1,2,2), stride 2) keeps the even frames)
+// Layouts: r~ [NC, Dp, H+1, W+2] (Dp = D+1, or 1 for tmode 0; the last column is an alignment pad, written as 0);
+//          planes [8][NC, Dq, H/2+1, W/2+1] (Dq = D/2+1, or 1), class = (ct*2 + cy)*2 + cx = parity of the padded index per axis.
+// ------------------------------------------------------------------------------------------------
+struct PoolBoxBatch { t2v_poolbox_job j[POOL_MT]; int begin[POOL_MT + 1]; int n; };
+
+__global__ __launch_bounds__(256) void pool_boxsum_k(const PoolBoxBatch tb) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < POOL_MT; ++k)
+        if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
+    const t2v_poolbox_job& q = tb.j[ji];
+    const int D = q.D, H = q.H, W = q.W, tm = q.tmode;
+    const int Dp = tm ? D + 1 : 1, Hp = H + 1, Wp = W + 2;
+    const long n = (long)q.NC * Dp * Hp * Wp;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const float* __restrict__ x = q.in;
+    const float* __restrict__ mk = q.mask;
+    const float floor_ = q.relu ? 0.f : -__builtin_inff();
+    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
+        const int xp = (int)(i % Wp); long r = i / Wp;
+        const int yp = (int)(r % Hp); r /= Hp;
+        const int fp = (int)(r % Dp); const long nc = r / Dp;
+        float acc = 0.f;
+        if (xp <= W) {
+            const int f0 = tm == 0 ? 0 : fp - 1, nf = tm == 1 ? 2 : 1;
+            for (int a = 0; a < nf; ++a) {
+                const int f = f0 + a;
+                if ((unsigned)f >= (unsigned)D) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int y = yp - 1 + b;
+                    if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int xx = xp - 1 + c;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const long o = ((nc * D + f) * H + y) * (long)W + xx;
+                        float v = x[o];
+                        if (mk) v = mk[o] > 0.f ? v : 0.f;
+                        acc += fmaxf(v, floor_);
+                    }
+                }
+            }
+        }
+        q.out[i] = acc * q.scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_unbox_k(const PoolBoxBatch tb) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < POOL_MT; ++k)
+        if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
+    const t2v_poolbox_job& q = tb.j[ji];
+    const int D = q.D, H = q.H, W = q.W, tm = q.tmode;
+    const int Dq = tm ? D / 2 + 1 : 1, Hq = H / 2 + 1, Wq = W / 2 + 1;
+    const long n = (long)q.NC * D * H * W;
+    const long plane = (long)q.NC * Dq * Hq * Wq;
+    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const float* __restrict__ pl = q.in;
+    const float* __restrict__ mk = q.mask;
+    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
+        const int xx = (int)(i % W); long r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int f = (int)(r % D); const long nc = r / D;
+        float acc = 0.f;
+        const int nf = tm == 1 ? 2 : 1;
+        for (int a = 0; a < nf; ++a) {
+            const int pt = tm == 0 ? 0 : f + 1 - a;            // padded time index of r~ this voxel contributed to
+            const int ct = pt & 1, at = pt >> 1;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int py = y + 1 - b, cy = py & 1, ay = py >> 1;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int px = xx + 1 - c, cx = px & 1, ax = px >> 1;
+                    acc += pl[(long)((ct * 2 + cy) * 2 + cx) * plane + ((nc * Dq + at) * Hq + ay) * (long)Wq + ax];
+                }
+            }
+        }
+        const bool keep = mk ? mk[i] > 0.f : true;
+        q.out[i] = keep ? acc * q.scale : 0.f;
+    }
+}
+
+static int poolbox_multi(const t2v_poolbox_job* jobs, int njobs, bool unbox, void* st) {
+    if (!jobs || njobs < 1) return T2V_EINVAL;
+    for (int at = 0; at < njobs; at += POOL_MT) {
+        PoolBoxBatch tb;
+        const int cnt = njobs - at < POOL_MT ? njobs - at : POOL_MT;
+        long blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const t2v_poolbox_job& q = jobs[at + i];
+            if (!q.in || !q.out || q.NC < 1 || q.D < 1 || q.H < 2 || q.W < 2 || (q.H & 1) || (q.W & 1) || q.tmode < 0 || q.tmode > 2) return T2V_EINVAL;
+            if ((q.tmode == 0 && q.D != 1) || (q.tmode != 0 && (q.D < 2 || (q.D & 1)))) return T2V_EINVAL;
+            tb.j[i] = q;
+            tb.begin[i] = (int)blocks;
+            const long n = unbox ? (long)q.NC * q.D * q.H * q.W
+                                 : (long)q.NC * (q.tmode ? q.D + 1 : 1) * (q.H + 1) * (q.W + 2);
+            blocks += (n + POOL_CHUNK - 1) / POOL_CHUNK;
+        }
+        for (int i = cnt; i <= POOL_MT; ++i) tb.begin[i] = (int)blocks;
+        for (int i = cnt; i < POOL_MT; ++i) tb.j[i] = tb.j[0];
+        tb.n = cnt;
+        if (blocks > 0x7fffffffL) return T2V_EINVAL;
+        if (unbox) T2V_LAUNCH(pool_unbox_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb);
+        else T2V_LAUNCH(pool_boxsum_k, dim3((unsigned)blocks), dim3(256), 0, S_(st), tb);
+    }
+    return launch_status();
+}
+extern "C" int t2v_pool_boxsum(const t2v_poolbox_job* jobs, int njobs, void* st) { return poolbox_multi(jobs, njobs, false, st); }
+extern "C" int t2v_pool_unbox(const t2v_poolbox_job* jobs, int njobs, void* st) { return poolbox_multi(jobs, njobs, true, st); }

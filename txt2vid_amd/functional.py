@@ -3112,6 +3112,16 @@ def _pass_none_through(cls):
     return cls
 
 
+# the pooled second convolution of the discriminator blocks (box-sum + stride-2 GEMMs): functional_pool.py
+from .functional_pool import (pool_conv_ok, pool_conv_group, pool_tmode, PoolConvG, PoolConvDgradG, PoolConvWgradG, boxsum_raw, unbox_raw,     # noqa: E402,F401
+                              pool_fwd_raw, pool_dgrad_raw, pool_wgrad_raw)
+
+
+def add_group(as_, bs):
+    """[a + b for a, b in zip(as_, bs)] in one launch (`AddG`)."""
+    return list(AddG.apply(*(list(as_) + list(bs))))
+
+
 for _cls in (Conv, ConvDgrad, ConvWgrad, ReluConv, ReluConvWgrad, Relu, ReluMask, Add, AvgPool3d, AddAvgPool3d, AvgPool3dBwd, MaxPool2x2,
              MaxScatter, MaxGather, RowSum, RowBcast, Bmm, Softmax, SoftmaxBwd, Dot, ScaleDev, CatFeatures, SliceCols,
              EmbedCols, CatBatch, ConvWgradG):

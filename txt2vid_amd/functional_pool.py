@@ -1,0 +1,347 @@
+"""Pooled convolution: the second 3^3 convolution of a discriminator block TOGETHER with the average pooling that is its only
+consumer (txt2vid/models/resnet3d.py:12-19 stem: `conv -> AvgPool3d((1,2,2), 2)`; txt2vid/models/layers.py:219-243 DownBlock:
+`conv -> DownSample`). Box filter and convolution commute, so
+
+    pool(conv3(relu(r))) = stride-2 conv3 of r~,   r~[p] = scale * sum_{delta in {0,1}^k} relu(r)[p - 1 + delta]
+
+— 27 taps over the POOLED voxels instead of 27 taps over all of them: 4x fewer MACs behind the stem's (1,2,2) pooling (which
+also keeps the even frames only), 8x behind a (2,2,2) DownSample; identical values up to fp32 summation order. The three GEMMs
+(forward, data gradient, weight gradient: `t2v_pool_conv_*`, conv.hip) and the two streaming passes (`t2v_pool_boxsum`,
+`t2v_pool_unbox`, pointwise.hip) form a triple closed under differentiation like conv / dgrad / wgrad, so the gradient
+penalty's recorded sweep and its second backward stay on these kernels. Part of the autograd surface `txt2vid_amd.functional`
+(re-exported there)."""
+import ctypes as C
+import os
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import lib, check, ConvGroup, PoolBoxJob, WgradSrc, MAX_GROUPS
+from ._ops import _stream, _p, _c
+
+_DISABLED = os.environ.get('T2V_NO_POOLCONV') is not None        # developer A/B switch: the un-pooled path everywhere
+
+
+def _TF():
+    from . import functional
+    return functional
+
+
+def pool_tmode(shape, stem):
+    """How the time axis of a [N,C,D,H,W] member is treated, or None when the pooled form does not apply to it:
+    0 no time axis (D == 1), 1 box + stride 2 (DownSample), 2 stride 2 without a box (the stem's pooling keeps the even frames)."""
+    D, H, W = shape[2], shape[3], shape[4]
+    if H < 2 or W < 2 or H % 2 or W % 2:
+        return None
+    if D == 1:
+        return 0
+    if D % 2:
+        return None
+    return 2 if stem else 1
+
+
+def pool_scale(tmode):
+    return 0.125 if tmode == 1 else 0.25
+
+
+def pool_conv_ok(xs, w, stem):
+    """True when `pool_conv_group` takes these members: 3x3x3 kernel, channels a multiple of 32, even H / W >= 2, D == 1 or even,
+    fp32 mode (the bf16-compute kernels have no strided form)."""
+    TF = _TF()
+    if _DISABLED or TF.CONV_PRECISION != 'fp32' or not (1 <= len(xs) <= MAX_GROUPS) or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        return False
+    if w.shape[0] % 32 or w.shape[1] % 32 or not xs[0].is_cuda:      # (both: the data gradient contracts over Cout)
+        return False
+    return all(x.dim() == 5 and pool_tmode(x.shape, stem) is not None for x in xs)
+
+
+def pooled_shape(shape, tmode):
+    N, _, D, H, W = shape
+    return (N, D // 2 if tmode else 1, H // 2, W // 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+# ------------------------------------------------------------------------------------------------
+
+def _box_jobs(ins, masks, outs, shapes, tmodes, relu):
+    arr = (PoolBoxJob * len(ins))()
+    for a, t, sh, tm, i in zip(arr, ins, shapes, tmodes, range(len(ins))):
+        a.in_, a.out = t.data_ptr(), outs[i].data_ptr()
+        a.mask = masks[i].data_ptr() if masks is not None else None
+        a.NC, a.D, a.H, a.W = sh[0] * sh[1], sh[2], sh[3], sh[4]
+        a.tmode, a.relu, a.scale = tm, 1 if relu else 0, pool_scale(tm)
+    return arr
+
+
+def boxsum_raw(ins, tmodes, relu, masks=None):
+    """r~ of every member (padded grid [N,C,Dp,H+1,W+2]); `masks`: the inputs are cotangents, multiplied by [mask > 0] first."""
+    ins = [_c(t) for t in ins]
+    masks = [_c(m) for m in masks] if masks is not None else None
+    shapes = [tuple(t.shape) for t in ins]
+    outs = [torch.empty((sh[0], sh[1], sh[2] + 1 if tm else 1, sh[3] + 1, sh[4] + 2), device=t.device, dtype=torch.float32)
+            for t, sh, tm in zip(ins, shapes, tmodes)]
+    check(lib().t2v_pool_boxsum(_box_jobs(ins, masks, outs, shapes, tmodes, relu), len(ins), _stream()), 't2v_pool_boxsum')
+    return outs
+
+
+def unbox_raw(planes, shapes, tmodes, masks=None):
+    """The adjoint of `boxsum_raw` applied to the 8 class planes of each member; `masks`: result zeroed where mask <= 0."""
+    masks = [_c(m) for m in masks] if masks is not None else None
+    outs = [torch.empty(tuple(sh), device=p.device, dtype=torch.float32) for p, sh in zip(planes, shapes)]
+    check(lib().t2v_pool_unbox(_box_jobs(planes, masks, outs, shapes, tmodes, False), len(planes), _stream()), 't2v_pool_unbox')
+    return outs
+
+
+def _tap_union(tmodes):
+    TF = _TF()
+    mask = (1 << 27) - 1 if any(tmodes) else 0x1ff << 9            # all taps, or the dz = 0 plane
+    return TF._tapset(27, mask)
+
+
+def _fwd_table(xs, ys, shapes, tmodes, ts):
+    slot_of = {t: j for j, t in enumerate(ts.taps)}
+    arr = (ConvGroup * len(xs))()
+    for a, x, y, sh, tm in zip(arr, xs, ys, shapes, tmodes):
+        a.x, a.y, a.mask = x.data_ptr(), (y.data_ptr() if y is not None else 0), None
+        a.N, a.D, a.H, a.W = sh[0], sh[2], sh[3], sh[4]
+        a.dstride = tm
+        j = 0
+        for dz in ((-1, 0, 1) if tm else (0,)):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    a.dz[j], a.dy[j], a.dx[j] = dz, dy, dx
+                    a.widx[j] = slot_of[((dz + 1) * 3 + dy + 1) * 3 + dx + 1]
+                    j += 1
+        a.ntaps = j
+    return arr
+
+
+def pool_fwd_raw(rts, shapes, tmodes, w5, bias=None):
+    """zs[i] = stride-2 conv3 of the padded box sums rts[i] (+ bias): [N, Cout, D', H', W']. `shapes`: the full-resolution
+    [N,C,D,H,W] of each member."""
+    TF = _TF()
+    w5 = _c(w5)
+    cout, cin = w5.shape[0], w5.shape[1]
+    ts = _tap_union(tmodes)
+    zs = []
+    for sh, tm, t in zip(shapes, tmodes, rts):
+        n, d, h, w_ = pooled_shape(sh, tm)
+        zs.append(torch.empty((n, cout, d, h, w_), device=t.device, dtype=torch.float32))
+    arr = _fwd_table(rts, zs, shapes, tmodes, ts)
+    nws = int(lib().t2v_pool_conv_fwd_ws_floats(arr, len(rts), cin, cout))
+    if nws < 0:
+        raise RuntimeError('bad pooled-convolution geometry')
+    ws = torch.empty((nws,), device=rts[0].device, dtype=torch.float32) if nws > 0 else None
+    wp = TF.packed_weight(w5, ts, 0)
+    check(lib().t2v_pool_conv_fwd(arr, len(rts), cin, cout, _p(wp), _p(bias), _p(ws), TF.FLAG_BIAS if bias is not None else 0, _stream()),
+          't2v_pool_conv_fwd')
+    return zs
+
+
+def pool_dgrad_raw(gzs, shapes, tmodes, w5):
+    """The 8 parity-class planes [8, N, Cin, Dq, H/2+1, W/2+1] of the data gradient on the padded grid, from dL/dy (pooled shape)."""
+    TF = _TF()
+    gzs = [_c(g) for g in gzs]
+    w5 = _c(w5)
+    cout, cin = w5.shape[0], w5.shape[1]
+    ts = _tap_union(tmodes)
+    slot_of = {t: j for j, t in enumerate(ts.taps)}
+    planes = [torch.empty((8, sh[0], cin, sh[2] // 2 + 1 if tm else 1, sh[3] // 2 + 1, sh[4] // 2 + 1), device=g.device, dtype=torch.float32)
+              for g, sh, tm in zip(gzs, shapes, tmodes)]
+    arr = (ConvGroup * len(gzs))()
+    for a, g, pl, sh, tm in zip(arr, gzs, planes, shapes, tmodes):
+        if tuple(g.shape) != (sh[0], cout) + pooled_shape(sh, tm)[1:]:
+            raise ValueError('pooled gradient of shape %s for a member of shape %s' % (tuple(g.shape), tuple(sh)))
+        a.x, a.y, a.mask = g.data_ptr(), pl.data_ptr(), None
+        a.N, a.D, a.H, a.W = sh[0], sh[2], sh[3], sh[4]
+        a.dstride, a.ntaps = tm, 27
+        for f in range(27):
+            a.widx[f] = slot_of.get(26 - f, -1)                   # mode-1 packing stores forward tap f in the slot of its mirror
+    wp = TF.packed_weight(w5, ts, 1)
+    check(lib().t2v_pool_conv_dgrad(arr, len(gzs), cout, cin, _p(wp), _stream()), 't2v_pool_conv_dgrad')
+    return planes
+
+
+def _wgrad_table(rts, gzs, shapes, tmodes):
+    arr = (ConvGroup * len(rts))()
+    for a, x, g, sh, tm in zip(arr, rts, gzs, shapes, tmodes):
+        a.x, a.y, a.mask = x.data_ptr(), g.data_ptr(), None
+        a.N, a.D, a.H, a.W = sh[0], sh[2], sh[3], sh[4]
+        a.dstride, a.ntaps = tm, 27 if tm else 9
+    return arr
+
+
+def pool_wgrad_raw(rts, gzs, shapes, tmodes, wshape, out=None, accum=False, dbias=None, accum_bias=False):
+    """dW (and the bias gradient when `dbias` is given) summed over the members, reduce pass included."""
+    TF = _TF()
+    gzs = [_c(g) for g in gzs]
+    cout, cin = wshape[0], wshape[1]
+    arr = _wgrad_table(rts, gzs, shapes, tmodes)
+    n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, 1 if dbias is not None else 0))
+    if n <= 0:
+        raise RuntimeError('bad pooled weight-gradient geometry')
+    slab = torch.empty((n,), device=rts[0].device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty(tuple(wshape), device=rts[0].device, dtype=torch.float32)
+    flags = (TF.FLAG_ACCUM if accum else 0) | (TF.FLAG_ACCUM_BIAS if accum_bias else 0)
+    check(lib().t2v_pool_conv_wgrad(arr, len(rts), cin, cout, _p(dw), _p(dbias), _p(slab), flags, _stream()), 't2v_pool_conv_wgrad')
+    return dw
+
+
+def _pool_wgrad_to_sink(w, b, rts, gzs, shapes, tmodes, need_b):
+    """Weight (and bias) gradient into the gradient sink's slots, deferred like `functional.conv_group_wgrad_partial` when the sink
+    batches its reductions. Returns (handled, gw, gb)."""
+    TF = _TF()
+    sink = TF._grad_sink
+    if sink is None or torch.is_grad_enabled():
+        return False, None, None
+    wbase = w._base if w._base is not None else w
+    if id(wbase) not in sink.slots or (need_b and id(b) not in sink.slots):
+        return False, None, None
+    gzs = [_c(g) for g in gzs]
+    cout, cin = w.shape[0], w.shape[1]
+    wflat, wacc = sink.take(wbase, sink.defer)
+    bflat, bacc = sink.take(b, sink.defer) if need_b else (None, False)
+    if sink.defer:
+        arr = _wgrad_table(rts, gzs, shapes, tmodes)
+        n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, 1 if need_b else 0))
+        if n <= 0:
+            raise RuntimeError('bad pooled weight-gradient geometry')
+        slab = sink.alloc_slab(n, rts[0].device)
+        src = WgradSrc()
+        check(lib().t2v_pool_conv_wgrad_partial(arr, len(rts), cin, cout, _p(slab), 1 if need_b else 0, 0, C.byref(src), _stream()),
+              't2v_pool_conv_wgrad_partial')
+        sink.add_partial(wbase, wflat.view(w.shape), wacc, b if need_b else None, bflat, bacc, src, slab, 27, cout, cout * cin)
+    else:
+        pool_wgrad_raw(rts, gzs, shapes, tmodes, tuple(w.shape), out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
+    return True, (None if wacc else wflat.view(w.shape)), ((None if bacc else bflat.view(b.shape)) if need_b else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd surface
+# ------------------------------------------------------------------------------------------------
+
+class PoolConvG(Function):
+    """ys[i] = pool_i(conv3(relu?(xs[i]), w)) + b, computed as the stride-2 convolution of the box-summed activation.
+    args: w, b, relu_in, tmodes (tuple), then the members. Members that receive no gradient cost nothing in the backward."""
+
+    @staticmethod
+    def forward(ctx, w, b, relu_in, tmodes, *xs):
+        xs = [_c(x) for x in xs]
+        shapes = [tuple(x.shape) for x in xs]
+        rts = boxsum_raw(xs, tmodes, relu_in)
+        ctx.save_for_backward(w, *xs, *rts)
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (relu_in, tuple(tmodes), shapes, b)
+        return tuple(pool_fwd_raw(rts, shapes, tmodes, w, b))
+
+    @staticmethod
+    def backward(ctx, *gzs):
+        TF = _TF()
+        relu_in, tmodes, shapes, b = ctx.cfg
+        saved = ctx.saved_tensors
+        n = len(shapes)
+        w, xs, rts = saved[0], saved[1:1 + n], saved[1 + n:]
+        live = [i for i, g in enumerate(gzs) if g is not None]
+        gxs = [None] * n
+        gw = gb = None
+        if not live:
+            return (None, None, None, None) + tuple(gxs)
+        need = [i for i in live if ctx.needs_input_grad[4 + i]]
+        if need:
+            res = PoolConvDgradG.apply(w, relu_in, tuple(tmodes[i] for i in need), len(need), *([gzs[i] for i in need] + [xs[i] for i in need]))
+            for i, r in zip(need, res):
+                gxs[i] = r
+        if TF._param_grads_enabled:
+            need_w, need_b = ctx.needs_input_grad[0], b is not None and ctx.needs_input_grad[1]
+            if need_w:
+                lr, lg = [rts[i] for i in live], [gzs[i] for i in live]
+                lsh, ltm = [shapes[i] for i in live], [tmodes[i] for i in live]
+                done, gw, gb = _pool_wgrad_to_sink(w, b, lr, lg, lsh, ltm, need_b)
+                if not done:
+                    gw = PoolConvWgradG.apply(tuple(w.shape), tuple(ltm), tuple(lsh), len(live), *(lr + lg))
+                    if need_b:
+                        gb = TF.ChannelSumG.apply(*lg)
+            elif need_b:
+                gb = TF.ChannelSumG.apply(*[gzs[i] for i in live])
+        return (gw, gb, None, None) + tuple(gxs)
+
+
+class PoolConvDgradG(Function):
+    """gxs[i] = [xs[i] > 0]? * boxsum^T(conv^T(subsample^T(gzs[i]))): the data gradient of `PoolConvG` from the POOLED gradient
+    (no zero-stuffed or un-pooled intermediate). Its adjoints: d/d gz = the pooled convolution of the masked cotangent, d/d w =
+    the pooled weight gradient of (box-summed masked cotangent, gz) — the triple is closed under differentiation.
+    args: w, masked, tmodes, n, gz_0.., x_0.. (the x are the ReLU masks; unused when `masked` is False)."""
+
+    @staticmethod
+    def forward(ctx, w, masked, tmodes, n, *gzs_xs):
+        gzs, xs = gzs_xs[:n], gzs_xs[n:]
+        shapes = [tuple(x.shape) for x in xs]
+        ctx.save_for_backward(w, *gzs_xs)
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (masked, tuple(tmodes), shapes, n)
+        planes = pool_dgrad_raw(gzs, shapes, tmodes, w)
+        return tuple(unbox_raw(planes, shapes, tmodes, masks=xs if masked else None))
+
+    @staticmethod
+    def backward(ctx, *ggxs):
+        TF = _TF()
+        masked, tmodes, shapes, n = ctx.cfg
+        saved = ctx.saved_tensors
+        w, gzs, xs = saved[0], saved[1:1 + n], saved[1 + n:]
+        live = [i for i, g in enumerate(ggxs) if g is not None]
+        d_w = None
+        d_gzs = [None] * n
+        if not live:
+            return (None, None, None, None) + tuple(d_gzs) + (None,) * n
+        ltm, lsh = [tmodes[i] for i in live], [shapes[i] for i in live]
+        need = [i for i in live if ctx.needs_input_grad[4 + i]]
+        want_w = ctx.needs_input_grad[0] and TF._param_grads_enabled
+        if not torch.is_grad_enabled():
+            # (the usual case: the second backward of the gradient penalty is not itself recorded) one box-sum pass with the
+            # mask fused serves both adjoints
+            rts = boxsum_raw([ggxs[i] for i in live], ltm, False, masks=[xs[i] for i in live] if masked else None)
+            if need:
+                pos = [live.index(i) for i in need]
+                res = pool_fwd_raw([rts[k] for k in pos], [lsh[k] for k in pos], [ltm[k] for k in pos], w, None)
+                for i, r in zip(need, res):
+                    d_gzs[i] = r
+            if want_w:
+                done, d_w, _ = _pool_wgrad_to_sink(w, None, rts, [gzs[i] for i in live], lsh, ltm, False)
+                if not done:
+                    d_w = pool_wgrad_raw(rts, [gzs[i] for i in live], lsh, ltm, tuple(w.shape))
+        else:
+            hs = list(TF.ReluMaskG.apply(len(live), *([ggxs[i] for i in live] + [xs[i] for i in live]))) if masked else [ggxs[i] for i in live]
+            if need:
+                pos = [live.index(i) for i in need]
+                res = PoolConvG.apply(w, None, False, tuple(ltm[k] for k in pos), *[hs[k] for k in pos])
+                for i, r in zip(need, res):
+                    d_gzs[i] = r
+            if want_w:
+                rts = boxsum_raw([h.detach() for h in hs], ltm, False)
+                d_w = PoolConvWgradG.apply(tuple(w.shape), tuple(ltm), tuple(lsh), len(live), *(rts + [gzs[i] for i in live]))
+        return (d_w, None, None, None) + tuple(d_gzs) + (None,) * n
+
+
+class PoolConvWgradG(Function):
+    """gw = sum over the members of the pooled weight gradient (immediate reduce): the path without a gradient sink."""
+
+    @staticmethod
+    def forward(ctx, wshape, tmodes, shapes, n, *rts_gzs):
+        rts, gzs = rts_gzs[:n], rts_gzs[n:]
+        return pool_wgrad_raw(list(rts), list(gzs), list(shapes), list(tmodes), wshape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggw):
+        raise RuntimeError('the pooled weight gradient is differentiated at most once on this path')
+
+
+def pool_conv_group(xs, w, b=None, relu_in=True, stem=False):
+    """[pool(conv3(relu?(x), w) + b) for x in xs] in one box-sum launch + one strided GEMM launch; check `pool_conv_ok` first.
+    stem=True: the pooling is AvgPool3d((1,2,2), stride 2) (time: even frames); else DownSample (2 on every extent > 1)."""
+    tmodes = tuple(pool_tmode(x.shape, stem) for x in xs)
+    if any(t is None for t in tmodes):
+        raise ValueError('pool_conv_group: a member has odd extents (check pool_conv_ok first)')
+    return list(PoolConvG.apply(w, b, bool(relu_in), tmodes, *xs))

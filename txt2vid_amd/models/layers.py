@@ -314,6 +314,11 @@ def down_block_levels(block, xs):
     idm = block.main.identity_map
     # main conv1 and the skip conv read the same tensors: one Function, so their data gradients land in one buffer
     hs, ss = TF.conv_multi_group(xs, [(m[1].weight, m[1].bias, True), (idm[0].weight, idm[0].bias, False)])
+    if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample) and TF.pool_conv_ok(hs, m[3].weight, False):
+        # the second convolution feeds ONLY DownSample: pool(conv3(relu(h))) as the stride-2 convolution of the box-summed
+        # activation (an eighth of the MACs where all three extents are pooled); the skip path's pooling adds it in its launch
+        zs = TF.pool_conv_group(hs, m[3].weight, m[3].bias, relu_in=True, stem=False)
+        return TF.avg_pool3d_group(ss, [downsample_cfg(s_) for s_ in ss], adds=zs)
     hs = TF.conv_group(hs, m[3].weight, m[3].bias, relu_in=True)
     if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
         return TF.avg_pool3d_group(ss, [downsample_cfg(s_) for s_ in ss], x2s=hs)     # one launch for all levels

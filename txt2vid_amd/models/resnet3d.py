@@ -54,7 +54,16 @@ class Resnet3D(nn.Module):
         xs, xs_skip = TF.fork_group(xs)
         hs = TF.conv_group(xs, m[0].weight, m[0].bias)
         pool_h = None
-        if isinstance(m[3], AvgPool3d) and isinstance(idm[0], AvgPool3d):
+        if isinstance(m[3], AvgPool3d) and isinstance(idm[0], AvgPool3d) and \
+                (m[3].kernel_size, m[3].stride, m[3].padding) == ((1, 2, 2), (2, 2, 2), (0, 0, 0)) and TF.pool_conv_ok(hs, m[2].weight, True):
+            # conv2 feeds ONLY the pooling: pool(conv3(relu(h))) = stride-2 conv3 of the box-summed activation — 27 taps over the
+            # pooled voxels (a quarter of the even-frame MACs), same values up to summation order (functional_pool.py)
+            zs = TF.pool_conv_group(hs, m[2].weight, m[2].bias, relu_in=True, stem=True)
+            cfg_x = [(idm[0].kernel_size, idm[0].stride, idm[0].padding)] * len(xs)
+            ss = TF.conv_group(TF.avg_pool3d_group(xs_skip, cfg_x), idm[1].weight, idm[1].bias)
+            hs = TF.add_group(zs, ss)
+            pool_h = False
+        elif isinstance(m[3], AvgPool3d) and isinstance(idm[0], AvgPool3d):
             pool_h = (m[3].kernel_size, m[3].stride, m[3].padding)
             if pool_h[0][0] == 1 and pool_h[1][0] == 2 and pool_h[2][0] == 0 and TF.even_frames_ok(hs, m[2].weight):
                 # AvgPool3d((1,2,2), stride 2) keeps the even frames of conv2 only: compute just those (half the forward GEMM)
@@ -65,7 +74,9 @@ class Resnet3D(nn.Module):
                 hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
         else:
             hs = TF.conv_group(hs, m[2].weight, m[2].bias, relu_in=True)
-        if pool_h is not None:
+        if pool_h is False:
+            pass                                                                  # (pooled convolution above: already summed)
+        elif pool_h is not None:
             cfg_h = [pool_h] * len(xs)
             cfg_x = [(idm[0].kernel_size, idm[0].stride, idm[0].padding)] * len(xs)
             ss = TF.conv_group(TF.avg_pool3d_group(xs_skip, cfg_x), idm[1].weight, idm[1].bias)
