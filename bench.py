@@ -168,7 +168,7 @@ def per_tile_breakdown(path, steps, peak, kind):
     """Forward / data-gradient GEMM launches of the instrumented iterations grouped by kernel family: launches and GPU ms per
     iteration, achieved TFLOP/s on the executed FLOPs, fraction of the MFMA peak (from the library's per-launch records)."""
     import csv
-    names = {0: 'igemm', 1: 'strip', 5: 'strip3'}
+    names = {0: 'igemm', 1: 'strip', 5: 'strip3', 9: 'pool fwd', 10: 'pool dgrad'}
     agg = {}
     try:
         with open(path) as f:

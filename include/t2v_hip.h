@@ -463,15 +463,23 @@ int t2v_gather_rows(const float* x, const int32_t* perm, float* out, int64_t row
  * dstride = tmode: 0 no time axis (D == 1), 1 time box-summed and strided like H / W (DownSample), 2 time strided without a
  * box (the stem keeps the even frames). fwd / wgrad: x = r~, y = pooled output / dL/dy, taps in (dz,dy,dx) product order (9 or
  * 27) with widx = packed slot (mode 0). dgrad: x = dL/dy, y = planes [8][N, C, Dq, H/2+1, W/2+1], widx[f] for the 27 FORWARD
- * taps f = ((dz+1)*3 + dy+1)*3 + dx+1: the slot of the mode-1 packed weight holding that tap's matrix (ntaps ignored). */
+ * taps f = ((dz+1)*3 + dy+1)*3 + dx+1: the slot of the mode-1 packed weight holding that tap's matrix (ntaps ignored).
+ *
+ * The SAME kernels serve the generator's `Upsample(2) -> conv3x3` pairs (txt2vid/models/layers.py:152-195, UpBlock) in transposed
+ * roles — nearest up-sampling is the box filter of the zero-stuffed map, so conv3(up2(x)) = box-sum of the class planes of x:
+ *   forward  = t2v_pool_conv_dgrad (x = the SMALL map, mode-0 packed weight, K = Cin, C = Cout) + t2v_pool_unbox (scale 1, + bias)
+ *   d/dx     = t2v_pool_boxsum(dL/dy, scale 1) + t2v_pool_conv_fwd with the mode-1 packed weight (Cin := Cout, Cout := Cin)
+ *   d/dw     = t2v_pool_conv_wgrad(x = box-summed dL/dy, y = the small map) + t2v_wgrad_swap
+ * — 9 taps per INPUT pixel instead of 9 per output pixel: a quarter of the MACs. */
 typedef struct t2v_poolbox_job {
     const float* in;      /* boxsum: r (or a cotangent); unbox: the 8 class planes                                  */
     const float* mask;    /* optional: boxsum multiplies `in` by [mask > 0]; unbox zeroes the result where mask <= 0 */
     float* out;           /* boxsum: r~ [NC, Dp, H+1, W+2]; unbox: [NC, D, H, W]                                     */
+    const float* bias;    /* unbox only, optional: out += bias[channel] (channel = (row of NC) % C)                  */
     int32_t NC, D, H, W;  /* full-resolution extents                                                                */
     int32_t tmode, relu;  /* relu: boxsum clamps its input at 0 first                                               */
-    float scale;          /* 1 / window volume (0.25 or 0.125): folded into r~ and into the adjoint                 */
-    int32_t reserved;
+    float scale;          /* 1 / window volume (0.25 or 0.125; 1 for the up-sampling form): folded into both passes */
+    int32_t C;            /* channels (only read with `bias`)                                                       */
 } t2v_poolbox_job;
 int t2v_pool_boxsum(const t2v_poolbox_job* jobs, int njobs, void* stream);
 int t2v_pool_unbox(const t2v_poolbox_job* jobs, int njobs, void* stream);
@@ -479,11 +487,15 @@ int64_t t2v_pool_conv_fwd_ws_floats(const t2v_conv_group* groups, int ngroups, i
 int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp, const float* bias, float* ws,
                       int flags, void* stream);
 int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, const float* wp, void* stream);
-int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int want_bias);
-int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, float* slab, int flags,
-                        void* stream);
-int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* slab, int want_bias, int flags,
-                                t2v_wgrad_src* out_src, void* stream);
+/* kD: 3 for [Cout,Cin,3,3,3] weights, 1 for [Cout,Cin,(1,)3,3] (then no member may have a time axis) */
+int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int want_bias);
+int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, float* dw, float* dbias, float* slab,
+                        int flags, void* stream);
+int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, float* slab, int want_bias,
+                                int flags, t2v_wgrad_src* out_src, void* stream);
+/* dst[co][ci][t] (+= if accum) src[ci][co][T-1-t]: the weight gradient of the up-sampling form (below) comes out of the pooled
+ * weight-gradient kernel with its operand roles — hence (co, ci) — swapped and its taps mirrored. */
+int t2v_wgrad_swap(const float* src, float* dst, int Cout, int Cin, int T, int accum, void* stream);
 /* Launch plans (host arithmetic): out[0] kind (9 pool forward, 10 pool data gradient, 11 pool weight gradient), out[1] tile
  * voxels, out[2] 64, out[3] 32, out[5] VECB, out[7] split-K / k-split count S. */
 int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int32_t* out);

@@ -294,10 +294,12 @@ def _sync_from_oracle(tr, gan, optD, optG):
             so = opt_o.state.get(P[k], {})
             if not so:
                 continue
-            sp = opt_p.state[named[k]]
+            pp = named[k]
+            sp = opt_p.state[pp]
             sp['step'] = int(so['step'])
-            sp['exp_avg'] = so['exp_avg'].detach().clone().to(DEV)
-            sp['exp_avg_sq'] = so['exp_avg_sq'].detach().clone().to(DEV)
+            for key in ('exp_avg', 'exp_avg_sq'):                     # in the PARAMETER's memory layout (tap-major ConvLSTM masters):
+                sp[key] = torch.empty_strided(pp.shape, pp.stride(), dtype=pp.dtype, device=pp.device).copy_(so[key].detach())   # the fused
+                #                                                        optimiser walks parameter, gradient and moments with one flat index
     from txt2vid_amd import functional as TF
     TF.bump_weight_epoch()
 

@@ -985,3 +985,26 @@ def test_pool_conv_group_at_benchmark_size():
             db_ref += br.grad.double()
         close(dw, dw_ref, rtol=2e-4, atol=2e-4)
         close(dbias, db_ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(3, 64, 32, 4, 4), (2, 128, 64, 8, 6), (5, 32, 32, 1, 1), (2, 96, 160, 16, 16)])
+def test_up_conv(n, cin, cout, h, w):
+    """`up_conv` (the pooled-convolution kernels in transposed roles, functional_pool.py): conv3x3(upsample2x(x)) + b of the
+    generator's UpBlocks (layers.py:152-195) without the up-sampled tensor — values and first-order gradients (data, weight, bias)
+    against torch's conv2d(interpolate(x, nearest x2)) on the CPU, with and without a gradient sink slot."""
+    from txt2vid_amd import functional as TF
+    x_h, w_h, b_h = rnd(1, n, cin, h, w), rnd(2, cout, cin, 3, 3) * 0.05, rnd(3, cout)
+    xr, wr, br = x_h.clone().requires_grad_(True), w_h.clone().requires_grad_(True), b_h.clone().requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, br, padding=1)
+    gy = rnd(4, *yr.shape)
+    (yr * gy).sum().backward()
+    xd = x_h.to(dev()).requires_grad_(True)
+    wd, bd = torch.nn.Parameter(w_h.to(dev())), torch.nn.Parameter(b_h.to(dev()))
+    assert TF.up_conv_ok(xd, wd)
+    yd = TF.up_conv(xd, wd, bd)
+    assert yd.shape == yr.shape
+    close(yd, yr)
+    (yd * gy.to(dev())).sum().backward()
+    close(xd.grad, xr.grad)
+    close(wd.grad, wr.grad, rtol=2e-4, atol=2e-4)
+    close(bd.grad, br.grad, rtol=2e-4, atol=2e-4)

@@ -42,8 +42,8 @@ class PoolJob(C.Structure):
 
 class PoolBoxJob(C.Structure):
     """t2v_poolbox_job (include/t2v_hip.h)."""
-    _fields_ = [('in_', C.c_void_p), ('mask', C.c_void_p), ('out', C.c_void_p), ('NC', C.c_int32), ('D', C.c_int32), ('H', C.c_int32),
-                ('W', C.c_int32), ('tmode', C.c_int32), ('relu', C.c_int32), ('scale', C.c_float), ('reserved', C.c_int32)]
+    _fields_ = [('in_', C.c_void_p), ('mask', C.c_void_p), ('out', C.c_void_p), ('bias', C.c_void_p), ('NC', C.c_int32), ('D', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('tmode', C.c_int32), ('relu', C.c_int32), ('scale', C.c_float), ('C', C.c_int32)]
 
 
 class MultiJob(C.Structure):
@@ -193,9 +193,10 @@ SIGNATURES = {
     't2v_pool_conv_fwd_ws_floats': [_P, _I, _I, _I],
     't2v_pool_conv_fwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_pool_conv_dgrad': [_P, _I, _I, _I, _P, _P],
-    't2v_pool_conv_wgrad_slab_floats': [_P, _I, _I, _I, _I],
-    't2v_pool_conv_wgrad': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
-    't2v_pool_conv_wgrad_partial': [_P, _I, _I, _I, _P, _I, _I, _P, _P],
+    't2v_pool_conv_wgrad_slab_floats': [_P, _I, _I, _I, _I, _I],
+    't2v_pool_conv_wgrad': [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    't2v_pool_conv_wgrad_partial': [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    't2v_wgrad_swap': [_P, _P, _I, _I, _I, _I, _P],
     't2v_pool_conv_plan': [_I, _P, _I, _I, _I, _I3],
     't2v_synth_clips': [_P, _I, _L, _I, _I, _I, _I3, _P, _P, _P, _P],
     't2v_prof_begin': [_I],

@@ -3883,8 +3883,8 @@ extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, in
 }
 
 // weight gradient: chunks of 32 pooled voxels, one kernel row (dz, dy) per workgroup, k-split like build_wtable
-static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, bool need_ptrs, WGroupTable& tab, WgradPlan& p) {
-    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1) return false;
+static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, bool need_ptrs, WGroupTable& tab, WgradPlan& p) {
+    if (!groups || ngroups < 1 || ngroups > T2V_MAX_GROUPS || Cin < 1 || Cout < 1 || (kD != 1 && kD != 3)) return false;
     long nch = 0;
     bool any_t = false;
     tab.n = ngroups;
@@ -3893,6 +3893,7 @@ static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin
         if (!pool_member_ok(g, need_ptrs)) return false;
         if ((long)g.N * pool_padded(g) * Cin >= (1L << 29) || pool_rows(g) * Cout >= (1L << 29)) return false;
         any_t = any_t || g.dstride != 0;
+        if (kD == 1 && g.dstride != 0) return false;             // a [.,.,3,3] weight has no time taps
         tab.g[i] = g;
         tab.chunk_start[i] = (int32_t)nch;
         nch += (pool_rows(g) + WG_BK - 1) / WG_BK;
@@ -3919,28 +3920,29 @@ static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin
     p.S = (int)((nch + p.cps - 1) / p.cps);
     return true;
 }
-extern "C" int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int want_bias) {
+extern "C" int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int want_bias) {
     WGroupTable tab;
     WgradPlan p;
-    if (!build_pool_wtable(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+    if (!build_pool_wtable(groups, ngroups, Cin, Cout, kD, false, tab, p)) return T2V_EINVAL;
     return (int64_t)p.S * p.nlive * Cout * Cin + (want_bias ? (int64_t)p.S * Cout : 0);
 }
-static int pool_wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, bool want_bias,
+static int pool_wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, float* dw, float* dbias, bool want_bias,
                            float* slab, int flags, void* stream, t2v_wgrad_src* out_src) {
     WGroupTable tab;
     WgradPlan p;
-    if ((!dw && !out_src) || !slab || !build_pool_wtable(groups, ngroups, Cin, Cout, true, tab, p)) return T2V_EINVAL;
+    if ((!dw && !out_src) || !slab || !build_pool_wtable(groups, ngroups, Cin, Cout, kD, true, tab, p)) return T2V_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     float* bias_part = slab + (size_t)p.S * p.nlive * Cout * Cin;
-    const int T = 27;
+    const int T = kD * 9;
     TapMap map;
     for (int t = 0; t < T2V_MAX_TAPS; ++t) map.j[t] = -1;
     LiveRows lrows;
     lrows.n = 0;
     for (int r = 0; r < 9; ++r) lrows.r[r] = 0;
-    for (int r = 0; r < 9; ++r)
+    for (int r = 0; r < 9; ++r)                              // kernel rows (dz, dy) in the 3x3x3 numbering the kernel decodes
         if ((p.liverows >> r) & 1u) {
-            for (int c = 0; c < 3; ++c) map.j[r * 3 + c] = lrows.n * 3 + c;
+            const int rw = kD == 3 ? r : r - 3;              // ... and in the weight's own (a [.,.,3,3] weight only has the dz = 0 rows)
+            for (int c = 0; c < 3; ++c) map.j[rw * 3 + c] = lrows.n * 3 + c;
             lrows.r[lrows.n++] = (int8_t)r;
         }
     double flops = 0;
@@ -3977,15 +3979,15 @@ static int pool_wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, i
                    (flags & T2V_CONV_ACCUM) ? 1 : 0, bias_in, dbias, Cout, accum_bias);
     return launch_status();
 }
-extern "C" int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* dw, float* dbias, float* slab,
-                                   int flags, void* stream) {
+extern "C" int t2v_pool_conv_wgrad(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, float* dw, float* dbias,
+                                   float* slab, int flags, void* stream) {
     if (!dw) return T2V_EINVAL;
-    return pool_wgrad_impl(groups, ngroups, Cin, Cout, dw, dbias, dbias != nullptr, slab, flags, stream, nullptr);
+    return pool_wgrad_impl(groups, ngroups, Cin, Cout, kD, dw, dbias, dbias != nullptr, slab, flags, stream, nullptr);
 }
-extern "C" int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, float* slab, int want_bias,
-                                           int flags, t2v_wgrad_src* out_src, void* stream) {
+extern "C" int t2v_pool_conv_wgrad_partial(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, float* slab,
+                                           int want_bias, int flags, t2v_wgrad_src* out_src, void* stream) {
     if (!out_src) return T2V_EINVAL;
-    return pool_wgrad_impl(groups, ngroups, Cin, Cout, nullptr, nullptr, want_bias != 0, slab, flags, stream, out_src);
+    return pool_wgrad_impl(groups, ngroups, Cin, Cout, kD, nullptr, nullptr, want_bias != 0, slab, flags, stream, out_src);
 }
 // what: 0 forward, 1 data gradient (Cin = K of dL/dy, Cout = channels of the planes), 2 weight gradient
 extern "C" int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int32_t* out) {
@@ -4002,7 +4004,7 @@ extern "C" int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ng
     if (what == 2) {
         WGroupTable tab;
         WgradPlan p;
-        if (!build_pool_wtable(groups, ngroups, Cin, Cout, false, tab, p)) return T2V_EINVAL;
+        if (!build_pool_wtable(groups, ngroups, Cin, Cout, 3, false, tab, p)) return T2V_EINVAL;
         out[0] = 11; out[1] = p.S; out[2] = p.cps; out[3] = p.nlive; out[4] = ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0;
         out[5] = (int32_t)((long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows * p.S);
         return T2V_OK;

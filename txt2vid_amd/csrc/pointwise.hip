@@ -2471,7 +2471,8 @@ __global__ __launch_bounds__(256) void pool_unbox_k(const PoolBoxBatch tb) {
             }
         }
         const bool keep = mk ? mk[i] > 0.f : true;
-        q.out[i] = keep ? acc * q.scale : 0.f;
+        const float bv = q.bias ? q.bias[nc % q.C] : 0.f;
+        q.out[i] = keep ? acc * q.scale + bv : 0.f;
     }
 }
 
@@ -2485,6 +2486,7 @@ static int poolbox_multi(const t2v_poolbox_job* jobs, int njobs, bool unbox, voi
             const t2v_poolbox_job& q = jobs[at + i];
             if (!q.in || !q.out || q.NC < 1 || q.D < 1 || q.H < 2 || q.W < 2 || (q.H & 1) || (q.W & 1) || q.tmode < 0 || q.tmode > 2) return T2V_EINVAL;
             if ((q.tmode == 0 && q.D != 1) || (q.tmode != 0 && (q.D < 2 || (q.D & 1)))) return T2V_EINVAL;
+            if (q.bias && (!unbox || q.C < 1 || (q.NC % q.C) != 0)) return T2V_EINVAL;
             tb.j[i] = q;
             tb.begin[i] = (int)blocks;
             const long n = unbox ? (long)q.NC * q.D * q.H * q.W
@@ -2502,3 +2504,18 @@ static int poolbox_multi(const t2v_poolbox_job* jobs, int njobs, bool unbox, voi
 }
 extern "C" int t2v_pool_boxsum(const t2v_poolbox_job* jobs, int njobs, void* st) { return poolbox_multi(jobs, njobs, false, st); }
 extern "C" int t2v_pool_unbox(const t2v_poolbox_job* jobs, int njobs, void* st) { return poolbox_multi(jobs, njobs, true, st); }
+
+__global__ __launch_bounds__(256) void wgrad_swap_k(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int T, int accum) {
+    const long n = (long)Cout * Cin * T;
+    GRID_STRIDE(i, n) {
+        const int t = (int)(i % T); const long r = i / T;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float v = src[((long)ci * Cout + co) * T + (T - 1 - t)];
+        dst[i] = accum ? dst[i] + v : v;
+    }
+}
+extern "C" int t2v_wgrad_swap(const float* src, float* dst, int Cout, int Cin, int T, int accum, void* st) {
+    if (!src || !dst || Cout < 1 || Cin < 1 || T < 1) return T2V_EINVAL;
+    T2V_LAUNCH(wgrad_swap_k, dim3(nblocks((long)Cout * Cin * T)), dim3(256), 0, S_(st), src, dst, Cout, Cin, T, accum);
+    return launch_status();
+}

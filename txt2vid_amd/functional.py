@@ -3114,7 +3114,7 @@ def _pass_none_through(cls):
 
 # the pooled second convolution of the discriminator blocks (box-sum + stride-2 GEMMs): functional_pool.py
 from .functional_pool import (pool_conv_ok, pool_conv_group, pool_tmode, PoolConvG, PoolConvDgradG, PoolConvWgradG, boxsum_raw, unbox_raw,     # noqa: E402,F401
-                              pool_fwd_raw, pool_dgrad_raw, pool_wgrad_raw)
+                              pool_fwd_raw, pool_dgrad_raw, pool_wgrad_raw, up_conv, up_conv_ok, UpConvFn)
 
 
 def add_group(as_, bs):

@@ -65,39 +65,51 @@ def pooled_shape(shape, tmode):
 # raw launches
 # ------------------------------------------------------------------------------------------------
 
-def _box_jobs(ins, masks, outs, shapes, tmodes, relu):
+def _box_jobs(ins, masks, outs, shapes, tmodes, relu, scale=None, bias=None):
     arr = (PoolBoxJob * len(ins))()
     for a, t, sh, tm, i in zip(arr, ins, shapes, tmodes, range(len(ins))):
         a.in_, a.out = t.data_ptr(), outs[i].data_ptr()
         a.mask = masks[i].data_ptr() if masks is not None else None
-        a.NC, a.D, a.H, a.W = sh[0] * sh[1], sh[2], sh[3], sh[4]
-        a.tmode, a.relu, a.scale = tm, 1 if relu else 0, pool_scale(tm)
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.NC, a.D, a.H, a.W, a.C = sh[0] * sh[1], sh[2], sh[3], sh[4], sh[1]
+        a.tmode, a.relu, a.scale = tm, 1 if relu else 0, pool_scale(tm) if scale is None else scale
     return arr
 
 
-def boxsum_raw(ins, tmodes, relu, masks=None):
-    """r~ of every member (padded grid [N,C,Dp,H+1,W+2]); `masks`: the inputs are cotangents, multiplied by [mask > 0] first."""
+def boxsum_raw(ins, tmodes, relu, masks=None, scale=None):
+    """r~ of every member (padded grid [N,C,Dp,H+1,W+2]); `masks`: the inputs are cotangents, multiplied by [mask > 0] first.
+    `scale`: instead of 1 / window volume (the up-sampling form passes 1)."""
     ins = [_c(t) for t in ins]
     masks = [_c(m) for m in masks] if masks is not None else None
     shapes = [tuple(t.shape) for t in ins]
     outs = [torch.empty((sh[0], sh[1], sh[2] + 1 if tm else 1, sh[3] + 1, sh[4] + 2), device=t.device, dtype=torch.float32)
             for t, sh, tm in zip(ins, shapes, tmodes)]
-    check(lib().t2v_pool_boxsum(_box_jobs(ins, masks, outs, shapes, tmodes, relu), len(ins), _stream()), 't2v_pool_boxsum')
+    check(lib().t2v_pool_boxsum(_box_jobs(ins, masks, outs, shapes, tmodes, relu, scale), len(ins), _stream()), 't2v_pool_boxsum')
     return outs
 
 
-def unbox_raw(planes, shapes, tmodes, masks=None):
-    """The adjoint of `boxsum_raw` applied to the 8 class planes of each member; `masks`: result zeroed where mask <= 0."""
+def unbox_raw(planes, shapes, tmodes, masks=None, scale=None, bias=None):
+    """The adjoint of `boxsum_raw` applied to the 8 class planes of each member; `masks`: result zeroed where mask <= 0;
+    `bias`: a per-channel constant added on top (the up-sampling form's convolution bias)."""
     masks = [_c(m) for m in masks] if masks is not None else None
     outs = [torch.empty(tuple(sh), device=p.device, dtype=torch.float32) for p, sh in zip(planes, shapes)]
-    check(lib().t2v_pool_unbox(_box_jobs(planes, masks, outs, shapes, tmodes, False), len(planes), _stream()), 't2v_pool_unbox')
+    check(lib().t2v_pool_unbox(_box_jobs(planes, masks, outs, shapes, tmodes, False, scale, bias), len(planes), _stream()), 't2v_pool_unbox')
     return outs
 
 
-def _tap_union(tmodes):
+def _tap_union(tmodes, kD=3):
+    """The taps to pack: all 27, or the dz = 0 plane when no member has a time axis; the 9 taps of a [.,.,1,3,3] weight (kD = 1)."""
     TF = _TF()
-    mask = (1 << 27) - 1 if any(tmodes) else 0x1ff << 9            # all taps, or the dz = 0 plane
+    if kD == 1:
+        if any(tmodes):
+            raise ValueError('a 2-D kernel cannot serve members with a time axis')
+        return TF._tapset(9, 0x1ff)
+    mask = (1 << 27) - 1 if any(tmodes) else 0x1ff << 9
     return TF._tapset(27, mask)
+
+
+def _tap_index(ts, dz, dy, dx):
+    return (dy + 1) * 3 + dx + 1 if ts.T == 9 else ((dz + 1) * 3 + dy + 1) * 3 + dx + 1
 
 
 def _fwd_table(xs, ys, shapes, tmodes, ts):
@@ -112,19 +124,20 @@ def _fwd_table(xs, ys, shapes, tmodes, ts):
             for dy in (-1, 0, 1):
                 for dx in (-1, 0, 1):
                     a.dz[j], a.dy[j], a.dx[j] = dz, dy, dx
-                    a.widx[j] = slot_of[((dz + 1) * 3 + dy + 1) * 3 + dx + 1]
+                    a.widx[j] = slot_of[_tap_index(ts, dz, dy, dx)]
                     j += 1
         a.ntaps = j
     return arr
 
 
-def pool_fwd_raw(rts, shapes, tmodes, w5, bias=None):
+def pool_fwd_raw(rts, shapes, tmodes, w5, bias=None, transpose=False):
     """zs[i] = stride-2 conv3 of the padded box sums rts[i] (+ bias): [N, Cout, D', H', W']. `shapes`: the full-resolution
-    [N,C,D,H,W] of each member."""
+    [N,C,D,H,W] of each member. `transpose`: contract over the weight's OUTPUT channels with mirrored taps (mode-1 packing) — the
+    data gradient of the up-sampling form."""
     TF = _TF()
     w5 = _c(w5)
-    cout, cin = w5.shape[0], w5.shape[1]
-    ts = _tap_union(tmodes)
+    cout, cin = (w5.shape[1], w5.shape[0]) if transpose else (w5.shape[0], w5.shape[1])
+    ts = _tap_union(tmodes, w5.shape[2])
     zs = []
     for sh, tm, t in zip(shapes, tmodes, rts):
         n, d, h, w_ = pooled_shape(sh, tm)
@@ -134,19 +147,21 @@ def pool_fwd_raw(rts, shapes, tmodes, w5, bias=None):
     if nws < 0:
         raise RuntimeError('bad pooled-convolution geometry')
     ws = torch.empty((nws,), device=rts[0].device, dtype=torch.float32) if nws > 0 else None
-    wp = TF.packed_weight(w5, ts, 0)
+    wp = TF.packed_weight(w5, ts, 1 if transpose else 0)
     check(lib().t2v_pool_conv_fwd(arr, len(rts), cin, cout, _p(wp), _p(bias), _p(ws), TF.FLAG_BIAS if bias is not None else 0, _stream()),
           't2v_pool_conv_fwd')
     return zs
 
 
-def pool_dgrad_raw(gzs, shapes, tmodes, w5):
-    """The 8 parity-class planes [8, N, Cin, Dq, H/2+1, W/2+1] of the data gradient on the padded grid, from dL/dy (pooled shape)."""
+def pool_dgrad_raw(gzs, shapes, tmodes, w5, transpose=False):
+    """The 8 parity-class planes [8, N, Cin, Dq, H/2+1, W/2+1] of the data gradient on the padded grid, from dL/dy (pooled shape).
+    `transpose`: contract over the weight's INPUT channels instead (mode-0 packing): the class planes of `conv3(zero-stuffed x)`,
+    i.e. the forward of the up-sampling form (then `gzs` are the small maps and the planes have Cout channels)."""
     TF = _TF()
     gzs = [_c(g) for g in gzs]
     w5 = _c(w5)
-    cout, cin = w5.shape[0], w5.shape[1]
-    ts = _tap_union(tmodes)
+    cout, cin = (w5.shape[1], w5.shape[0]) if transpose else (w5.shape[0], w5.shape[1])          # (K of the GEMM, channels of the planes)
+    ts = _tap_union(tmodes, w5.shape[2])
     slot_of = {t: j for j, t in enumerate(ts.taps)}
     planes = [torch.empty((8, sh[0], cin, sh[2] // 2 + 1 if tm else 1, sh[3] // 2 + 1, sh[4] // 2 + 1), device=g.device, dtype=torch.float32)
               for g, sh, tm in zip(gzs, shapes, tmodes)]
@@ -157,9 +172,11 @@ def pool_dgrad_raw(gzs, shapes, tmodes, w5):
         a.x, a.y, a.mask = g.data_ptr(), pl.data_ptr(), None
         a.N, a.D, a.H, a.W = sh[0], sh[2], sh[3], sh[4]
         a.dstride, a.ntaps = tm, 27
-        for f in range(27):
-            a.widx[f] = slot_of.get(26 - f, -1)                   # mode-1 packing stores forward tap f in the slot of its mirror
-    wp = TF.packed_weight(w5, ts, 1)
+        for f in range(27):                                       # the kernel numbers its taps f = ((dz+1)*3 + dy+1)*3 + dx+1
+            # mode-1 packing stores forward tap f in the slot of its mirror; in the transposed (mode-0) role the class structure
+            # itself asks for the mirrored tap: the same index either way
+            a.widx[f] = slot_of.get(26 - f, -1) if ts.T == 27 else (slot_of.get(8 - (f - 9), -1) if 9 <= f < 18 else -1)
+    wp = TF.packed_weight(w5, ts, 0 if transpose else 1)
     check(lib().t2v_pool_conv_dgrad(arr, len(gzs), cout, cin, _p(wp), _stream()), 't2v_pool_conv_dgrad')
     return planes
 
@@ -174,18 +191,18 @@ def _wgrad_table(rts, gzs, shapes, tmodes):
 
 
 def pool_wgrad_raw(rts, gzs, shapes, tmodes, wshape, out=None, accum=False, dbias=None, accum_bias=False):
-    """dW (and the bias gradient when `dbias` is given) summed over the members, reduce pass included."""
+    """dW (and the bias gradient when `dbias` is given) summed over the members, reduce pass included. wshape: [Cout,Cin,kD,3,3]."""
     TF = _TF()
     gzs = [_c(g) for g in gzs]
-    cout, cin = wshape[0], wshape[1]
+    cout, cin, kD = wshape[0], wshape[1], wshape[2]
     arr = _wgrad_table(rts, gzs, shapes, tmodes)
-    n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, 1 if dbias is not None else 0))
+    n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, kD, 1 if dbias is not None else 0))
     if n <= 0:
         raise RuntimeError('bad pooled weight-gradient geometry')
     slab = torch.empty((n,), device=rts[0].device, dtype=torch.float32)
     dw = out if out is not None else torch.empty(tuple(wshape), device=rts[0].device, dtype=torch.float32)
     flags = (TF.FLAG_ACCUM if accum else 0) | (TF.FLAG_ACCUM_BIAS if accum_bias else 0)
-    check(lib().t2v_pool_conv_wgrad(arr, len(rts), cin, cout, _p(dw), _p(dbias), _p(slab), flags, _stream()), 't2v_pool_conv_wgrad')
+    check(lib().t2v_pool_conv_wgrad(arr, len(rts), cin, cout, kD, _p(dw), _p(dbias), _p(slab), flags, _stream()), 't2v_pool_conv_wgrad')
     return dw
 
 
@@ -205,12 +222,12 @@ def _pool_wgrad_to_sink(w, b, rts, gzs, shapes, tmodes, need_b):
     bflat, bacc = sink.take(b, sink.defer) if need_b else (None, False)
     if sink.defer:
         arr = _wgrad_table(rts, gzs, shapes, tmodes)
-        n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, 1 if need_b else 0))
+        n = int(lib().t2v_pool_conv_wgrad_slab_floats(arr, len(rts), cin, cout, 3, 1 if need_b else 0))
         if n <= 0:
             raise RuntimeError('bad pooled weight-gradient geometry')
         slab = sink.alloc_slab(n, rts[0].device)
         src = WgradSrc()
-        check(lib().t2v_pool_conv_wgrad_partial(arr, len(rts), cin, cout, _p(slab), 1 if need_b else 0, 0, C.byref(src), _stream()),
+        check(lib().t2v_pool_conv_wgrad_partial(arr, len(rts), cin, cout, 3, _p(slab), 1 if need_b else 0, 0, C.byref(src), _stream()),
               't2v_pool_conv_wgrad_partial')
         sink.add_partial(wbase, wflat.view(w.shape), wacc, b if need_b else None, bflat, bacc, src, slab, 27, cout, cout * cin)
     else:
@@ -345,3 +362,72 @@ def pool_conv_group(xs, w, b=None, relu_in=True, stem=False):
     if any(t is None for t in tmodes):
         raise ValueError('pool_conv_group: a member has odd extents (check pool_conv_ok first)')
     return list(PoolConvG.apply(w, b, bool(relu_in), tmodes, *xs))
+
+
+# ------------------------------------------------------------------------------------------------
+# The same kernels in transposed roles: `Upsample(2) -> conv3x3` of the generator's UpBlocks (layers.py:152-195). Nearest
+# up-sampling is the box filter of the zero-stuffed map and box filter and convolution commute, so
+#     conv3(up2(x)) = boxsum( conv3(zero-stuffed x) )
+# and the convolution of a zero-stuffed map only ever multiplies each input pixel by the taps of its parity class: 9 taps per
+# INPUT pixel instead of 9 per output pixel — a quarter of the MACs, no up-sampled tensor in memory. Forward = the pooled form's
+# data-gradient kernel (class planes) + unbox; data gradient = box-sum + the pooled forward kernel; weight gradient = the pooled
+# weight-gradient kernel with its operands swapped (+ a small transpose). First-order only (generator side).
+# ------------------------------------------------------------------------------------------------
+
+def up_conv_ok(x, w):
+    TF = _TF()
+    return (not _DISABLED and TF.CONV_PRECISION == 'fp32' and x.dim() == 4 and x.is_cuda and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+            and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
+
+
+class UpConvFn(Function):
+    """y = conv3x3(upsample2x(x), w) + b for [N,Cin,h,w] -> [N,Cout,2h,2w]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        N, cin, h, w_ = x.shape
+        cout = w.shape[0]
+        w5 = w.unsqueeze(2)
+        full = (N, cout, 1, 2 * h, 2 * w_)                      # the up-sampled geometry ("full resolution" of the pooled kernels)
+        planes = pool_dgrad_raw([x.unsqueeze(2)], [(N, cin, 1, 2 * h, 2 * w_)], [0], w5, transpose=True)
+        y = unbox_raw(planes, [full], [0], scale=1.0, bias=b)[0]
+        ctx.save_for_backward(x, w)
+        ctx.bias = b
+        return y.squeeze(2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        TF = _TF()
+        x, w = ctx.saved_tensors
+        b = ctx.bias
+        gy = _c(gy)
+        N, cin, h, w_ = x.shape
+        cout = w.shape[0]
+        w5 = w.unsqueeze(2)
+        full = (N, cout, 1, 2 * h, 2 * w_)
+        gts = boxsum_raw([gy.unsqueeze(2)], [0], False, scale=1.0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = pool_fwd_raw(gts, [full], [0], w5, None, transpose=True)[0].squeeze(2)
+        if ctx.needs_input_grad[1]:
+            # operands swapped: "dL/dy" := the small map (Cin channels), "r~" := the box-summed gradient (Cout channels)
+            tmp = pool_wgrad_raw(gts, [x.unsqueeze(2)], [full], [0], (cin, cout, 1, 3, 3))
+
+            def swap(out, acc):
+                check(lib().t2v_wgrad_swap(_p(tmp), _p(out), cout, cin, 9, 1 if acc else 0, _stream()), 't2v_wgrad_swap')
+            done, gw = TF._to_sink(w, swap)
+            if not done:
+                gw = torch.empty_like(w)
+                swap(gw, False)
+        if b is not None and ctx.needs_input_grad[2]:
+            done, gb = TF._to_sink(b, lambda out, acc: TF.channel_sum_raw(gy.unsqueeze(2), out=out, accum=acc))
+            if not done:
+                gb = TF.channel_sum_raw(gy.unsqueeze(2))
+        return gx, gw, gb
+
+
+def up_conv(x, w, b=None):
+    """conv3x3(upsample2x(x), w) + b without the up-sampled tensor; check `up_conv_ok` first."""
+    return UpConvFn.apply(x, w, b)

@@ -231,7 +231,11 @@ class UpBlock(nn.Module):
 
     def forward(self, x):
         m = self.main.inner_module
-        if isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample):
+        if isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample) and isinstance(m[3], Conv2d) and TF.up_conv_ok(x, m[3].weight):
+            # Up -> conv3x3 without the up-sampled tensor: 9 taps per INPUT pixel (a quarter of the MACs), functional_pool.py
+            _check_same_conv(m[3])
+            h = TF.up_conv(m[0](x, relu=True), m[3].weight, m[3].bias)
+        elif isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample):
             h = m[3](m[0](x, relu=True, up=True))                                      # BN+ReLU+Up fused
         else:
             h = m[0](x, relu=True) if isinstance(m[0], BatchNorm2d) else m[1](m[0](x))
