@@ -477,7 +477,7 @@ typedef struct t2v_poolbox_job {
     float* out;           /* boxsum: r~ [NC, Dp, H+1, W+2]; unbox: [NC, D, H, W]                                     */
     const float* bias;    /* unbox only, optional: out += bias[channel] (channel = (row of NC) % C)                  */
     int32_t NC, D, H, W;  /* full-resolution extents                                                                */
-    int32_t tmode, relu;  /* relu: boxsum clamps its input at 0 first                                               */
+    int32_t tmode, relu;  /* relu: boxsum clamps its input at 0 first; unbox: number of plane sets to sum (0 / 1: one)      */
     float scale;          /* 1 / window volume (0.25 or 0.125; 1 for the up-sampling form): folded into both passes */
     int32_t C;            /* channels (only read with `bias`)                                                       */
 } t2v_poolbox_job;
@@ -486,6 +486,9 @@ int t2v_pool_unbox(const t2v_poolbox_job* jobs, int njobs, void* stream);
 int64_t t2v_pool_conv_fwd_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout);
 int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, const float* wp, const float* bias, float* ws,
                       int flags, void* stream);
+/* the data gradient may split K: it then writes t2v_pool_conv_dgrad_splits() SETS of planes ([S][8][...] per member) and
+ * t2v_pool_unbox adds them up when its job's `relu` field carries S */
+int t2v_pool_conv_dgrad_splits(const t2v_conv_group* groups, int ngroups, int K, int C);
 int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, const float* wp, void* stream);
 /* kD: 3 for [Cout,Cin,3,3,3] weights, 1 for [Cout,Cin,(1,)3,3] (then no member may have a time axis) */
 int64_t t2v_pool_conv_wgrad_slab_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int want_bias);

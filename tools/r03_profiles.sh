@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the round-3 evidence under gpurun_out/r03 (copied into profiles/ afterwards). Run on the GPU box from the repo root:
+#   bash tools/r03_profiles.sh [quick]      (quick: the kernel trace + timeline of the default benchmark only)
+set -o pipefail
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+O=$R/gpurun_out/r03
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_d_roofline --no_extra > $O/trace.log 2>&1 && echo "trace ok"
+rc=$?
+cp $O/trace/*/*_kernel_stats.csv $O/r03_kernel_stats.csv 2>/dev/null
+python3 $R/tools/prof_summary.py $O/trace > $O/r03_kernel_trace_summary.txt 2>&1
+ms=$(grep -o '"ms_per_step": [0-9.]*' $O/trace.log | head -1 | cut -d' ' -f2)
+python3 $R/tools/gap_analysis.py $O/trace $ms > $O/r03_replay_timeline.txt 2>&1
+rm -rf $O/trace
+[ "$1" = "quick" ] && exit $rc
+cd $R
+# per-launch shape table of one iteration's convolution launches (T2V_PROF_DUMP) + the default line
+T2V_PROF_DUMP=$O/r03_conv_launches.csv python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/r03_bench_default.json && echo "bench ok"
+python3 tools/launch_table.py $O/r03_conv_launches.csv 5 > $O/r03_conv_launch_shapes.txt 2>&1
+# D forward+backward (the north star's own line) and BASELINE configs[2] under the profiler
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_d -- python3 $R/tools/d_roofline.py > $O/d_roofline.log 2>&1 && echo "d ok"
+cp $O/trace_d/*/*_kernel_stats.csv $O/r03_d_fwdbwd_kernel_stats.csv 2>/dev/null; rm -rf $O/trace_d
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 $R/bench.py --cond --bf16 --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_d_roofline --no_extra > $O/cfg2.log 2>&1 && echo "cfg2 ok"
+cp $O/trace_c2/*/*_kernel_stats.csv $O/r03_cfg2_kernel_stats.csv 2>/dev/null
+python3 $R/tools/gap_analysis.py $O/trace_c2 $(grep -o '"ms_per_step": [0-9.]*' $O/cfg2.log | head -1 | cut -d' ' -f2) > $O/r03_cfg2_replay_timeline.txt 2>&1
+rm -rf $O/trace_c2
+exit $rc

@@ -193,6 +193,7 @@ SIGNATURES = {
     't2v_pool_conv_fwd_ws_floats': [_P, _I, _I, _I],
     't2v_pool_conv_fwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_pool_conv_dgrad': [_P, _I, _I, _I, _P, _P],
+    't2v_pool_conv_dgrad_splits': [_P, _I, _I, _I],
     't2v_pool_conv_wgrad_slab_floats': [_P, _I, _I, _I, _I, _I],
     't2v_pool_conv_wgrad': [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     't2v_pool_conv_wgrad_partial': [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P],

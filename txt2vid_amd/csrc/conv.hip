@@ -1273,11 +1273,35 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     float rb[VECB ? 1 : 3 * LB];
     float4 rbv[VECB ? 3 * LBV : 1];
     const int ncb = K / BKT;
-    const int nrounds = nrow * ncb;
+    // k-split (gridDim.z): split z takes the channel blocks [cb0, cb1) of EVERY kernel row and writes its own set of planes;
+    // pool_unbox_k adds the sets up (launches of a few dozen tiles with K of several hundred are otherwise one workgroup per CU
+    // walking its rounds at memory latency)
+    const int cps = (ncb + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int cb0 = (int)blockIdx.z * cps;
+    const int cbn = (cb0 + cps <= ncb ? cps : ncb - cb0);
+    // kernel rows whose source voxels are out of range for EVERY voxel of this tile (a tile inside the first / last plane of the
+    // padded grid, the rows of a member with a single pooled frame, ...) are skipped whole: 4 workgroup-wide votes up front
+    uint32_t rows_live = 0;
+    for (int r = 0; r < nrow; ++r) {
+        const int rz = r / ndy, ry = r - rz * ndy;
+        const int dz = (tm && ct == 0) ? 2 * rz - 1 : 0, dy = cy == 0 ? 2 * ry - 1 : 0;
+        const int at = s_at + (dz > 0 ? -1 : 0), a = s_a + (dy > 0 ? -1 : 0);
+        const int hat = h_at + (dz > 0 ? -1 : 0), ha = h_a + (dy > 0 ? -1 : 0);
+        const bool v = ((unsigned)at < (unsigned)Dn && (unsigned)a < (unsigned)Hn && s_b < Wn) ||
+                       (halo_thread && (unsigned)hat < (unsigned)Dn && (unsigned)ha < (unsigned)Hn && h_b < Wn);
+        if (__syncthreads_or(v ? 1 : 0)) rows_live |= 1u << r;
+    }
+    uint32_t row_of = 0;                     // live kernel rows, one per byte
+    int nlive_rows = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r < nrow && ((rows_live >> r) & 1u)) { row_of |= (uint32_t)r << (8 * nlive_rows); ++nlive_rows; }
+    const int nrounds = cbn > 0 ? nlive_rows * cbn : 0;
     bool pend_av = false, pend_hv = false;
 
     auto load_round = [&](int q) {
-        const int r_cur = q / ncb, cb = q - r_cur * ncb;
+        const int r_i = q / cbn, cb = cb0 + (q - r_i * cbn);
+        const int r_cur = (int)((row_of >> (8 * r_i)) & 0xffu);
         const int c0 = cb * BKT;
         const int rz = r_cur / ndy, ry = r_cur - rz * ndy;
         const int dz = (tm && ct == 0) ? 2 * rz - 1 : 0, dy = cy == 0 ? 2 * ry - 1 : 0;
@@ -1360,7 +1384,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     if (m < M) {
         const int n = m / Vq, sp = m - n * Vq;
         const size_t plane = (size_t)gd.N * C * Vq;
-        float* p0 = gd.y + (size_t)((ct * 2 + cy) * 2 + 0) * plane + (size_t)n * C * Vq + sp;
+        float* p0 = gd.y + ((size_t)blockIdx.z * 8 + (size_t)((ct * 2 + cy) * 2 + 0)) * plane + (size_t)n * C * Vq + sp;
         float* p1 = p0 + plane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -3860,8 +3884,25 @@ static bool build_pool_dgrad(const t2v_conv_group* groups, int ngroups, int K, i
     for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) { tab.tile_start[i] = (int32_t)mt; tab.out_start[i] = 0; }
     p.tiles = mt * 4 * ((C + 63) / 64);
     p.vecb = (C % 4) == 0;
-    p.S = 1;
+    // k-split over the channel blocks when the launch cannot fill the chip: every split writes its own set of 8 planes
+    long S = 1;
+    const long ncb = K / 32;
+    if (p.tiles < 384 && ncb >= 4) {
+        S = (768 + p.tiles - 1) / p.tiles;
+        if (S > ncb / 2) S = ncb / 2;
+        if (S > 8) S = 8;
+        if (S < 1) S = 1;
+    }
+    p.S = (int)S;
     return true;
+}
+// number of plane SETS t2v_pool_conv_dgrad writes for these members (its k-split count): the caller allocates
+// [S][8][N, C, Dq, Hq, Wq] per member and hands S to t2v_pool_unbox (job.relu), which sums the sets
+extern "C" int t2v_pool_conv_dgrad_splits(const t2v_conv_group* groups, int ngroups, int K, int C) {
+    GroupTable tab;
+    PoolPlan p;
+    if (!build_pool_dgrad(groups, ngroups, K, C, false, tab, p)) return T2V_EINVAL;
+    return p.S;
 }
 extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, int K, int C, const float* wp, void* stream) {
     GroupTable tab;
@@ -3874,10 +3915,10 @@ extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, in
         flops += 2.0 * (double)pool_rows(groups[i]) * K * C * (groups[i].dstride ? 27 : 9);
         Mtot += (long)groups[i].N * pool_grid(groups[i]);
     }
-    ProfScope prof(0, flops, s, Mtot, K, C, 27, ngroups, 1);
-    int32_t plan_[8] = {10, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, 1};
+    ProfScope prof(0, flops, s, Mtot, K, C, 27, ngroups, p.S);
+    int32_t plan_[8] = {10, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
     ProfScope::set_plan(plan_, 8);
-    dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)(4 * ((C + 63) / 64)), 1u);
+    dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)(4 * ((C + 63) / 64)), (unsigned)p.S);
     T2V_LAUNCH_PROF(conv_pool_dgrad_kernel, grid, dim3(256), 0, s, tab, wp, K, C);
     return launch_status();
 }

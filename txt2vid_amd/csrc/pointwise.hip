@@ -2402,39 +2402,44 @@ __global__ __launch_bounds__(256) void pool_boxsum_k(const PoolBoxBatch tb) {
         if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
     const t2v_poolbox_job& q = tb.j[ji];
     const int D = q.D, H = q.H, W = q.W, tm = q.tmode;
-    const int Dp = tm ? D + 1 : 1, Hp = H + 1, Wp = W + 2;
-    const long n = (long)q.NC * Dp * Hp * Wp;
-    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const uint32_t Dp = tm ? D + 1 : 1, Hp = H + 1, Wp = W + 2;
+    const uint32_t n = (uint32_t)q.NC * Dp * Hp * Wp;              // (host: < 2^31; all index arithmetic in 32 bits)
+    const uint32_t base = (uint32_t)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
     const float* __restrict__ x = q.in;
     const float* __restrict__ mk = q.mask;
     const float floor_ = q.relu ? 0.f : -__builtin_inff();
-    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
-        const int xp = (int)(i % Wp); long r = i / Wp;
-        const int yp = (int)(r % Hp); r /= Hp;
-        const int fp = (int)(r % Dp); const long nc = r / Dp;
+    const float scale = q.scale;
+    const int nf = tm == 1 ? 2 : 1;
+#pragma unroll
+    for (int it = 0; it < POOL_CHUNK / 256; ++it) {
+        const uint32_t i = base + it * 256 + threadIdx.x;
+        if (i >= n) break;
+        const uint32_t r0 = i / Wp, xp = i - r0 * Wp;
+        const uint32_t r1 = r0 / Hp, yp = r0 - r1 * Hp;
+        const uint32_t nc = r1 / Dp, fp = r1 - nc * Dp;
         float acc = 0.f;
-        if (xp <= W) {
-            const int f0 = tm == 0 ? 0 : fp - 1, nf = tm == 1 ? 2 : 1;
+        if (xp <= (uint32_t)W) {
+            const int f0 = tm == 0 ? 0 : (int)fp - 1;
+            const bool y0 = yp >= 1, y1 = yp < (uint32_t)H, x0 = xp >= 1, x1 = xp < (uint32_t)W;
             for (int a = 0; a < nf; ++a) {
                 const int f = f0 + a;
                 if ((unsigned)f >= (unsigned)D) continue;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int y = yp - 1 + b;
-                    if ((unsigned)y >= (unsigned)H) continue;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int xx = xp - 1 + c;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const long o = ((nc * D + f) * H + y) * (long)W + xx;
-                        float v = x[o];
-                        if (mk) v = mk[o] > 0.f ? v : 0.f;
-                        acc += fmaxf(v, floor_);
-                    }
+                const uint32_t o = ((nc * D + f) * H + (yp - 1)) * W + (xp - 1);        // (y - 1, x - 1): the window's first corner
+                float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+                if (y0 && x0) v00 = x[o];
+                if (y0 && x1) v01 = x[o + 1];
+                if (y1 && x0) v10 = x[o + W];
+                if (y1 && x1) v11 = x[o + W + 1];
+                if (mk) {
+                    if (y0 && x0) v00 = mk[o] > 0.f ? v00 : 0.f;
+                    if (y0 && x1) v01 = mk[o + 1] > 0.f ? v01 : 0.f;
+                    if (y1 && x0) v10 = mk[o + W] > 0.f ? v10 : 0.f;
+                    if (y1 && x1) v11 = mk[o + W + 1] > 0.f ? v11 : 0.f;
                 }
+                acc += (fmaxf(v00, floor_) + fmaxf(v01, floor_)) + (fmaxf(v10, floor_) + fmaxf(v11, floor_));
             }
         }
-        q.out[i] = acc * q.scale;
+        q.out[i] = acc * scale;
     }
 }
 
@@ -2444,34 +2449,42 @@ __global__ __launch_bounds__(256) void pool_unbox_k(const PoolBoxBatch tb) {
     for (int k = 1; k < POOL_MT; ++k)
         if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
     const t2v_poolbox_job& q = tb.j[ji];
-    const int D = q.D, H = q.H, W = q.W, tm = q.tmode;
-    const int Dq = tm ? D / 2 + 1 : 1, Hq = H / 2 + 1, Wq = W / 2 + 1;
-    const long n = (long)q.NC * D * H * W;
-    const long plane = (long)q.NC * Dq * Hq * Wq;
-    const long base = (long)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const uint32_t D = q.D, H = q.H, W = q.W;
+    const int tm = q.tmode;
+    const uint32_t Dq = tm ? D / 2 + 1 : 1, Hq = H / 2 + 1, Wq = W / 2 + 1;
+    const uint32_t n = (uint32_t)q.NC * D * H * W;
+    const uint32_t plane = (uint32_t)q.NC * Dq * Hq * Wq;          // (host: 8 * sets * plane < 2^31)
+    const int sets = q.relu > 1 ? q.relu : 1;                     // plane sets to add up (the data-gradient GEMM's k-split)
+    const uint32_t base = (uint32_t)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
     const float* __restrict__ pl = q.in;
     const float* __restrict__ mk = q.mask;
-    for (long i = base + threadIdx.x; i < base + POOL_CHUNK && i < n; i += 256) {
-        const int xx = (int)(i % W); long r = i / W;
-        const int y = (int)(r % H); r /= H;
-        const int f = (int)(r % D); const long nc = r / D;
+    const int nf = tm == 1 ? 2 : 1;
+#pragma unroll
+    for (int it = 0; it < POOL_CHUNK / 256; ++it) {
+        const uint32_t i = base + it * 256 + threadIdx.x;
+        if (i >= n) break;
+        const uint32_t r0 = i / W, xx = i - r0 * W;
+        const uint32_t r1 = r0 / H, y = r0 - r1 * H;
+        const uint32_t nc = r1 / D, f = r1 - nc * D;
+        const bool keep = mk ? mk[i] > 0.f : true;
         float acc = 0.f;
-        const int nf = tm == 1 ? 2 : 1;
-        for (int a = 0; a < nf; ++a) {
-            const int pt = tm == 0 ? 0 : f + 1 - a;            // padded time index of r~ this voxel contributed to
-            const int ct = pt & 1, at = pt >> 1;
+        if (keep) {
+            for (int a = 0; a < nf; ++a) {
+                const uint32_t pt = tm == 0 ? 0u : f + 1 - a;         // padded time index of r~ this voxel contributed to
+                const uint32_t ct = pt & 1u, at = pt >> 1;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int py = y + 1 - b, cy = py & 1, ay = py >> 1;
+                for (int b = 0; b < 2; ++b) {
+                    const uint32_t py = y + 1 - b, cy = py & 1u, ay = py >> 1;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int px = xx + 1 - c, cx = px & 1, ax = px >> 1;
-                    acc += pl[(long)((ct * 2 + cy) * 2 + cx) * plane + ((nc * Dq + at) * Hq + ay) * (long)Wq + ax];
+                    for (int c = 0; c < 2; ++c) {
+                        const uint32_t px = xx + 1 - c, cx = px & 1u, ax = px >> 1;
+                        const uint32_t o = ((ct * 2 + cy) * 2 + cx) * plane + ((nc * Dq + at) * Hq + ay) * Wq + ax;
+                        for (int s_ = 0; s_ < sets; ++s_) acc += pl[o + (uint32_t)s_ * 8u * plane];
+                    }
                 }
             }
         }
-        const bool keep = mk ? mk[i] > 0.f : true;
-        const float bv = q.bias ? q.bias[nc % q.C] : 0.f;
+        const float bv = q.bias ? q.bias[nc % (uint32_t)q.C] : 0.f;
         q.out[i] = keep ? acc * q.scale + bv : 0.f;
     }
 }
@@ -2491,6 +2504,9 @@ static int poolbox_multi(const t2v_poolbox_job* jobs, int njobs, bool unbox, voi
             tb.begin[i] = (int)blocks;
             const long n = unbox ? (long)q.NC * q.D * q.H * q.W
                                  : (long)q.NC * (q.tmode ? q.D + 1 : 1) * (q.H + 1) * (q.W + 2);
+            const long sets = unbox && q.relu > 1 ? q.relu : 1;
+            if (n >= (1L << 31) || (unbox && 8 * sets * (long)q.NC * (q.tmode ? q.D / 2 + 1 : 1) * (q.H / 2 + 1) * (q.W / 2 + 1) >= (1L << 31)))
+                return T2V_EINVAL;                                   // 32-bit element indices inside the kernels
             blocks += (n + POOL_CHUNK - 1) / POOL_CHUNK;
         }
         for (int i = cnt; i <= POOL_MT; ++i) tb.begin[i] = (int)blocks;

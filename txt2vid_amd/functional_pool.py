@@ -66,13 +66,14 @@ def pooled_shape(shape, tmode):
 # ------------------------------------------------------------------------------------------------
 
 def _box_jobs(ins, masks, outs, shapes, tmodes, relu, scale=None, bias=None):
+    """`relu`: boxsum: clamp the input at 0; unbox: the number of plane sets to add up."""
     arr = (PoolBoxJob * len(ins))()
     for a, t, sh, tm, i in zip(arr, ins, shapes, tmodes, range(len(ins))):
         a.in_, a.out = t.data_ptr(), outs[i].data_ptr()
         a.mask = masks[i].data_ptr() if masks is not None else None
         a.bias = bias.data_ptr() if bias is not None else None
         a.NC, a.D, a.H, a.W, a.C = sh[0] * sh[1], sh[2], sh[3], sh[4], sh[1]
-        a.tmode, a.relu, a.scale = tm, 1 if relu else 0, pool_scale(tm) if scale is None else scale
+        a.tmode, a.relu, a.scale = tm, int(relu), pool_scale(tm) if scale is None else scale
     return arr
 
 
@@ -93,7 +94,8 @@ def unbox_raw(planes, shapes, tmodes, masks=None, scale=None, bias=None):
     `bias`: a per-channel constant added on top (the up-sampling form's convolution bias)."""
     masks = [_c(m) for m in masks] if masks is not None else None
     outs = [torch.empty(tuple(sh), device=p.device, dtype=torch.float32) for p, sh in zip(planes, shapes)]
-    check(lib().t2v_pool_unbox(_box_jobs(planes, masks, outs, shapes, tmodes, False, scale, bias), len(planes), _stream()), 't2v_pool_unbox')
+    sets = planes[0].shape[0] if planes[0].dim() == 7 else 1
+    check(lib().t2v_pool_unbox(_box_jobs(planes, masks, outs, shapes, tmodes, sets, scale, bias), len(planes), _stream()), 't2v_pool_unbox')
     return outs
 
 
@@ -154,7 +156,8 @@ def pool_fwd_raw(rts, shapes, tmodes, w5, bias=None, transpose=False):
 
 
 def pool_dgrad_raw(gzs, shapes, tmodes, w5, transpose=False):
-    """The 8 parity-class planes [8, N, Cin, Dq, H/2+1, W/2+1] of the data gradient on the padded grid, from dL/dy (pooled shape).
+    """The parity-class planes [S, 8, N, Cin, Dq, H/2+1, W/2+1] of the data gradient on the padded grid, from dL/dy (pooled shape);
+    S = the launch's k-split count (`unbox_raw` adds the S sets up).
     `transpose`: contract over the weight's INPUT channels instead (mode-0 packing): the class planes of `conv3(zero-stuffed x)`,
     i.e. the forward of the up-sampling form (then `gzs` are the small maps and the planes have Cout channels)."""
     TF = _TF()
@@ -163,19 +166,24 @@ def pool_dgrad_raw(gzs, shapes, tmodes, w5, transpose=False):
     cout, cin = (w5.shape[1], w5.shape[0]) if transpose else (w5.shape[0], w5.shape[1])          # (K of the GEMM, channels of the planes)
     ts = _tap_union(tmodes, w5.shape[2])
     slot_of = {t: j for j, t in enumerate(ts.taps)}
-    planes = [torch.empty((8, sh[0], cin, sh[2] // 2 + 1 if tm else 1, sh[3] // 2 + 1, sh[4] // 2 + 1), device=g.device, dtype=torch.float32)
-              for g, sh, tm in zip(gzs, shapes, tmodes)]
     arr = (ConvGroup * len(gzs))()
-    for a, g, pl, sh, tm in zip(arr, gzs, planes, shapes, tmodes):
+    for a, g, sh, tm in zip(arr, gzs, shapes, tmodes):
         if tuple(g.shape) != (sh[0], cout) + pooled_shape(sh, tm)[1:]:
             raise ValueError('pooled gradient of shape %s for a member of shape %s' % (tuple(g.shape), tuple(sh)))
-        a.x, a.y, a.mask = g.data_ptr(), pl.data_ptr(), None
+        a.x, a.y, a.mask = g.data_ptr(), None, None
         a.N, a.D, a.H, a.W = sh[0], sh[2], sh[3], sh[4]
         a.dstride, a.ntaps = tm, 27
         for f in range(27):                                       # the kernel numbers its taps f = ((dz+1)*3 + dy+1)*3 + dx+1
             # mode-1 packing stores forward tap f in the slot of its mirror; in the transposed (mode-0) role the class structure
             # itself asks for the mirrored tap: the same index either way
             a.widx[f] = slot_of.get(26 - f, -1) if ts.T == 27 else (slot_of.get(8 - (f - 9), -1) if 9 <= f < 18 else -1)
+    S = int(lib().t2v_pool_conv_dgrad_splits(arr, len(gzs), cout, cin))           # k-split: S sets of planes, summed by the unbox pass
+    if S < 1:
+        raise RuntimeError('bad pooled data-gradient geometry')
+    planes = [torch.empty((S, 8, sh[0], cin, sh[2] // 2 + 1 if tm else 1, sh[3] // 2 + 1, sh[4] // 2 + 1), device=g.device, dtype=torch.float32)
+              for g, sh, tm in zip(gzs, shapes, tmodes)]
+    for a, pl in zip(arr, planes):
+        a.y = pl.data_ptr()
     wp = TF.packed_weight(w5, ts, 0 if transpose else 1)
     check(lib().t2v_pool_conv_dgrad(arr, len(gzs), cout, cin, _p(wp), _stream()), 't2v_pool_conv_dgrad')
     return planes
@@ -390,10 +398,16 @@ class UpConvFn(Function):
         cout = w.shape[0]
         w5 = w.unsqueeze(2)
         full = (N, cout, 1, 2 * h, 2 * w_)                      # the up-sampled geometry ("full resolution" of the pooled kernels)
-        planes = pool_dgrad_raw([x.unsqueeze(2)], [(N, cin, 1, 2 * h, 2 * w_)], [0], w5, transpose=True)
-        y = unbox_raw(planes, [full], [0], scale=1.0, bias=b)[0]
         ctx.save_for_backward(x, w)
         ctx.bias = b
+        if min(h, w_) < 4:
+            # tiny maps: the class planes live on a padded (h+1) x (w+1) grid whose border rows multiply zeros — at 1x1 / 2x2 that is
+            # as much work as the plain convolution of the up-sampled map, which has no second pass: forward the plain way (the
+            # backward below never needs the up-sampled tensor either way)
+            TF = _TF()
+            return TF.conv_fwd_raw(TF.Upsample2x.apply(x).unsqueeze(2), w5, b).squeeze(2)
+        planes = pool_dgrad_raw([x.unsqueeze(2)], [(N, cin, 1, 2 * h, 2 * w_)], [0], w5, transpose=True)
+        y = unbox_raw(planes, [full], [0], scale=1.0, bias=b)[0]
         return y.squeeze(2)
 
     @staticmethod
