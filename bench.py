@@ -135,7 +135,7 @@ def extra_record(flags):
     """Run `python bench.py <flags>` as a child (no CPU baseline, no roofline passes) and return the fields of its JSON line that
     identify and size the measurement; an error string if it failed."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_roofline', '--no_d_roofline', '--no_extra']
+    cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_roofline', '--no_d_roofline', '--no_extra', '--no_hbm']
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         line = [l for l in p.stdout.decode(errors='replace').splitlines() if l.startswith('{')]
@@ -192,6 +192,101 @@ def per_tile_breakdown(path, steps, peak, kind):
     return out
 
 
+class _Run(object):
+    pass
+
+
+def timed_run(args, cond, size, channels, steps, warmup, rank, world, dev, log, prof_eager=False):
+    """Build the models of one workload (current conv precision), warm up (2 eager iterations + graph capture), then time exactly
+    `steps` iterations between barrier + synchronize pairs. Returns the objects the roofline passes need plus `dt` (this rank's
+    wall time of the timed region), the final losses and — for world > 1 — the event-timed gradient exchanges."""
+    from txt2vid_amd import dist as tdist
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd._lib import lib
+    import torch.distributed as dist
+    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
+    R = _Run()
+    gen, dis, optD, optG, losses, CondGan = build_models(dev, cond=cond, size=size, channels=channels)
+    txt = tokens = None
+    if cond:                    # Bi-LSTM sentence encoder (random init) + 8-token synthetic captions
+        from txt2vid_amd.data import Vocab
+        from txt2vid_amd.models.txt.basic import Seq2Seq
+        from txt2vid_amd.util.torch.init import init
+        txt = Seq2Seq(vocab_size=len(Vocab()))
+        init(txt, 'xavier')
+        txt.to(dev)
+        tokens = torch.randint(4, len(Vocab()), (args.batch, 8)).to(dev)
+    gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'], gp_scale=float(world))
+    grad_sync = None
+    if world > 1:
+        arenas = {'D': tdist.model_arena(dis, TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
+        grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
+    prm = Params()
+    prm.frame_sizes = [size // 8, size // 4, size // 2, size]
+    pool = synthetic_batches(args.batch, 4, 100 + rank, dev, size, channels)
+    random.seed(100 + rank)
+    np.random.seed(100 + rank)
+    torch.manual_seed(100 + rank)
+
+    graphed = None
+    if not args.eager:
+        graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2,
+                                   cond_dim=256 if cond else 0)
+    graphed_txt = None
+    if txt is not None and not args.eager:
+        from txt2vid_amd.gan.trainer import GraphedSentenceEncoder
+        graphed_txt = GraphedSentenceEncoder(txt, dev)
+
+    def sentence_codes():            # part of every iteration: its own HIP graph per caption length (lengths vary in real data)
+        if txt is None:
+            return None
+        if graphed_txt is not None:
+            return graphed_txt.encode(tokens, [8] * args.batch)
+        return txt.encode(tokens, [8] * args.batch)[2].detach()
+
+    def step(i):
+        if graphed is not None:
+            return graphed.step(pool[i % len(pool)], sentence_codes()) + (None, None)
+        return train_iteration(gan, pool[i % len(pool)], sentence_codes(), optD, optG, losses, prm, dev, grad_sync=grad_sync)
+
+    if graphed is not None and warmup < 3:
+        warmup = 3                           # 2 eager iterations + the capture must precede the timed region
+    log('models + data ready; warm-up')
+    for i in range(warmup):
+        step(i)
+        torch.cuda.synchronize()
+        log('warm-up step %d done' % i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    R.prof_in_region = prof_eager and graphed is None        # eager launches: events bracket them inside the timed region
+    barrier()
+    if R.prof_in_region:
+        lib().t2v_prof_begin(min(1 << 16, 4096 * steps))
+        log('instrumentation ready')
+    if grad_sync is not None:
+        grad_sync.time_exchanges(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lD, lG, _, _ = step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    R.dt = time.perf_counter() - t0
+    R.exchange = None
+    if grad_sync is not None:
+        R.exchange = grad_sync.exchange_ms()
+        grad_sync.time_exchanges(False)
+    R.lD, R.lG = float(lD), float(lG)
+    R.gan, R.optD, R.optG, R.losses, R.prm, R.pool, R.graphed, R.grad_sync, R.txt = gan, optD, optG, losses, prm, pool, graphed, grad_sync, txt
+    R.sentence_codes, R.warmup = sentence_codes, warmup
+    return R
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -209,6 +304,7 @@ def main():
     ap.add_argument('--size', type=int, default=64, choices=(64, 128), help='frame side; 128 with --channels 3 --cond --bf16 --batch 16 '
                                                                           '= the per-GPU share of BASELINE configs[4] (MSRVDC shape)')
     ap.add_argument('--channels', type=int, default=1, choices=(1, 3))
+    ap.add_argument('--no_hbm', action='store_true', help='skip the HBM-bound kernels block')
     ap.add_argument('--no_extra', action='store_true', help='skip the extra BASELINE configs[2] record (text-conditioned, bf16 compute) of the default run')
     args = ap.parse_args()
 
@@ -236,84 +332,18 @@ def main():
     dev = torch.device('cuda', local)
 
     T0 = time.perf_counter()
-    gen, dis, optD, optG, losses, CondGan = build_models(dev, cond=args.cond, size=args.size, channels=args.channels)
-    txt = tokens = None
-    if args.cond:                    # Bi-LSTM sentence encoder (random init) + 8-token synthetic captions
-        from txt2vid_amd.data import Vocab
-        from txt2vid_amd.models.txt.basic import Seq2Seq
-        from txt2vid_amd.util.torch.init import init
-        txt = Seq2Seq(vocab_size=len(Vocab()))
-        init(txt, 'xavier')
-        txt.to(dev)
-        tokens = torch.randint(4, len(Vocab()), (args.batch, 8)).to(dev)
-    gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'], gp_scale=float(world))
-    grad_sync = None
-    if world > 1:
-        arenas = {'D': tdist.model_arena(dis, TF.copy_into), 'G': tdist.model_arena(gen, TF.copy_into)}
-        grad_sync = tdist.make_grad_sync(arenas, {'D': optD, 'G': optG}, world)
-    prm = Params()
-    prm.frame_sizes = [args.size // 8, args.size // 4, args.size // 2, args.size]
-    pool = synthetic_batches(args.batch, 4, 100 + rank, dev, args.size, args.channels)
-    random.seed(100 + rank)
-    np.random.seed(100 + rank)
-    torch.manual_seed(100 + rank)
-
-    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
-
-    graphed = None
-    if not args.eager:
-        graphed = GraphedTrainStep(gan, optD, optG, losses, prm, dev, tuple(pool[0].shape), grad_sync=grad_sync, warmup=2,
-                                   cond_dim=256 if args.cond else 0)
-
-    graphed_txt = None
-    if txt is not None and not args.eager:
-        from txt2vid_amd.gan.trainer import GraphedSentenceEncoder
-        graphed_txt = GraphedSentenceEncoder(txt, dev)
-
-    def sentence_codes():            # part of every iteration: its own HIP graph per caption length (lengths vary in real data)
-        if txt is None:
-            return None
-        if graphed_txt is not None:
-            return graphed_txt.encode(tokens, [8] * args.batch)
-        return txt.encode(tokens, [8] * args.batch)[2].detach()
-
-    def step(i):
-        if graphed is not None:
-            return graphed.step(pool[i % len(pool)], sentence_codes()) + (None, None)
-        return train_iteration(gan, pool[i % len(pool)], sentence_codes(), optD, optG, losses, prm, dev, grad_sync=grad_sync)
 
     def log(msg):
         if rank == 0:
             sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - T0, msg))
             sys.stderr.flush()
 
-    if graphed is not None and args.warmup < 3:
-        args.warmup = 3                      # 2 eager iterations + the capture must precede the timed region
-    log('models + data ready; warm-up')
-    for i in range(args.warmup):
-        step(i)
-        torch.cuda.synchronize()
-        log('warm-up step %d done' % i)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     prof = not args.no_roofline
-    prof_in_region = prof and graphed is None        # eager launches: events bracket them inside the timed region
-    barrier()
-    if prof_in_region:
-        lib().t2v_prof_begin(min(1 << 16, 4096 * args.steps))
-        log('instrumentation ready')
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        lD, lG, _, _ = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    R = timed_run(args, args.cond, args.size, args.channels, args.steps, args.warmup, rank, world, dev, log, prof_eager=prof)
+    args.warmup = R.warmup
+    gan, optD, optG, losses, prm, pool, graphed, grad_sync, txt = R.gan, R.optD, R.optG, R.losses, R.prm, R.pool, R.graphed, R.grad_sync, R.txt
+    sentence_codes, dt, lD, lG, prof_in_region = R.sentence_codes, R.dt, R.lD, R.lG, R.prof_in_region
+    from txt2vid_amd.gan.trainer import train_iteration
     log('timed region done: %.1f ms/step' % (dt / args.steps * 1e3))
     lD, lG = float(lD), float(lG)
     roof = None
@@ -415,6 +445,16 @@ def main():
     }
     if grad_sync is not None:
         res['config']['grad_exchange_mb_per_step'] = sum(a.exchanged_bytes() for a in grad_sync.arenas.values()) / 1e6
+        # the two per-step collectives (D gradients, G gradients), event-timed on the issuing stream inside the timed region,
+        # max over ranks; `rccl_ranks` = ranks of the process group when its backend is nccl (= RCCL on ROCm), else 0
+        ex = R.exchange or {'D': 0.0, 'G': 0.0, 'n': 0}
+        tx = torch.tensor([ex['D'], ex['G']], device=dev, dtype=torch.float64)
+        dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+        res['allreduce_ms_per_step'] = float(tx.sum().item()) / args.steps
+        res['allreduce'] = {'D_ms_per_step': float(tx[0].item()) / args.steps, 'G_ms_per_step': float(tx[1].item()) / args.steps,
+                            'collectives_per_step': ex['n'] / args.steps, 'backend': dist.get_backend(),
+                            'overlap': 'none: D\'s Adam needs every reduced D gradient before the next kernel, G\'s likewise (DESIGN §6)'}
+        res['rccl_ranks'] = dist.get_world_size() if dist.get_backend() == 'nccl' else 0
     if roof is not None:
         if gf:
             # the REFERENCE-executed FLOP of the iteration (what the reference's kernels compute, incl. the ConvLSTM's dead
@@ -435,6 +475,45 @@ def main():
         # same line: measured by a child process after this one's timed region, never part of `value`
         log('extra record: BASELINE configs[2] (child process)')
         res['extra_records'] = {'configs[2]': extra_record(['--cond', '--bf16', '--batch', str(args.batch), '--steps', '10', '--warmup', '3'])}
+    if rank == 0 and world == 1 and prof and not args.no_hbm and default_shape and not args.cond and not bf16:
+        # the HBM-bound sub-operations, each in isolation at the benchmark's shapes: GB/s on algorithmic bytes vs ~8 TB/s
+        from txt2vid_amd.util.roofline import hbm_bound_lines
+        log('HBM-bound kernels in isolation')
+        try:
+            res['hbm_bound'] = hbm_bound_lines(device=dev, batch=args.batch)
+            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')
+            if os.path.exists(pmc):
+                res['hbm_bound']['pmc'] = 'profiles/r03_pmc_hbm.json (rocprofv3 FETCH_SIZE / WRITE_SIZE per launch of the same micro-benchmark)'
+        except Exception as e:                                    # never let a side measurement take the headline down
+            res['hbm_bound'] = {'error': repr(e)[:300]}
+    if world > 1 and not args.no_extra and not args.cond and not bf16 and default_shape and not args.eager:
+        # BASELINE configs[3] (the scaling config: text-conditioned, bf16 compute, per-GPU batch 32, RCCL data parallel) as an EXTRA
+        # record beside the configs[1] value: the same ranks, after the headline's timed region — never part of `value`
+        log('extra record: BASELINE configs[3] on the same %d ranks' % world)
+        del R, gan, optD, optG, graphed, grad_sync, pool
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        rec = None
+        try:
+            TF.set_conv_precision('bf16')
+            R3 = timed_run(args, True, args.size, args.channels, 10, 3, rank, world, dev, lambda m: log('[configs[3]] ' + m))
+            t3 = torch.tensor([R3.dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            ex3 = torch.tensor([R3.exchange['D'], R3.exchange['G']], device=dev, dtype=torch.float64)
+            dist.all_reduce(ex3, op=dist.ReduceOp.MAX)
+            dt3 = float(t3.item())
+            rec = {'value': gb * 10 / dt3, 'unit': 'videos/s', 'ms_per_step': dt3 / 10 * 1e3, 'steps': 10, 'warmup': R3.warmup, 'n_gpus': world,
+                   'dtype': 'bf16 compute, f32 storage + accumulation (pooled conv2 layers: fp32 GEMMs)',
+                   'allreduce_ms_per_step': float(ex3.sum().item()) / 10,
+                   'config': {'workload': 'BASELINE configs[3]: text-conditioned TGANv2 16x64x64x1, per-GPU batch %d, bf16 compute, data parallel '
+                                          'over %d ranks' % (args.batch, world), 'global_batch': gb, 'parallelism': 'dp%d' % world},
+                   'final_losses': {'lossD': R3.lD, 'lossG': R3.lG}}
+        except Exception as e:
+            rec = {'error': repr(e)[:300]}
+        finally:
+            TF.set_conv_precision('fp32')
+        res.setdefault('extra_records', {})['configs[3]'] = rec
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

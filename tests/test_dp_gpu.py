@@ -44,6 +44,7 @@ def test_bench_starts_its_own_ranks():
     ranks itself as a child torch.distributed.run before touching the GPU, relays rank 0's JSON line and exit code.
     Rehearsed here with gloo and both ranks on device 0 (one GPU per lease); over RCCL when the box has two GPUs."""
     import json
+    import numpy as np
     import torch
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if torch.cuda.device_count() < 2:
@@ -58,6 +59,13 @@ def test_bench_starts_its_own_ranks():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 16 and res['scaling'] == 'weak'
     assert res['config']['grad_exchange_mb_per_step'] > 100          # D 116 MB + G's live 76 MB
+    # the two per-step collectives are event-timed inside the timed region; `rccl_ranks` says whether they ran over RCCL
+    assert res['allreduce_ms_per_step'] > 0 and res['allreduce']['collectives_per_step'] >= 2
+    assert res['rccl_ranks'] == (2 if torch.cuda.device_count() >= 2 else 0)
+    # BASELINE's scaling config (configs[3]: text-conditioned, bf16 compute) rides along as an extra record on the same ranks
+    c3 = res['extra_records']['configs[3]']
+    assert 'error' not in c3, c3
+    assert c3['n_gpus'] == 2 and c3['value'] > 0 and c3['allreduce_ms_per_step'] > 0 and np.isfinite(c3['final_losses']['lossD'])
     assert res['value'] > 0 and res['steps'] == 2
 
 

@@ -732,7 +732,10 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
     bf_fwd, bf_wg = cc.all_checked_bf16_variants()
     checked_fwd = set(cc.all_checked_fwd_variants())
     checked_wgrad = set(cc.all_checked_wgrad_variants())
-    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3'}        # (no pooled form in bf16-compute mode)
+    pool_fwd, pool_wg = cc.all_checked_pool_variants()
+    checked_fwd |= set(pool_fwd)
+    checked_wgrad |= set(pool_wg)
+    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad'}
     launched = set()
     rows = dump.read_text().strip().splitlines()[1:]
     assert len(rows) > 150
@@ -748,7 +751,7 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
             key = (kinds[plan[0]],) + tuple(plan[1:7])
             assert key in checked_fwd, key
         elif kind == 1:
-            name = ('taps', 'cols', 'rows3')[plan[0]]
+            name = {0: 'taps', 1: 'cols', 2: 'rows3', 11: 'pool_rows3'}[plan[0]]
             if plan[6] == 1:
                 key = (name, 1, plan[7])
                 assert key in bf_wg, ('bf16 weight-gradient launch covered by no BF16_CASES entry', key, line)
@@ -758,7 +761,9 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
         else:
             continue
         launched.add(key)
-    assert ('strip3_bf16', 128, 1) in launched and ('rows3', 1, 1) in launched      # the stem conv2's frame-strided forms did run
+    # bf16-compute mode keeps the un-pooled layers (the pooled form is fp32-only and measured slower than un-pooled bf16): the stem
+    # conv2's frame-strided bf16 forms did run
+    assert ('strip3_bf16', 128, 1) in launched and ('rows3', 1, 1) in launched and not any(k[0].startswith('pool') for k in launched)
     print('B=32 bf16: %d convolution launches on %d instantiations, all covered' % (len(rows), len(launched)))
 
 

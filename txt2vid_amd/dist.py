@@ -220,11 +220,35 @@ class GradSync(object):
 
     def __init__(self, arenas, optimizers, world):
         self.arenas, self.optimizers, self.world = arenas, optimizers, world
+        self.timing = None                  # list of (which, start event, end event) while `time_exchanges(True)`
 
     def pre(self, which):
         self.arenas[which].gather()
 
+    def time_exchanges(self, on=True):
+        """Bracket every exchange with a pair of events on the stream that issues it (bench.py: `allreduce_ms_per_step`). The
+        collective runs on the backend's own stream between two waits on this one, so the pair spans exactly what the iteration
+        waits for."""
+        self.timing = [] if on else None
+
+    def exchange_ms(self):
+        """Total milliseconds of the exchanges recorded since `time_exchanges(True)`, per model: {'D': ms, 'G': ms, 'n': exchanges}."""
+        out = {'D': 0.0, 'G': 0.0, 'n': 0}
+        for which, e0, e1 in self.timing or ():
+            e1.synchronize()
+            out[which] = out.get(which, 0.0) + e0.elapsed_time(e1)
+            out['n'] += 1
+        return out
+
     def exchange(self, which):
+        flat = self.arenas[which].flat
+        if self.timing is not None and flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.arenas[which].all_reduce()
+            e1.record()
+            self.timing.append((which, e0, e1))
+            return
         self.arenas[which].all_reduce()
 
     def post(self, which):

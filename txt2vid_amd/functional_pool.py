@@ -21,6 +21,7 @@ from ._lib import lib, check, ConvGroup, PoolBoxJob, WgradSrc, MAX_GROUPS
 from ._ops import _stream, _p, _c
 
 _DISABLED = os.environ.get('T2V_NO_POOLCONV') is not None        # developer A/B switch: the un-pooled path everywhere
+_NO_UPCONV = os.environ.get('T2V_NO_UPCONV') is not None         # developer A/B switch: UpBlocks up-sample, then convolve
 
 
 def _TF():
@@ -47,7 +48,8 @@ def pool_scale(tmode):
 
 def pool_conv_ok(xs, w, stem):
     """True when `pool_conv_group` takes these members: 3x3x3 kernel, channels a multiple of 32, even H / W >= 2, D == 1 or even,
-    fp32 mode (the bf16-compute kernels have no strided form)."""
+    fp32 mode. (bf16-compute mode keeps the un-pooled layers: measured, the pooled fp32 GEMMs + their two streaming passes lose to
+    the un-pooled bf16 GEMMs — 10.1 vs 9.4 ms per iteration; a bf16 form of the pooled kernels is the open item there.)"""
     TF = _TF()
     if _DISABLED or TF.CONV_PRECISION != 'fp32' or not (1 <= len(xs) <= MAX_GROUPS) or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
         return False
@@ -384,7 +386,7 @@ def pool_conv_group(xs, w, b=None, relu_in=True, stem=False):
 
 def up_conv_ok(x, w):
     TF = _TF()
-    return (not _DISABLED and TF.CONV_PRECISION == 'fp32' and x.dim() == 4 and x.is_cuda and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    return (not _DISABLED and not _NO_UPCONV and TF.CONV_PRECISION == 'fp32' and x.dim() == 4 and x.is_cuda and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
             and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
 
 

@@ -64,3 +64,86 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
             'all_in': {'wall_ms': wall * 1e3, 'tflops': flops / wall / 1e12, 'frac_of_fp32_mfma_peak': flops / wall / 1e12 / P,
                        'videos_per_s': batch / wall},
             'peak_tflops': P}
+
+
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_bound_lines(device=None, batch=32, iters=20):
+    """The HBM-bound sub-operations of the iteration, each timed in isolation at the benchmark's shapes with
+    events on the launch stream: achieved GB/s on the ALGORITHMIC bytes (what a single streaming pass must move) against the
+    ~8 TB/s of HBM3E. {name: {bytes, us, achieved GB/s, frac}}. These kernels launch on torch's current stream, so torch events
+    bracket them."""
+    from .. import functional as TF
+    from ..functional_pool import boxsum_raw, unbox_raw, pool_dgrad_raw
+    dev = device or torch.device('cuda', torch.cuda.current_device())
+    out = {}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3          # us per call
+
+    def line(name, nbytes, us, what):
+        out[name] = {'algorithmic_bytes': int(nbytes), 'us': us, 'achieved': nbytes / us / 1e3, 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
+                     'frac': nbytes / us / 1e3 / PEAK_HBM_GBS, 'what': what}
+
+    g = torch.Generator(device='cpu')
+    g.manual_seed(5)
+    # ---- Adam: the discriminator's 29 M parameters as 64 tensors, one multi-tensor launch (read p, g, m, v; write p, m, v)
+    n_each = 29_040_000 // 64
+    items = [tuple(torch.randn(n_each, generator=g).to(dev) for _ in range(4)) for _ in range(64)]
+    for it in items:
+        it[3].abs_()
+    us = timed(lambda: TF.adam_step_multi(items, 2e-4, 0.5, 0.999, 1e-8, 3))
+    line('adam_multi_k', 64 * n_each * 28, us, 'Adam on 29.0 M parameters (64 tensors, one launch): 28 B per parameter')
+    del items
+    # ---- weight repack: [512,256,3,3,3] -> wp[27][256][512]
+    w = torch.randn(512, 256, 3, 3, 3, generator=g).to(dev)
+    geom = TF.conv_geom(1, 256, 4, 4, 4, 512, 3, 3, 3)
+    wp = torch.empty((27, 256 * 512), device=dev)
+    us = timed(lambda: TF.check(TF.lib().t2v_pack_weight(TF._p(w), TF._p(wp), 512, 256, 27, geom.taps_c, 27, 0, TF._stream()), 'pack'))
+    line('pack_weight_kernel', w.numel() * 8, us, 'repack of a [512,256,3,3,3] weight (read 4 B + write 4 B per weight)')
+    del w, wp
+    # ---- BatchNorm2d forward (training statistics + apply + ReLU) on the generator's [512,128,8,8] map
+    x = torch.randn(batch * 16, 128, 8, 8, generator=g).to(dev)
+    gam, bet = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    rm, rv = torch.zeros(128, device=dev), torch.ones(128, device=dev)
+    us = timed(lambda: TF.batch_norm_act(x, gam, bet, rm, rv, True, 0.1, 1e-5, True))
+    line('bn_train_fwd', x.numel() * 12, us, 'BatchNorm2d + ReLU, training mode, [%d,128,8,8]: statistics pass (4 B read) + apply pass (4 B read + 4 B write)' % (batch * 16))
+    del x
+    # ---- the Cin = 1 stem convolution over the 8 discriminator-step members (reads 4 B, writes 64 x 4 B per voxel)
+    lv = [(2 * batch >> l if l else 2 * batch, 16 >> l, 8 << l) for l in range(4)]
+    members = [(max(1, (2 * batch) >> l), 16 >> l, 8 << l) for l in range(4)] + [(max(1, batch >> l), 16 >> l, 8 << l) for l in range(4)]
+    xs = [torch.randn(n, 1, d, s, s, generator=g).to(dev) for n, d, s in members]
+    w1 = torch.randn(64, 1, 3, 3, 3, generator=g).to(dev) * 0.1
+    b1 = torch.zeros(64, device=dev)
+    M = sum(t.numel() for t in xs)
+    us = timed(lambda: TF.conv_group_raw(xs, w1, b1, False, 0))
+    line('stem_conv1_cin1', M * (4 + 256), us, 'stem conv 1->64, 3x3x3, the 8 D-step members (M = %d voxels): 4 B read + 256 B written per voxel' % M)
+    # ---- RenderBlock convolution ch -> 1 (thin kernel): [16,32,64,64]
+    xr = torch.randn(max(1, batch // 8) * 2 * 2, 32, 1, 64, 64, generator=g).to(dev)
+    wr = torch.randn(1, 32, 1, 3, 3, generator=g).to(dev) * 0.1
+    us = timed(lambda: TF.conv_group_raw([xr], wr, None, False, 0))
+    line('render_conv_cout1', xr.numel() * 4 + xr.numel() // 32 * 4, us, 'RenderBlock conv 32->1, 3x3 on [%d,32,64,64]: reads the map once, writes one channel' % xr.shape[0])
+    del xr
+    # ---- the pooled convolution's streaming passes on the stem's 8 members ([.,64,.,.,.]): box-sum and its adjoint
+    hs = [torch.randn(n, 64, d, s, s, generator=g).to(dev) for n, d, s in members]
+    tm = [2] * 8
+    shapes = [tuple(h.shape) for h in hs]
+    nb_in = sum(h.numel() for h in hs) * 4
+    rts = boxsum_raw(hs, tm, True)
+    us = timed(lambda: boxsum_raw(hs, tm, True))
+    line('pool_boxsum_k', nb_in + sum(r.numel() for r in rts) * 4, us, 'box-sum (+ReLU) of the stem activation, 8 members: reads r, writes the padded r~')
+    gz = [torch.randn(sh[0], 64, sh[2] // 2, sh[3] // 2, sh[4] // 2, generator=g).to(dev) for sh in shapes]
+    planes = pool_dgrad_raw(gz, shapes, tm, torch.randn(64, 64, 3, 3, 3, generator=g).to(dev) * 0.05)
+    us = timed(lambda: unbox_raw(planes, shapes, tm, masks=hs))
+    line('pool_unbox_k', sum(p.numel() for p in planes) * 4 + 2 * nb_in, us, 'adjoint of the box-sum: reads the class planes and the ReLU mask, writes dL/dr')
+    return out
