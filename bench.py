@@ -81,20 +81,20 @@ def pmc_traffic():
     process). The profile names the commit whose conv.hip it measured; when the kernel source has changed since, the
     figure is dropped (None) rather than reported stale. Returns (bytes, note) or (None, None)."""
     try:
-        path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
         if not os.path.exists(path):
             return None, None
         d = json.load(open(path))
         import hashlib
         src = open(os.path.join(ROOT, 'txt2vid_amd', 'csrc', 'conv.hip'), 'rb').read()
         if d.get('conv_hip_sha1') != hashlib.sha1(src).hexdigest():
-            return None, 'profiles/r02_pmc_traffic.json was measured on an older conv.hip (sha1 %s): dropped' % d.get('conv_hip_sha1', '?')[:10]
+            return None, 'profiles/r03_pmc_traffic.json was measured on an older conv.hip (sha1 %s): dropped' % d.get('conv_hip_sha1', '?')[:10]
         for k, v in d['kernels'].items():
-            if 'conv_igemm' in k and v.get('FETCH_SIZE_KB_per_launch') and v.get('WRITE_SIZE_KB_per_launch'):
+            if 'conv_igemm_strip3' in k and v.get('FETCH_SIZE_KB_per_launch') and v.get('WRITE_SIZE_KB_per_launch'):
                 b = (v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
-                return b, ('profiles/r02_pmc_traffic.json: %s, per launch; algorithmic %.0f MB; FETCH_SIZE may under-count '
-                           'streaming reads by up to 2x on gfx950' % (d['workload'].split(':')[1].split(',')[0].strip(),
-                                                                      d['algorithmic_bytes_per_launch']['igemm (x + y + w)'] / 1e6))
+                return b, ('profiles/r03_pmc_traffic.json: %s, HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 PMC passes; '
+                           'average over its forward and masked data-gradient launches); algorithmic %.1f MB; FETCH_SIZE may under-count '
+                           'streaming reads by up to 2x on gfx950' % (k, d['algorithmic_bytes_per_launch']['strip3<64> fwd / dgrad (x + y + w)'] / 1e6))
     except Exception:
         pass
     return None, None

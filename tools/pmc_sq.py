@@ -7,7 +7,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
     name = r['Kernel_Name'].split('(')[0]
-    if not any(t in name for t in ('conv_igemm', 'conv_wgrad')):
+    if not any(t in name for t in ('conv_igemm', 'conv_wgrad', 'conv_pool')):
         continue
     agg[name][r['Counter_Name']] += float(r['Counter_Value'])
     cnt[name].add(r['Dispatch_Id'])

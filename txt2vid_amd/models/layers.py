@@ -304,8 +304,13 @@ class DownBlock(nn.Module):
         m = self.main.inner_module
         if isinstance(m[1], Conv3d) and isinstance(m[3], Conv3d):
             h = TF.relu_conv(x, m[1].weight, m[1].bias)            # ReLU fused into the conv gather
-            h = TF.relu_conv(h, m[3].weight, m[3].bias)
             idm = self.main.identity_map
+            if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample) and TF.pool_conv_ok([h], m[3].weight, False):
+                # conv2 -> DownSample as ONE pooled convolution; the skip path's pooling adds it in its launch (as `down_block_levels`)
+                z = TF.pool_conv_group([h], m[3].weight, m[3].bias, relu_in=True, stem=False)[0]
+                s_ = idm[0](x)
+                return TF.avg_pool3d_group([s_], [downsample_cfg(s_)], adds=[z])[0]
+            h = TF.relu_conv(h, m[3].weight, m[3].bias)
             if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample):
                 return downsample_sum(idm[0](x), h)
             return TF.add(idm(x), m[4](h))

@@ -35,6 +35,11 @@ class Resnet3D(nn.Module):
         m = self.res_block.inner_module
         if isinstance(m[0], Conv3d) and isinstance(m[2], Conv3d):
             h = m[0](x)
+            if isinstance(m[3], AvgPool3d) and (m[3].kernel_size, m[3].stride, m[3].padding) == ((1, 2, 2), (2, 2, 2), (0, 0, 0)) and \
+                    TF.pool_conv_ok([h], m[2].weight, True):
+                # conv2 -> pooling as ONE pooled convolution (functional_pool.py), as in `forward_levels`
+                z = TF.pool_conv_group([h], m[2].weight, m[2].bias, relu_in=True, stem=True)[0]
+                return TF.add(self.res_block.identity_map(x), z)
             h = TF.relu_conv(h, m[2].weight, m[2].bias)
             return TF.add(self.res_block.identity_map(x), m[3](h))
         return self.res_block(x)

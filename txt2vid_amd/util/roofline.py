@@ -63,6 +63,12 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
                              'wgrad': {'ms': wg_ms + red_ms, 'tflops': wg_fl / (wg_ms + red_ms) / 1e9, 'launches': wg_n}},
             'all_in': {'wall_ms': wall * 1e3, 'tflops': flops / wall / 1e12, 'frac_of_fp32_mfma_peak': flops / wall / 1e12 / P,
                        'videos_per_s': batch / wall},
+            # SURVEY §8(d)'s algorithmic figure for this unit of work: 75.75 GFLOP per [1,1,16,64,64] sample forward+backward (what the
+            # reference's convolutions execute; the pooled second convolutions here execute a quarter / an eighth of their share). Over
+            # the wall time: the rate a reference-equivalent implementation would have to sustain to match — NOT matrix-pipe utilisation
+            'survey_algorithmic': ({'gflop_per_sample': 75.75, 'tflops': 75.75e9 * batch / wall / 1e12,
+                                    'frac_of_fp32_mfma_peak': 75.75e9 * batch / wall / 1e12 / P}
+                                   if (frames, size) == (16, 64) else None),
             'peak_tflops': P}
 
 
@@ -120,7 +126,6 @@ def hbm_bound_lines(device=None, batch=32, iters=20):
     line('bn_train_fwd', x.numel() * 12, us, 'BatchNorm2d + ReLU, training mode, [%d,128,8,8]: statistics pass (4 B read) + apply pass (4 B read + 4 B write)' % (batch * 16))
     del x
     # ---- the Cin = 1 stem convolution over the 8 discriminator-step members (reads 4 B, writes 64 x 4 B per voxel)
-    lv = [(2 * batch >> l if l else 2 * batch, 16 >> l, 8 << l) for l in range(4)]
     members = [(max(1, (2 * batch) >> l), 16 >> l, 8 << l) for l in range(4)] + [(max(1, batch >> l), 16 >> l, 8 << l) for l in range(4)]
     xs = [torch.randn(n, 1, d, s, s, generator=g).to(dev) for n, d, s in members]
     w1 = torch.randn(64, 1, 3, 3, 3, generator=g).to(dev) * 0.1
