@@ -2395,6 +2395,17 @@ extern "C" const char* t2v_version(void) { return "t2v_hip 0.1 (gfx950, fp32 MFM
 // ------------------------------------------------------------------------------------------------
 struct PoolBoxBatch { t2v_poolbox_job j[POOL_MT]; int begin[POOL_MT + 1]; int n; };
 
+// q = m / d for small m (< 2^22) via the float reciprocal with a +-1 fix-up
+__device__ __forceinline__ uint32_t small_div(uint32_t m, uint32_t d, float rcp) {
+    int q = (int)((float)m * rcp);
+    const int r = (int)m - q * (int)d;
+    q += (r >= (int)d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return (uint32_t)q;
+}
+// Both passes work on PAIRS of neighbouring x positions (W and W + 2 are even): one index decode, three column loads per row
+// instead of four, and 8-byte stores. A workgroup owns POOL_CHUNK consecutive pairs; its first pair is decoded with integer
+// divisions once, every pair inside the chunk with small float-reciprocal divisions of small numbers.
 __global__ __launch_bounds__(256) void pool_boxsum_k(const PoolBoxBatch tb) {
     int ji = 0;
 #pragma unroll
@@ -2402,44 +2413,56 @@ __global__ __launch_bounds__(256) void pool_boxsum_k(const PoolBoxBatch tb) {
         if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
     const t2v_poolbox_job& q = tb.j[ji];
     const int D = q.D, H = q.H, W = q.W, tm = q.tmode;
-    const uint32_t Dp = tm ? D + 1 : 1, Hp = H + 1, Wp = W + 2;
-    const uint32_t n = (uint32_t)q.NC * Dp * Hp * Wp;              // (host: < 2^31; all index arithmetic in 32 bits)
+    const uint32_t Dp = tm ? D + 1 : 1, Hp = H + 1, Wp = W + 2, Wp2 = Wp / 2;
+    const uint32_t n2 = (uint32_t)q.NC * Dp * Hp * Wp2;           // pairs (host: elements < 2^31)
     const uint32_t base = (uint32_t)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const uint32_t b_r0 = base / Wp2, b_x = base - b_r0 * Wp2;
+    const uint32_t b_r1 = b_r0 / Hp, b_y = b_r0 - b_r1 * Hp;
+    const uint32_t b_nc = b_r1 / Dp, b_f = b_r1 - b_nc * Dp;
+    const float rW = 1.0f / (float)Wp2, rH = 1.0f / (float)Hp, rD = 1.0f / (float)Dp;
     const float* __restrict__ x = q.in;
     const float* __restrict__ mk = q.mask;
     const float floor_ = q.relu ? 0.f : -__builtin_inff();
     const float scale = q.scale;
     const int nf = tm == 1 ? 2 : 1;
+    float2* __restrict__ out2 = reinterpret_cast<float2*>(q.out);
 #pragma unroll
     for (int it = 0; it < POOL_CHUNK / 256; ++it) {
-        const uint32_t i = base + it * 256 + threadIdx.x;
-        if (i >= n) break;
-        const uint32_t r0 = i / Wp, xp = i - r0 * Wp;
-        const uint32_t r1 = r0 / Hp, yp = r0 - r1 * Hp;
-        const uint32_t nc = r1 / Dp, fp = r1 - nc * Dp;
-        float acc = 0.f;
-        if (xp <= (uint32_t)W) {
-            const int f0 = tm == 0 ? 0 : (int)fp - 1;
-            const bool y0 = yp >= 1, y1 = yp < (uint32_t)H, x0 = xp >= 1, x1 = xp < (uint32_t)W;
-            for (int a = 0; a < nf; ++a) {
-                const int f = f0 + a;
-                if ((unsigned)f >= (unsigned)D) continue;
-                const uint32_t o = ((nc * D + f) * H + (yp - 1)) * W + (xp - 1);        // (y - 1, x - 1): the window's first corner
-                float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
-                if (y0 && x0) v00 = x[o];
-                if (y0 && x1) v01 = x[o + 1];
-                if (y1 && x0) v10 = x[o + W];
-                if (y1 && x1) v11 = x[o + W + 1];
-                if (mk) {
-                    if (y0 && x0) v00 = mk[o] > 0.f ? v00 : 0.f;
-                    if (y0 && x1) v01 = mk[o + 1] > 0.f ? v01 : 0.f;
-                    if (y1 && x0) v10 = mk[o + W] > 0.f ? v10 : 0.f;
-                    if (y1 && x1) v11 = mk[o + W + 1] > 0.f ? v11 : 0.f;
-                }
-                acc += (fmaxf(v00, floor_) + fmaxf(v01, floor_)) + (fmaxf(v10, floor_) + fmaxf(v11, floor_));
+        const uint32_t t = it * 256 + threadIdx.x;
+        if (base + t >= n2) break;
+        const uint32_t ix = b_x + t, q1 = small_div(ix, Wp2, rW), xp = (ix - q1 * Wp2) * 2;
+        const uint32_t iy = b_y + q1, q2 = small_div(iy, Hp, rH), yp = iy - q2 * Hp;
+        const uint32_t if_ = b_f + q2, q3 = small_div(if_, Dp, rD), fp = if_ - q3 * Dp;
+        const uint32_t nc = b_nc + q3;
+        float a0 = 0.f, a1 = 0.f;                                  // outputs xp and xp + 1
+        const int f0 = tm == 0 ? 0 : (int)fp - 1;
+        const bool y0 = yp >= 1, y1 = yp < (uint32_t)H;
+        const bool c0 = xp >= 1 && xp <= (uint32_t)W, c1 = xp < (uint32_t)W, c2 = xp + 1 < (uint32_t)W;       // input columns xp-1, xp, xp+1
+        for (int a = 0; a < nf; ++a) {
+            const int f = f0 + a;
+            if ((unsigned)f >= (unsigned)D) continue;
+            const uint32_t o = ((nc * D + f) * H + (yp - 1)) * W + (xp - 1);                      // (row yp-1, column xp-1)
+            float v00 = 0.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 0.f, v12 = 0.f;
+            if (y0 && c0) v00 = x[o];
+            if (y0 && c1) v01 = x[o + 1];
+            if (y0 && c2) v02 = x[o + 2];
+            if (y1 && c0) v10 = x[o + W];
+            if (y1 && c1) v11 = x[o + W + 1];
+            if (y1 && c2) v12 = x[o + W + 2];
+            if (mk) {
+                if (y0 && c0) v00 = mk[o] > 0.f ? v00 : 0.f;
+                if (y0 && c1) v01 = mk[o + 1] > 0.f ? v01 : 0.f;
+                if (y0 && c2) v02 = mk[o + 2] > 0.f ? v02 : 0.f;
+                if (y1 && c0) v10 = mk[o + W] > 0.f ? v10 : 0.f;
+                if (y1 && c1) v11 = mk[o + W + 1] > 0.f ? v11 : 0.f;
+                if (y1 && c2) v12 = mk[o + W + 2] > 0.f ? v12 : 0.f;
             }
+            v00 = fmaxf(v00, floor_); v01 = fmaxf(v01, floor_); v02 = fmaxf(v02, floor_);
+            v10 = fmaxf(v10, floor_); v11 = fmaxf(v11, floor_); v12 = fmaxf(v12, floor_);
+            a0 += (v00 + v01) + (v10 + v11);
+            a1 += (v01 + v02) + (v11 + v12);
         }
-        q.out[i] = acc * scale;
+        out2[base + t] = make_float2(a0 * scale, xp + 1 <= (uint32_t)W ? a1 * scale : 0.f);
     }
 }
 
@@ -2449,43 +2472,54 @@ __global__ __launch_bounds__(256) void pool_unbox_k(const PoolBoxBatch tb) {
     for (int k = 1; k < POOL_MT; ++k)
         if (k < tb.n && (int)blockIdx.x >= tb.begin[k]) ji = k;
     const t2v_poolbox_job& q = tb.j[ji];
-    const uint32_t D = q.D, H = q.H, W = q.W;
+    const uint32_t D = q.D, H = q.H, W = q.W, W2 = W / 2;
     const int tm = q.tmode;
     const uint32_t Dq = tm ? D / 2 + 1 : 1, Hq = H / 2 + 1, Wq = W / 2 + 1;
-    const uint32_t n = (uint32_t)q.NC * D * H * W;
+    const uint32_t n2 = (uint32_t)q.NC * D * H * W2;
     const uint32_t plane = (uint32_t)q.NC * Dq * Hq * Wq;          // (host: 8 * sets * plane < 2^31)
     const int sets = q.relu > 1 ? q.relu : 1;                     // plane sets to add up (the data-gradient GEMM's k-split)
     const uint32_t base = (uint32_t)((int)blockIdx.x - tb.begin[ji]) * POOL_CHUNK;
+    const uint32_t b_r0 = base / W2, b_x = base - b_r0 * W2;
+    const uint32_t b_r1 = b_r0 / H, b_y = b_r0 - b_r1 * H;
+    const uint32_t b_nc = b_r1 / D, b_f = b_r1 - b_nc * D;
+    const float rW = 1.0f / (float)W2, rH = 1.0f / (float)H, rD = 1.0f / (float)D;
     const float* __restrict__ pl = q.in;
-    const float* __restrict__ mk = q.mask;
+    const float2* __restrict__ mk2 = reinterpret_cast<const float2*>(q.mask);
+    float2* __restrict__ out2 = reinterpret_cast<float2*>(q.out);
     const int nf = tm == 1 ? 2 : 1;
 #pragma unroll
     for (int it = 0; it < POOL_CHUNK / 256; ++it) {
-        const uint32_t i = base + it * 256 + threadIdx.x;
-        if (i >= n) break;
-        const uint32_t r0 = i / W, xx = i - r0 * W;
-        const uint32_t r1 = r0 / H, y = r0 - r1 * H;
-        const uint32_t nc = r1 / D, f = r1 - nc * D;
-        const bool keep = mk ? mk[i] > 0.f : true;
-        float acc = 0.f;
-        if (keep) {
+        const uint32_t t = it * 256 + threadIdx.x;
+        if (base + t >= n2) break;
+        const uint32_t ix = b_x + t, q1 = small_div(ix, W2, rW), bx = ix - q1 * W2;          // x = 2 bx, 2 bx + 1
+        const uint32_t iy = b_y + q1, q2 = small_div(iy, H, rH), y = iy - q2 * H;
+        const uint32_t if_ = b_f + q2, q3 = small_div(if_, D, rD), f = if_ - q3 * D;
+        const uint32_t nc = b_nc + q3;
+        float2 m2 = make_float2(1.f, 1.f);
+        if (mk2) m2 = mk2[base + t];
+        float a0 = 0.f, a1 = 0.f;
+        if (m2.x > 0.f || m2.y > 0.f) {
             for (int a = 0; a < nf; ++a) {
-                const uint32_t pt = tm == 0 ? 0u : f + 1 - a;         // padded time index of r~ this voxel contributed to
+                const uint32_t pt = tm == 0 ? 0u : f + 1 - a;         // padded time index of r~ these voxels contributed to
                 const uint32_t ct = pt & 1u, at = pt >> 1;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const uint32_t py = y + 1 - b, cy = py & 1u, ay = py >> 1;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const uint32_t px = xx + 1 - c, cx = px & 1u, ax = px >> 1;
-                        const uint32_t o = ((ct * 2 + cy) * 2 + cx) * plane + ((nc * Dq + at) * Hq + ay) * Wq + ax;
-                        for (int s_ = 0; s_ < sets; ++s_) acc += pl[o + (uint32_t)s_ * 8u * plane];
+                    // x = 2 bx reads padded columns 2 bx + 1 (class 1, index bx) and 2 bx (class 0, index bx);
+                    // x = 2 bx + 1 reads 2 bx + 2 (class 0, index bx + 1) and 2 bx + 1 (class 1, index bx)
+                    const uint32_t o0 = ((ct * 2 + cy) * 2 + 0) * plane + ((nc * Dq + at) * Hq + ay) * Wq + bx;
+                    const uint32_t o1 = o0 + plane;
+                    for (int s_ = 0; s_ < sets; ++s_) {
+                        const uint32_t so = (uint32_t)s_ * 8u * plane;
+                        const float e0 = pl[o0 + so], e1 = pl[o0 + 1 + so], d1 = pl[o1 + so];
+                        a0 += e0 + d1;
+                        a1 += e1 + d1;
                     }
                 }
             }
         }
         const float bv = q.bias ? q.bias[nc % (uint32_t)q.C] : 0.f;
-        q.out[i] = keep ? acc * q.scale + bv : 0.f;
+        out2[base + t] = make_float2(m2.x > 0.f ? a0 * q.scale + bv : 0.f, m2.y > 0.f ? a1 * q.scale + bv : 0.f);
     }
 }
 
@@ -2507,7 +2541,8 @@ static int poolbox_multi(const t2v_poolbox_job* jobs, int njobs, bool unbox, voi
             const long sets = unbox && q.relu > 1 ? q.relu : 1;
             if (n >= (1L << 31) || (unbox && 8 * sets * (long)q.NC * (q.tmode ? q.D / 2 + 1 : 1) * (q.H / 2 + 1) * (q.W / 2 + 1) >= (1L << 31)))
                 return T2V_EINVAL;                                   // 32-bit element indices inside the kernels
-            blocks += (n + POOL_CHUNK - 1) / POOL_CHUNK;
+            if (((uintptr_t)q.out & 7u) || (unbox && q.mask && ((uintptr_t)q.mask & 7u))) return T2V_EINVAL;      // 8-byte pair accesses
+            blocks += (n / 2 + POOL_CHUNK - 1) / POOL_CHUNK;          // a workgroup owns POOL_CHUNK PAIRS of neighbouring x positions
         }
         for (int i = cnt; i <= POOL_MT; ++i) tb.begin[i] = (int)blocks;
         for (int i = cnt; i < POOL_MT; ++i) tb.j[i] = tb.j[0];
