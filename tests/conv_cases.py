@@ -44,6 +44,9 @@ SINGLE_CASES = [
     ((2, 40, 4, 8, 8), 64, (3, 3, 3)),       # Cin=40: generic-K path on 64x64 tiles with Cout=64
     ((16, 128, 4, 4), 256, (3, 3)),          # 2-D, M=256, K=1152: deep split-K
     ((8, 64, 8, 32, 32), 64, (1, 1, 1)),     # 1x1x1 64->64 at M=65536: per-tap weight gradient with the many-splits reduce
+    # the 1- / 3-channel stems run on the narrow-input kernel (conv_stem_kernel): the generic-K tiles they used to reach need other cases
+    ((6, 20, 16, 32, 32), 64, (3, 3, 3)),    # Cin=20 at M=98304: generic-K 128x64 tile
+    ((2, 5, 2, 5, 7), 8, (3, 3, 3)),         # Cin=5, Cout=8: generic-K 128x32 tile
 ]
 
 
@@ -114,7 +117,7 @@ def fwd_plan(members, cin, cout, k, flags=0):
     rc = lib().t2v_conv_fwd_plan(_group_array(members, cin, cout, k3(k)), len(members), cin, cout, flags, out)
     assert rc == 0, rc
     v = list(out)
-    return (('igemm', 'strip', 'thin', 'linear', 'thin2', 'strip3')[v[0]],) + tuple(v[1:])
+    return ({0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 12: 'stem'}[v[0]],) + tuple(v[1:])
 
 
 def wgrad_plan(members, cin, cout, k):

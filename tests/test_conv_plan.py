@@ -38,7 +38,8 @@ for bm, bn, bk in _TILES:
             ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>
 for bm, bn in ((128, 32), (128, 64), (64, 64)):
     ALL_FWD.add(('igemm', bm, bn, 16, 0, 0, 1))                              # generic-K: conv_igemm_kernel<BM,BN,*,16,false,false>
-ALL_FWD |= {('thin', 256, 1, 0, 0, 0, 0), ('thin', 256, 4, 0, 0, 0, 0), ('thin2', 256, 1, 0, 0, 0, 0),
+ALL_FWD |= {('stem', 256, 1, 0, 0, 0, 0), ('stem', 256, 3, 0, 0, 0, 0),          # conv_stem_kernel<1 / 3>: the clips' first convolution
+            ('thin', 256, 1, 0, 0, 0, 0), ('thin', 256, 4, 0, 0, 0, 0), ('thin2', 256, 1, 0, 0, 0, 0),
             ('linear', 0, 1, 0, 0, 0, 0), ('linear', 0, 4, 0, 0, 0, 0)}
 ALL_WGRAD = set(itertools.product(('taps', 'cols', 'rows3'), ('reduce', 'reduce_small')))
 

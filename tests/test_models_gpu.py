@@ -676,7 +676,7 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
     pool_fwd, pool_wg = cc.all_checked_pool_variants()
     checked_fwd = set(cc.all_checked_fwd_variants()) | set(pool_fwd)
     checked_wgrad = set(cc.all_checked_wgrad_variants()) | set(pool_wg)
-    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad'}
+    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad', 12: 'stem'}
     launched = set()
     rows = dump.read_text().strip().splitlines()[1:]
     assert len(rows) > 150
@@ -735,7 +735,7 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
     pool_fwd, pool_wg = cc.all_checked_pool_variants()
     checked_fwd |= set(pool_fwd)
     checked_wgrad |= set(pool_wg)
-    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad'}
+    kinds = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 9: 'pool_fwd', 10: 'pool_dgrad', 12: 'stem'}
     launched = set()
     rows = dump.read_text().strip().splitlines()[1:]
     assert len(rows) > 150

@@ -20,7 +20,7 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
-want = ('adam_multi_k', 'pool_boxsum_k', 'pool_unbox_k', 'pack_weight_kernel', 'bn_', 'conv_igemm_kernel', 'conv_thin_kernel')
+want = ('adam_multi_k', 'pool_boxsum_k', 'pool_unbox_k', 'pack_weight_kernel', 'bn_', 'conv_igemm_kernel', 'conv_stem_kernel', 'conv_thin_kernel')
 kern = {}
 for k in sorted(set(fetch) | set(write)):
     if any(t in k for t in want):

@@ -1904,7 +1904,9 @@ __global__ __launch_bounds__(256) void linear_thin_kernel(const GroupTable tab, 
 // P (nslots x M floats per member, members back to back) lives in the caller's workspace.
 __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
                                                         const int Cin, const int nslots, const int flags) {
-    __shared__ float sw[THIN_MAX_W];                     // w[slot][ci]
+    // the weights w[slot][ci] (Cout == 1: wp[slot][ci][0]) are read straight from memory at wave-uniform addresses, i.e. through
+    // scalar loads into SGPR operands of the FMAs: the LDS copy this kernel used to broadcast from cost one ds_read per FMA (1 728 per
+    // voxel for the stem) and set its pace (41 us for 33 MB of dL/dy)
     const int tid = threadIdx.x;
     int gi = 0;
 #pragma unroll
@@ -1912,8 +1914,6 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
         if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
     const t2v_conv_group& gd = tab.g[gi];
     const int DHW = gd.D * gd.H * gd.W, M = gd.N * DHW;
-    for (int i = tid; i < nslots * Cin; i += 256) sw[i] = wp[i];          // Cout == 1: wp[slot][ci][0]
-    __syncthreads();
     const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + tid;
     if (m >= M) return;
     const int n = m / DHW, sp = m - n * DHW;
@@ -1937,7 +1937,7 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
 #pragma unroll
         for (int t = 0; t < T2V_MAX_TAPS; ++t) {
             if (t < nslots) {
-                const float* wt = sw + t * Cin + c0;     // rows past Cin multiply zeros; THIN_MAX_W leaves the slack
+                const float* __restrict__ wt = wp + t * Cin + c0;     // (channels past Cin multiply zeros: clamped index)
 #pragma unroll
                 for (int u = 0; u < 16; ++u) acc[t] += v[u] * wt[c0 + u < Cin ? u : 0];
             }
@@ -1982,6 +1982,88 @@ __global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable ta
     gd.y[m] = (flags & T2V_CONV_ACCUM) ? gd.y[m] + v : v;
 }
 // worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
+// ------------------------------------------------------------------------------------------------
+// NARROW-INPUT convolution (Cin <= 3: the stem's first convolution on 1- or 3-channel clips, resnet3d.py:13). K = 27 * Cin is far
+// too short for a matrix tile (the generic implicit GEMM ran it at 0.9 TB/s of output bandwidth); the layer is one read of the clip
+// and Cout writes per voxel, i.e. HBM-write bound. One lane per voxel: its <= 27 * Cin input values sit in registers, the weights
+// arrive through scalar loads (uniform addresses: wp[tap][ci][co .. co+3] as one s_load_dwordx4), four output channels at a time,
+// every store a 256-byte row of consecutive voxels. Algorithmic traffic: 4 * Cin B read + 4 * Cout B written per voxel.
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                            const float* __restrict__ bias, const int Cout, const int flags) {
+    // one lane per voxel, all Cout channels: the <= 27 * Cin input values sit in registers, the weights arrive through scalar loads
+    // (per-tap tables live one entry per lane and are read back with v_readlane: no dependent scalar loads, so the 27 weight loads of
+    // a channel group are in flight together). Measured against the alternatives (graph-timed, 8 D-step members, 393 216 voxels): this
+    // form 59 us, the generic implicit GEMM 74 us, a channel-group-major form with contiguous 16 KB output runs 171 us (its 16x
+    // repeated address / bounds arithmetic costs more than the stores it straightens).
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + (int)threadIdx.x;
+    const bool mv = m < M;
+    const int mm = mv ? m : 0;
+    const int n = mm / DHW, sp = mm - n * DHW;
+    const int d = sp / HW, r = sp - d * HW;
+    const int h = r / W, w_ = r - h * W;
+    const float* __restrict__ px = gd.x + (size_t)n * CIN * DHW;
+    const bool relu = flags & T2V_CONV_RELU_IN;
+    const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const int ntaps = gd.ntaps;
+    const int lane = (int)threadIdx.x & 63;
+    const int lt = lane < ntaps ? lane : 0;
+    const int tab_dz = gd.dz[lt], tab_dy = gd.dy[lt], tab_dx = gd.dx[lt];
+    const int tab_w = lane < ntaps ? gd.widx[lt] * CIN * Cout : 0;
+    float xv[T2V_MAX_TAPS * CIN];
+#pragma unroll
+    for (int t = 0; t < T2V_MAX_TAPS; ++t) {
+        const bool live = t < ntaps;
+        const int dd = d + __builtin_amdgcn_readlane(tab_dz, t), hh = h + __builtin_amdgcn_readlane(tab_dy, t);
+        const int ww = w_ + __builtin_amdgcn_readlane(tab_dx, t);
+        const bool ok = live && mv && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int off = ok ? (dd * H + hh) * W + ww : 0;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float v = px[(size_t)ci * DHW + off];
+            xv[t * CIN + ci] = ok ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
+        }
+    }
+    float* __restrict__ py = gd.y + (size_t)n * Cout * DHW + sp;
+    for (int co = 0; co < Cout; co += 4) {
+        float a0 = has_bias ? bias[co] : 0.f, a1 = has_bias ? bias[co + 1] : 0.f;
+        float a2 = has_bias ? bias[co + 2] : 0.f, a3 = has_bias ? bias[co + 3] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T2V_MAX_TAPS; ++t) {
+            const float* __restrict__ wt = wp + __builtin_amdgcn_readlane(tab_w, t) + co;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wt + ci * Cout);
+                const float v = xv[t * CIN + ci];
+                a0 = fmaf(w4.x, v, a0); a1 = fmaf(w4.y, v, a1); a2 = fmaf(w4.z, v, a2); a3 = fmaf(w4.w, v, a3);
+            }
+        }
+        if (mv) {
+            py[(size_t)co * DHW] = a0;
+            py[(size_t)(co + 1) * DHW] = a1;
+            py[(size_t)(co + 2) * DHW] = a2;
+            py[(size_t)(co + 3) * DHW] = a3;
+        }
+    }
+}
+// the narrow-input kernel takes: 1 or 3 input channels, Cout a multiple of 4 (>= 8), plain stores (no accumulate / masked epilogue /
+// frame stride)
+static bool stem_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags) {
+    if ((Cin != 1 && Cin != 3) || Cout < 8 || (Cout % 4) != 0) return false;      // (grey or RGB clips)
+    if (flags & (T2V_CONV_ACCUM | T2V_CONV_MASK_OUT)) return false;
+    for (int i = 0; i < ngroups; ++i)
+        if (groups[i].dstride == 2 || groups[i].ydstride == 2) return false;
+    return true;
+}
+
 static bool thin_two_pass(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int nslots) {
     if (Cout != 1 || nslots < 9 || Cin < 16 || nslots * Cin > THIN_MAX_W) return false;
     long M = 0;
@@ -2236,6 +2318,7 @@ static void fill_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, in
         out[1] = 256; out[2] = Cout == 1 ? 1 : 4; out[7] = 1;
         return;
     }
+    if (stem_ok(groups, ngroups, Cin, Cout, flags)) { out[0] = 12; out[1] = 256; out[2] = Cin; out[7] = 1; return; }      // conv_stem_kernel<Cin>
     const int bk = (p.bm == 256 && p.bn == 64) ? 16 : (p.bk == 32 ? 32 : 16);
     const ConvVariant v = conv_variant(tab, p, p.bm, p.bn, bk, Cin, Cout, flags);
     out[0] = v.s3 ? 5 : (v.strip ? 1 : 0);
@@ -2281,7 +2364,7 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
 #endif
     int nslots;
     const bool thin = thin_ok(groups, ngroups, Cin, Cout, nslots);
-    if (!thin && p.S > 1 && !ws) return T2V_EINVAL;
+    if (!thin && p.S > 1 && !ws && !stem_ok(groups, ngroups, Cin, Cout, flags)) return T2V_EINVAL;
     if (p.dstride2) {                      // frame-strided outputs: the three-taps-per-round strip kernels only
         if (thin || (flags & T2V_CONV_ACCUM)) return T2V_EINVAL;
         bool s3 = false;
@@ -2335,6 +2418,19 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         ProfScope::set_plan(plan_, 8);
         if (Cout == 1) T2V_LAUNCH_PROF(conv_thin_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
         else T2V_LAUNCH_PROF(conv_thin_kernel<4>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cin, Cout, nslots, flags);
+        return launch_status();
+    }
+    if (stem_ok(groups, ngroups, Cin, Cout, flags)) {
+        long mt = 0;
+        for (int i = 0; i < ngroups; ++i) {
+            tab.tile_start[i] = (int32_t)mt;
+            mt += ((long)groups[i].N * groups[i].D * groups[i].H * groups[i].W + 255) / 256;
+        }
+        for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
+        ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
+        ProfScope::set_plan(plan_, 8);
+        if (Cin == 1) T2V_LAUNCH_PROF(conv_stem_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cout, flags);
+        else T2V_LAUNCH_PROF(conv_stem_kernel<3>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cout, flags);
         return launch_status();
     }
     ProfScope prof(0, flops, s, Mtot_, Cin, Cout, taps_, ngroups, p.S);      // executed (non-padding-tap) MACs x 2

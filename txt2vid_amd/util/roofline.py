@@ -78,24 +78,34 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 def hbm_bound_lines(device=None, batch=32, iters=20):
     """The HBM-bound sub-operations of the iteration, each timed in isolation at the benchmark's shapes with
     events on the launch stream: achieved GB/s on the ALGORITHMIC bytes (what a single streaming pass must move) against the
-    ~8 TB/s of HBM3E. {name: {bytes, us, achieved GB/s, frac}}. These kernels launch on torch's current stream, so torch events
-    bracket them."""
+    ~8 TB/s of HBM3E. {name: {bytes, us, achieved GB/s, frac}}. Timed under HIP-graph replay (no host time between launches)."""
     from .. import functional as TF
     from ..functional_pool import boxsum_raw, unbox_raw, pool_dgrad_raw
     dev = device or torch.device('cuda', torch.cuda.current_device())
     out = {}
 
+    side = torch.cuda.Stream(device=dev)
+
     def timed(fn):
-        for _ in range(3):
+        """us per call with the host out of the picture: `iters` calls are captured into ONE HIP graph (the Python side of a call —
+        group tables, allocations — costs more than these kernels run) and the replay is bracketed by events."""
+        for _ in range(2):
             fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+        torch.cuda.synchronize()
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(iters):
-            fn()
+        for _ in range(3):
+            g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters * 1e3          # us per call
+        return e0.elapsed_time(e1) / (3 * iters) * 1e3          # us per call
 
     def line(name, nbytes, us, what):
         out[name] = {'algorithmic_bytes': int(nbytes), 'us': us, 'achieved': nbytes / us / 1e3, 'unit': 'GB/s', 'peak': PEAK_HBM_GBS,
@@ -128,14 +138,14 @@ def hbm_bound_lines(device=None, batch=32, iters=20):
     # ---- the Cin = 1 stem convolution over the 8 discriminator-step members (reads 4 B, writes 64 x 4 B per voxel)
     members = [(max(1, (2 * batch) >> l), 16 >> l, 8 << l) for l in range(4)] + [(max(1, batch >> l), 16 >> l, 8 << l) for l in range(4)]
     xs = [torch.randn(n, 1, d, s, s, generator=g).to(dev) for n, d, s in members]
-    w1 = torch.randn(64, 1, 3, 3, 3, generator=g).to(dev) * 0.1
+    w1 = torch.nn.Parameter(torch.randn(64, 1, 3, 3, 3, generator=g).to(dev) * 0.1)       # (a Parameter: its packed form is cached)
     b1 = torch.zeros(64, device=dev)
     M = sum(t.numel() for t in xs)
     us = timed(lambda: TF.conv_group_raw(xs, w1, b1, False, 0))
     line('stem_conv1_cin1', M * (4 + 256), us, 'stem conv 1->64, 3x3x3, the 8 D-step members (M = %d voxels): 4 B read + 256 B written per voxel' % M)
     # ---- RenderBlock convolution ch -> 1 (thin kernel): [16,32,64,64]
     xr = torch.randn(max(1, batch // 8) * 2 * 2, 32, 1, 64, 64, generator=g).to(dev)
-    wr = torch.randn(1, 32, 1, 3, 3, generator=g).to(dev) * 0.1
+    wr = torch.nn.Parameter(torch.randn(1, 32, 1, 3, 3, generator=g).to(dev) * 0.1)
     us = timed(lambda: TF.conv_group_raw([xr], wr, None, False, 0))
     line('render_conv_cout1', xr.numel() * 4 + xr.numel() // 32 * 4, us, 'RenderBlock conv 32->1, 3x3 on [%d,32,64,64]: reads the map once, writes one channel' % xr.shape[0])
     del xr
