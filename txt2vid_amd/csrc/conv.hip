@@ -1981,10 +1981,9 @@ __global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable ta
     if ((flags & T2V_CONV_MASK_OUT) && gd.mask) v = gd.mask[m] > 0.f ? v : 0.f;
     gd.y[m] = (flags & T2V_CONV_ACCUM) ? gd.y[m] + v : v;
 }
-// worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
 // ------------------------------------------------------------------------------------------------
 // NARROW-INPUT convolution (Cin <= 3: the stem's first convolution on 1- or 3-channel clips, resnet3d.py:13). K = 27 * Cin is far
-// too short for a matrix tile (the generic implicit GEMM ran it at 0.9 TB/s of output bandwidth); the layer is one read of the clip
+// too short for a matrix tile (the generic implicit GEMM ran it at 1.4 TB/s of output bandwidth); the layer is one read of the clip
 // and Cout writes per voxel, i.e. HBM-write bound. One lane per voxel: its <= 27 * Cin input values sit in registers, the weights
 // arrive through scalar loads (uniform addresses: wp[tap][ci][co .. co+3] as one s_load_dwordx4), four output channels at a time,
 // every store a 256-byte row of consecutive voxels. Algorithmic traffic: 4 * Cin B read + 4 * Cout B written per voxel.
@@ -2064,6 +2063,7 @@ static bool stem_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout
     return true;
 }
 
+// worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
 static bool thin_two_pass(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int nslots) {
     if (Cout != 1 || nslots < 9 || Cin < 16 || nslots * Cin > THIN_MAX_W) return false;
     long M = 0;
