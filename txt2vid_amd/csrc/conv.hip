@@ -1380,9 +1380,16 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
         __syncthreads();
     }
     // ---- epilogue: rows (registers) = channel, columns (lanes) = grid voxel; two class planes
+    // Entries nobody reads are not written: an odd-parity class only lives on the first D' / H' / W' grid positions of its axis (its
+    // padded index 2a + 1 must stay inside the box-summed tensor), the unbox pass never touches the rest — about a quarter of the
+    // plane bytes, in a kernel whose 32 KB of output per 2-8 barrier rounds make it store-bound.
     const int m = m0 + wm * WM + l31;
     if (m < M) {
         const int n = m / Vq, sp = m - n * Vq;
+        const int at = sp / HWq, r2 = sp - at * HWq;
+        const int a = r2 / Wq, b = r2 - a * Wq;
+        const bool row_ok = (ct == 0 || at < Dn) && (cy == 0 || a < Hn);
+        const bool ok1 = row_ok && b < Wn;
         const size_t plane = (size_t)gd.N * C * Vq;
         float* p0 = gd.y + ((size_t)blockIdx.z * 8 + (size_t)((ct * 2 + cy) * 2 + 0)) * plane + (size_t)n * C * Vq + sp;
         float* p1 = p0 + plane;
@@ -1390,8 +1397,8 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * WCO + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (co < C) {
-                p0[(size_t)co * Vq] = acc0[r];
-                p1[(size_t)co * Vq] = acc1[r];
+                if (row_ok) p0[(size_t)co * Vq] = acc0[r];
+                if (ok1) p1[(size_t)co * Vq] = acc1[r];
             }
         }
     }
