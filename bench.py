@@ -377,8 +377,8 @@ def main():
             os.environ['T2V_PROF_DUMP'] = dump
         over = lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
         by_tile = per_tile_breakdown(dump, prof_steps, PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS, 5 if bf16 else 0)
+        os.environ.pop('T2V_PROF_DUMP', None)      # (the later roofline passes must not overwrite a dump the caller asked for)
         if own_dump:
-            os.environ.pop('T2V_PROF_DUMP', None)
             try:
                 os.remove(dump)
             except OSError:

@@ -2063,11 +2063,16 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const GroupTable tab, co
 // the narrow-input kernel takes: 1 or 3 input channels, Cout a multiple of 4 (>= 8), plain stores (no accumulate / masked epilogue /
 // frame stride)
 static bool stem_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags) {
-    if ((Cin != 1 && Cin != 3) || Cout < 8 || (Cout % 4) != 0) return false;      // (grey or RGB clips)
+    if ((Cin != 1 && Cin != 3) || Cout < 8 || Cout > 256 || (Cout % 4) != 0) return false;      // (grey or RGB clips)
     if (flags & (T2V_CONV_ACCUM | T2V_CONV_MASK_OUT)) return false;
-    for (int i = 0; i < ngroups; ++i)
+    long M = 0;
+    for (int i = 0; i < ngroups; ++i) {
         if (groups[i].dstride == 2 || groups[i].ydstride == 2) return false;
-    return true;
+        M += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+    }
+    // a lane per voxel walks ALL output channels: only worth it with enough voxels to fill the chip (the data gradient of a
+    // 1-output Linear head is also a "1-channel convolution" — 32 voxels x 1024 channels — and took 220 us on this kernel)
+    return M >= 16384;
 }
 
 // worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
