@@ -1911,9 +1911,9 @@ __global__ __launch_bounds__(256) void linear_thin_kernel(const GroupTable tab, 
 // P (nslots x M floats per member, members back to back) lives in the caller's workspace.
 __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
                                                         const int Cin, const int nslots, const int flags) {
-    // the weights w[slot][ci] (Cout == 1: wp[slot][ci][0]) are read straight from memory at wave-uniform addresses, i.e. through
-    // scalar loads into SGPR operands of the FMAs: the LDS copy this kernel used to broadcast from cost one ds_read per FMA (1 728 per
-    // voxel for the stem) and set its pace (41 us for 33 MB of dL/dy)
+    // (round 3: reading the weights at wave-uniform addresses through scalar loads instead of this LDS copy was measured and dropped:
+    // 441 dependent s_load / s_waitcnt pairs per wave, 24.6 -> 41.7 us per launch)
+    __shared__ float sw[THIN_MAX_W];                     // w[slot][ci]
     const int tid = threadIdx.x;
     int gi = 0;
 #pragma unroll
@@ -1921,6 +1921,8 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
         if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
     const t2v_conv_group& gd = tab.g[gi];
     const int DHW = gd.D * gd.H * gd.W, M = gd.N * DHW;
+    for (int i = tid; i < nslots * Cin; i += 256) sw[i] = wp[i];          // Cout == 1: wp[slot][ci][0]
+    __syncthreads();
     const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + tid;
     if (m >= M) return;
     const int n = m / DHW, sp = m - n * DHW;
@@ -1944,7 +1946,7 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
 #pragma unroll
         for (int t = 0; t < T2V_MAX_TAPS; ++t) {
             if (t < nslots) {
-                const float* __restrict__ wt = wp + t * Cin + c0;     // (channels past Cin multiply zeros: clamped index)
+                const float* wt = sw + t * Cin + c0;     // rows past Cin multiply zeros; THIN_MAX_W leaves the slack
 #pragma unroll
                 for (int u = 0; u < 16; ++u) acc[t] += v[u] * wt[c0 + u < Cin ? u : 0];
             }
