@@ -767,6 +767,46 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
     print('B=32 bf16: %d convolution launches on %d instantiations, all covered' % (len(rows), len(launched)))
 
 
+def test_pooled_and_unpooled_forms_agree_at_benchmark_size(monkeypatch):
+    """A size-independent cross-check at BASELINE configs[1]'s full size (B=32): the SAME iteration computed with the pooled
+    second convolutions / the up-sampling form (box-sum + stride-2 GEMMs, functional_pool.py) and with the un-pooled layers
+    (convolution, then pooling; up-sampling, then convolution) — two different algorithms for the same mathematics — must give the
+    same losses and the same per-parameter gradient norms up to fp32 summation order."""
+    from txt2vid_amd import functional_pool as FP
+    from txt2vid_amd.gan.trainer import train_iteration
+    B = 32
+    random.seed(21)
+    np.random.seed(21)
+    torch.manual_seed(21)
+    x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous().to(DEV)
+    states = (torch.get_rng_state(), np.random.get_state(), random.getstate())
+    out = {}
+    for mode in ('pooled', 'plain'):
+        monkeypatch.setattr(FP, '_DISABLED', mode == 'plain')
+        torch.set_rng_state(states[0])
+        np.random.set_state(states[1])
+        random.setstate(states[2])
+        gan, optD, optG, losses, prm = _make_uncond()
+        snap = {}
+        step_d = optD.step
+
+        def spy(*a, _snap=snap, _gan=gan, _step=step_d, **kw):      # D's gradients as its optimiser sees them (the G step zeroes them)
+            _snap.update({k: float(p.grad.norm()) for k, p in _gan.discrims[0].named_parameters() if p.grad is not None})
+            return _step(*a, **kw)
+        optD.step = spy
+        lD, lG, _, _ = train_iteration(gan, x, None, optD, optG, losses, prm, DEV)
+        torch.cuda.synchronize()
+        out[mode] = (float(lD), float(lG), snap, {k: float(p.grad.norm()) for k, p in gan.gen.named_parameters() if p.grad is not None})
+    (lD0, lG0, d0, g0), (lD1, lG1, d1, g1) = out['pooled'], out['plain']
+    print('pooled %.7f %.7f | plain %.7f %.7f' % (lD0, lG0, lD1, lG1))
+    assert abs(lD0 - lD1) < 2e-5 and abs(lG0 - lG1) < 2e-5
+    for a, b in ((d0, d1), (g0, g1)):
+        assert set(a) == set(b) and len(a) > 20
+        top = max(b.values())
+        for k in b:
+            assert abs(a[k] - b[k]) <= 1e-3 * abs(b[k]) + 1e-6 * top + 1e-7, (k, a[k], b[k])
+
+
 def test_iteration_bf16_compute_mode_vs_oracle():
     """bf16-compute mode (forward / data-gradient GEMMs on bf16 MFMA; BASELINE configs 2-4 "bf16 compute / fp32 master"): one
     full iteration against the fp32 CPU oracle. bf16 operands carry 8 mantissa bits, so this is a LOOSER, separately stated
