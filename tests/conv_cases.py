@@ -44,7 +44,8 @@ SINGLE_CASES = [
     ((2, 40, 4, 8, 8), 64, (3, 3, 3)),       # Cin=40: generic-K path on 64x64 tiles with Cout=64
     ((16, 128, 4, 4), 256, (3, 3)),          # 2-D, M=256, K=1152: deep split-K
     ((8, 64, 8, 32, 32), 64, (1, 1, 1)),     # 1x1x1 64->64 at M=65536: per-tap weight gradient with the many-splits reduce
-    # the 1- / 3-channel stems run on the narrow-input kernel (conv_stem_kernel): the generic-K tiles they used to reach need other cases
+    # big 1- / 3-channel 3-D stems run on the narrow-input kernel (conv_stem_kernel): the generic-K tiles they used to reach need other cases
+    ((4, 1, 16, 32, 32), 64, (3, 3, 3)),     # the grey-clip stem at M=65536: conv_stem_kernel<1> (RGB: the Cin=3 case above)
     ((6, 20, 16, 32, 32), 64, (3, 3, 3)),    # Cin=20 at M=98304: generic-K 128x64 tile
     ((2, 5, 2, 5, 7), 8, (3, 3, 3)),         # Cin=5, Cout=8: generic-K 128x32 tile
 ]

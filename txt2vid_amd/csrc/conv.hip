@@ -2068,13 +2068,17 @@ static bool stem_ok(const t2v_conv_group* groups, int ngroups, int Cin, int Cout
     if ((Cin != 1 && Cin != 3) || Cout < 8 || Cout > 256 || (Cout % 4) != 0) return false;      // (grey or RGB clips)
     if (flags & (T2V_CONV_ACCUM | T2V_CONV_MASK_OUT)) return false;
     long M = 0;
+    int taps = 0;
     for (int i = 0; i < ngroups; ++i) {
         if (groups[i].dstride == 2 || groups[i].ydstride == 2) return false;
         M += (long)groups[i].N * groups[i].D * groups[i].H * groups[i].W;
+        if (groups[i].ntaps > taps) taps = groups[i].ntaps;
     }
-    // a lane per voxel walks ALL output channels: only worth it with enough voxels to fill the chip (the data gradient of a
-    // 1-output Linear head is also a "1-channel convolution" — 32 voxels x 1024 channels — and took 220 us on this kernel)
-    return M >= 16384;
+    // a lane per voxel walks ALL output channels and all 27 tap slots: only worth it for real 3-D stems with enough voxels to fill
+    // the chip. (Other "1-channel convolutions" exist: the data gradient of a 1-output head is 32 voxels x 1024 channels and took
+    // 220 us on this kernel; the data gradients of the render convolutions and the stem's 1x1x1 skip have 9 / 1 live taps and ran
+    // 2-4x slower here than on the generic tiles.)
+    return M >= 65536 && taps > 18;
 }
 
 // worth it when the input would otherwise be re-read many times: several taps, enough channels and voxels
