@@ -410,6 +410,9 @@ def main():
                     'all_in_frac': conv_flops / prof_steps / (dt / args.steps) / 1e12 / peak,
                     # the same launches by kernel family (tile): `frac` above is their time-weighted aggregate
                     'by_tile': by_tile,
+                    # the single kernel family with the most GPU time among them (what `traffic` was measured on)
+                    'dominant_kernel': (dict(max(by_tile.items(), key=lambda kv: kv[1]['gpu_ms_per_step'])[1],
+                                             family=max(by_tile.items(), key=lambda kv: kv[1]['gpu_ms_per_step'])[0]) if by_tile else None),
                     'executed_conv_tflop_per_step': conv_flops / prof_steps / 1e12,
                     'wgrad': {'achieved': (out[4] / (out[3] * 1e-3) / 1e12) if out[3] > 0 else None,
                               'launches_per_step': out[5] / prof_steps, 'gpu_ms_per_step': out[3] / prof_steps,
