@@ -301,6 +301,20 @@ int t2v_lstm_gates_slab(const float* slab, int S, const float* bias, const float
                         float* act, int B, int C, void* stream);
 int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S, const float* gc_in, const float* act,
                             const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* stream);
+/* One launch per recurrence step on 1x1 maps (conv_lstm.py:75-97 at [B,1024,1,1]): pre = x [B][K] . w [K][4C] + bias, then the gate
+   math of t2v_lstm_gates, fused. `wr` is the unit-major copy of the packed weight, wr[u][k/4][g*4 + j][k%4] = w[k][g*C + 4u + j]
+   (t2v_lstm_pack_major, K*4C floats), so that a workgroup's four hidden units are one contiguous stream. act is [B][4C] (i,f,c,o),
+   h / c_prev / c_new are [B][C]. t2v_lstm_step_fused_ok: B <= 32, K % 128 == 0, C % 4 == 0 (else the slab pair above). */
+int t2v_lstm_step_fused_ok(int B, int K, int C);
+int t2v_lstm_pack_major(const float* w, float* wr, int K, int C, void* stream);
+int t2v_lstm_step_fused(const float* x, const float* wr, const float* bias, const float* c_prev, float* h, float* c_new,
+                        float* act, int B, int K, int C, void* stream);
+/* Its adjoint, also one launch per step: dL/dh_t = gh + gnext [B][4C] . w1 [4C][C] (gnext = dL/dpre of step t+1, NULL at the last
+   step), then the gate adjoints of t2v_lstm_gates_bwd. w1r is the column-block-major copy of the data-gradient form of the packed
+   Wh: w1r[ub][n/4][j][n%4] = w1[n][16 ub + j] (t2v_lstm_pack_cols with R = 4C rows, Cn = C columns). Additionally C % 64 == 0. */
+int t2v_lstm_pack_cols(const float* w, float* wr, int R, int Cn, void* stream);
+int t2v_lstm_step_bwd_fused(const float* gh, const float* gnext, const float* w1r, const float* gc_in, const float* act,
+                            const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* stream);
 
 /* ---- non-local block (layers.py:23-36, 52-68) -------------------------------------------------- */
 /* C[b] = alpha * op(A[b]) x op(B[b]); row-major A[b]: (ta? K x M : M x K), B[b]: (tb? N x K : K x N). */

@@ -739,10 +739,11 @@ def test_upblock_identity_path_on_the_small_map(cin, cout):
         close(a, r, rtol=2e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize('hw,C,B', [(1, 16, 3), (2, 16, 3), (1, 128, 5), (1, 256, 33)])
+@pytest.mark.parametrize('hw,C,B', [(1, 16, 3), (2, 16, 3), (1, 128, 5), (1, 256, 33), (1, 1024, 32)])
 def test_conv_lstm(hw, C, B):
-    """conv_lstm.py:75-97 vs the oracle; C % 128 == 0 on 1x1 maps takes the wave-per-strip GEMM + slab-summing gate
-    kernels (the generator's [B,1024,1,1] case), B = 33 a second, ragged MFMA row tile."""
+    """conv_lstm.py:75-97 vs the oracle. On 1x1 maps with B <= 32 and C % 64 == 0 a step is ONE launch (GEMM + gates fused on
+    the unit-major weight copy: C = 128 the generic instantiation with a ragged row tile, [32,1024,1,1] the generator's own
+    case); B = 33 takes the wave-per-strip GEMM + slab-summing gate kernels (a second, ragged MFMA row tile)."""
     from txt2vid_amd import functional as TF
     from oracle import tganv2_oracle as O
     steps = 5

@@ -906,6 +906,226 @@ extern "C" int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S
     return launch_status();
 }
 
+// ---- one launch per recurrence step: GEMM + gate math fused (replaces skinny_gemm_slab + lstm_gates_slab, 17.5 -> ~7 us per step).
+// A workgroup owns FOUR hidden units = 16 of the 4C gate columns (i,f,c,o of each unit), so the gate math needs nothing from any other
+// workgroup. Its 16 weight columns live contiguously in the "unit-major" copy  wr[u][k/4][g*4 + j][k%4] = wp[k][g*C + 4u + j]  (lstm_pack_major_k,
+// one streaming pass per weight update); the four waves split K, each runs two 16x16x4 fp32 MFMA row tiles (32 batch rows) and the partial
+// sums meet in LDS. Workgroups are numbered so that the 32 of one XCD take consecutive units (their weight lines share that XCD's L2).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// tile = 8 k x 64 units: reads run along the units (1 KB per (k, gate)); a thread then gathers the four k of one (unit, column) into
+// the float4 the MFMA lane will load, 1 KB of output per unit
+__global__ __launch_bounds__(256) void lstm_pack_major_k(const float* __restrict__ wp, float* __restrict__ wr, int K, int Cc) {
+    __shared__ float tile[8 * 4][260];
+    const int U = Cc / 4, u0 = blockIdx.x * 64, k0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) {
+        const int uu = i & 63, kg = i >> 6, g = kg & 3, kk = kg >> 2;
+        if (u0 + uu < U && k0 + kk < K) *(float4*)&tile[kg][4 * uu] = *(const float4*)(wp + ((size_t)(k0 + kk) * 4 + g) * Cc + 4 * (u0 + uu));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 2 * 16; i += 256) {
+        const int c16 = i & 15, kgrp = (i >> 4) & 1, uu = i >> 5, g = c16 >> 2, j = c16 & 3;
+        if (u0 + uu < U && k0 + 4 * kgrp < K) {
+            const float4 v = {tile[(4 * kgrp + 0) * 4 + g][4 * uu + j], tile[(4 * kgrp + 1) * 4 + g][4 * uu + j],
+                              tile[(4 * kgrp + 2) * 4 + g][4 * uu + j], tile[(4 * kgrp + 3) * 4 + g][4 * uu + j]};
+            *(float4*)(wr + ((((size_t)(u0 + uu) * K + k0) >> 2) + kgrp) * 64 + 4 * c16) = v;
+        }
+    }
+}
+template <int KWT, int NW>                                               // K slice per wave when known at compile time (0: any); waves
+__global__ __launch_bounds__(64 * NW) void lstm_step_fused_k(const float* __restrict__ xin, const float* __restrict__ wr,
+                                                         const float* __restrict__ bias, const float* __restrict__ c_prev,
+                                                         float* __restrict__ h, float* __restrict__ c_new, float* __restrict__ act,
+                                                         const int B, const int K, const int Cc) {
+    __shared__ float part[NW][32][17];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int u = (nwg % 8 == 0) ? (bid % 8) * (nwg / 8) + bid / 8 : bid;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, c16 = l & 15, kq = l >> 4;
+    const int KW = KWT ? KWT : K / NW;                                   // K slice of this wave (multiple of 16)
+    const float* __restrict__ pw = wr + ((((size_t)u * K + (size_t)wv * KW) >> 2) + kq) * 64 + 4 * c16;   // [u][k/4][16][4]
+    const int r0 = c16 < B ? c16 : B - 1, r1 = 16 + c16 < B ? 16 + c16 : B - 1;      // clamped rows: computed, never stored
+    const float* __restrict__ pa0 = xin + (size_t)r0 * K + (size_t)wv * KW + 4 * kq;
+    const float* __restrict__ pa1 = xin + (size_t)r1 * K + (size_t)wv * KW + 4 * kq;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // 16x16x4: lane (c16, kq) supplies A[row c16][k-slot kq] and B[k-slot kq][col c16]; the four k of a lane's float4 go to four issues
+#define LSTM_KSTEP(kb) {                                                                              \
+        const float4 a0 = *(const float4*)(pa0 + (kb)), a1 = *(const float4*)(pa1 + (kb));                \
+        const float4 b = *(const float4*)(pw + (size_t)(kb) * 16);                                        \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc0, 0, 0, 0);                            \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc1, 0, 0, 0);                            \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc0, 0, 0, 0);                            \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc1, 0, 0, 0);                            \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc0, 0, 0, 0);                            \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc1, 0, 0, 0);                            \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc0, 0, 0, 0);                            \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc1, 0, 0, 0); }
+    if (KWT) {
+#pragma unroll
+        for (int kb = 0; kb < KWT; kb += 16) LSTM_KSTEP(kb)
+    } else {
+        for (int kb = 0; kb < KW; kb += 16) LSTM_KSTEP(kb)
+    }
+#undef LSTM_KSTEP
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                        // D: col = lane & 15, row = 4 (lane >> 4) + r
+        part[wv][4 * kq + r][c16] = acc0[r];
+        part[wv][16 + 4 * kq + r][c16] = acc1[r];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int b = tid >> 2, j = tid & 3;
+        if (b < B) {
+            float p[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) v += part[q][b][4 * g + j];
+                p[g] = v + (bias ? bias[g * Cc + 4 * u + j] : 0.f);
+            }
+            const float gi = sigm(p[0]), gf = sigm(p[1]), gg = tanhf(p[2]), go = sigm(p[3]);
+            const size_t i = (size_t)b * Cc + 4 * u + j;
+            const float cc = gf * c_prev[i] + gi * gg;
+            c_new[i] = cc;
+            h[i] = go * tanhf(cc);
+            float* pa = act + (size_t)b * 4 * Cc + 4 * u + j;
+            pa[0] = gi; pa[Cc] = gf; pa[2 * (size_t)Cc] = gg; pa[3 * (size_t)Cc] = go;
+        }
+    }
+}
+// B <= 32 rows (one pair of MFMA row tiles), K a multiple of 128 (up to eight waves x 16-wide k groups), C a multiple of 4
+extern "C" int t2v_lstm_step_fused_ok(int B, int K, int C) {
+    return (B >= 1 && B <= 32 && K >= 128 && (K % 128) == 0 && C >= 4 && (C % 4) == 0) ? 1 : 0;
+}
+static int lstm_waves() { static const int w = getenv("T2V_LSTM_WAVES") ? atoi(getenv("T2V_LSTM_WAVES")) : 8; return w == 4 ? 4 : 8; }
+extern "C" int t2v_lstm_pack_major(const float* wp, float* wr, int K, int C, void* st) {
+    if (!wp || !wr || K < 1 || C < 4 || (C % 4) != 0) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_pack_major_k, dim3((unsigned)((C / 4 + 63) / 64), (unsigned)((K + 7) / 8)), dim3(256), 0, S_(st), wp, wr, K, C);
+    return launch_status();
+}
+extern "C" int t2v_lstm_step_fused(const float* x, const float* wr, const float* bias, const float* c_prev, float* h, float* c_new,
+                                   float* act, int B, int K, int C, void* st) {
+    if (!x || !wr || !c_prev || !h || !c_new || !act || !t2v_lstm_step_fused_ok(B, K, C)) return T2V_EINVAL;
+    const dim3 grid((unsigned)(C / 4));
+    if (lstm_waves() == 4) {
+        if (K == 1024) T2V_LAUNCH((lstm_step_fused_k<256, 4>), grid, dim3(256), 0, S_(st), x, wr, bias, c_prev, h, c_new, act, B, K, C);
+        else T2V_LAUNCH((lstm_step_fused_k<0, 4>), grid, dim3(256), 0, S_(st), x, wr, bias, c_prev, h, c_new, act, B, K, C);
+    } else {
+        if (K == 1024) T2V_LAUNCH((lstm_step_fused_k<128, 8>), grid, dim3(512), 0, S_(st), x, wr, bias, c_prev, h, c_new, act, B, K, C);
+        else T2V_LAUNCH((lstm_step_fused_k<0, 8>), grid, dim3(512), 0, S_(st), x, wr, bias, c_prev, h, c_new, act, B, K, C);
+    }
+    return launch_status();
+}
+
+// column-block-major, k-interleaved copy of a row-major matrix: wr[cb][r / 4][j][r % 4] = w[r][16 cb + j] (the adjoint step's 16-unit
+// weight stream). Tile = 16 rows x 256 columns: reads 1 KB per row, writes 1 KB per column block.
+__global__ __launch_bounds__(256) void lstm_pack_cols_k(const float* __restrict__ w, float* __restrict__ wr, int R, int Cn) {
+    __shared__ float tile[16][260];
+    const int c0 = blockIdx.x * 256, r0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int q = i & 63, rr = i >> 6;
+        if (c0 + 4 * q < Cn && r0 + rr < R) *(float4*)&tile[rr][4 * q] = *(const float4*)(w + (size_t)(r0 + rr) * Cn + c0 + 4 * q);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 4 * 16; i += 256) {
+        const int j = i & 15, rg = (i >> 4) & 3, cbl = i >> 6;           // column j of block cbl, row group rg (4 rows)
+        const int cb = (c0 >> 4) + cbl;
+        if (16 * cb < Cn && r0 + 4 * rg < R) {
+            const float4 v = {tile[4 * rg][16 * cbl + j], tile[4 * rg + 1][16 * cbl + j], tile[4 * rg + 2][16 * cbl + j],
+                              tile[4 * rg + 3][16 * cbl + j]};
+            *(float4*)(wr + ((((size_t)cb * R + r0) >> 2) + rg) * 64 + 4 * j) = v;
+        }
+    }
+}
+// The adjoint step in one launch: dL/dh_t = gh_t + gpre_{t+1} [B][4C] . w1 [4C][C], then the gate adjoints of t2v_lstm_gates_bwd. w1
+// arrives as its column-block-major copy w1r[ub][n][16] (lstm_pack_cols_k; reading the 64-byte pieces of the row-major form cost 21 us
+// per step against 17 for the two-launch form). A workgroup owns 16 hidden
+// units x 16 batch rows = one 16x16x4 MFMA tile; four waves split K = 4C. Workgroup pairs (the two batch halves read the same weights)
+// and neighbouring unit blocks share an XCD.
+template <int CT, int NW>                                                // C when known at compile time (0: any); waves (4 | 8)
+__global__ __launch_bounds__(64 * NW) void lstm_step_bwd_fused_k(const float* __restrict__ gh, const float* __restrict__ gnext,
+                                                             const float* __restrict__ w1, const float* __restrict__ gc_in,
+                                                             const float* __restrict__ act, const float* __restrict__ c_prev,
+                                                             const float* __restrict__ c_new, float* __restrict__ gpre,
+                                                             float* __restrict__ gc_prev, const int B, const int Cc, const int halves) {
+    __shared__ float part[NW][16][17];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int v = (nwg % 8 == 0) ? (bid % 8) * (nwg / 8) + bid / 8 : bid;
+    const int ub = v / halves, bh = v - ub * halves;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, c16 = l & 15, kq = l >> 4;
+    if (gnext) {
+        const int K = 4 * Cc, KW = CT ? CT * 4 / NW : Cc * 4 / NW;       // K slice of this wave
+        const int row = 16 * bh + c16 < B ? 16 * bh + c16 : B - 1;
+        const float* __restrict__ pa = gnext + (size_t)row * K + (size_t)wv * KW + 4 * kq;
+        const float* __restrict__ pw = w1 + ((((size_t)ub * K + (size_t)wv * KW) >> 2) + kq) * 64 + 4 * c16;   // [ub][k/4][16][4]
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#define LSTM_BSTEP(kb) {                                                                                  \
+            const float4 a = *(const float4*)(pa + (kb)), a2 = *(const float4*)(pa + (kb) + 16);         \
+            const float4 b = *(const float4*)(pw + (size_t)(kb) * 16), d = *(const float4*)(pw + (size_t)(kb) * 16 + 256);     \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, d.x, acc2, 0, 0, 0);                        \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, d.y, acc2, 0, 0, 0);                        \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, d.z, acc2, 0, 0, 0);                        \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);                           \
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, d.w, acc2, 0, 0, 0); }
+        if (CT) {
+#pragma unroll 8
+            for (int kb = 0; kb < CT * 4 / NW; kb += 32) LSTM_BSTEP(kb)
+        } else {
+            for (int kb = 0; kb < KW; kb += 32) LSTM_BSTEP(kb)
+        }
+#undef LSTM_BSTEP
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wv][4 * kq + r][c16] = acc[r] + acc2[r];
+        __syncthreads();
+    }
+    const int bl = (tid >> 4) & 15, c = tid & 15, b = 16 * bh + bl;
+    if (tid < 256 && b < B) {
+        const size_t i = (size_t)b * Cc + 16 * ub + c;
+        float back = 0.f;
+        if (gnext) {
+#pragma unroll
+            for (int q = 0; q < NW; ++q) back += part[q][bl][c];
+        }
+        const float* pa = act + (size_t)b * 4 * Cc + 16 * ub + c;
+        const float gi = pa[0], gf = pa[Cc], gg = pa[2 * (size_t)Cc], go = pa[3 * (size_t)Cc];
+        const float tc = tanhf(c_new[i]);
+        const float dh = gh[i] + back;
+        const float dc = dh * go * (1.f - tc * tc) + (gc_in ? gc_in[i] : 0.f);
+        float* pg = gpre + (size_t)b * 4 * Cc + 16 * ub + c;
+        pg[0] = dc * gg * gi * (1.f - gi);
+        pg[Cc] = dc * c_prev[i] * gf * (1.f - gf);
+        pg[2 * (size_t)Cc] = dc * gi * (1.f - gg * gg);
+        pg[3 * (size_t)Cc] = dh * tc * go * (1.f - go);
+        gc_prev[i] = dc * gf;
+    }
+}
+// gnext = NULL: the last step (nothing arrives from a later one). w1r = t2v_lstm_pack_cols of the [4C][C] data-gradient weight. Same
+// shape rules as the forward step plus C % 32.
+extern "C" int t2v_lstm_pack_cols(const float* w, float* wr, int R, int Cn, void* st) {
+    if (!w || !wr || R < 1 || Cn < 16 || (Cn % 16) != 0) return T2V_EINVAL;
+    T2V_LAUNCH(lstm_pack_cols_k, dim3((unsigned)((Cn + 255) / 256), (unsigned)((R + 15) / 16)), dim3(256), 0, S_(st), w, wr, R, Cn);
+    return launch_status();
+}
+extern "C" int t2v_lstm_step_bwd_fused(const float* gh, const float* gnext, const float* w1, const float* gc_in, const float* act,
+                                       const float* c_prev, const float* c_new, float* gpre, float* gc_prev, int B, int C, void* st) {
+    if (!gh || (gnext && !w1) || !act || !c_prev || !c_new || !gpre || !gc_prev || !t2v_lstm_step_fused_ok(B, C, C) || (C % 64) != 0)
+        return T2V_EINVAL;
+    const int halves = (B + 15) / 16;
+    const dim3 grid((unsigned)(C / 16 * halves));
+    if (lstm_waves() == 4) {
+        if (C == 1024) T2V_LAUNCH((lstm_step_bwd_fused_k<1024, 4>), grid, dim3(256), 0, S_(st), gh, gnext, w1, gc_in, act, c_prev, c_new, gpre,
+                                  gc_prev, B, C, halves);
+        else T2V_LAUNCH((lstm_step_bwd_fused_k<0, 4>), grid, dim3(256), 0, S_(st), gh, gnext, w1, gc_in, act, c_prev, c_new, gpre, gc_prev, B, C, halves);
+    } else {
+        if (C == 1024) T2V_LAUNCH((lstm_step_bwd_fused_k<1024, 8>), grid, dim3(512), 0, S_(st), gh, gnext, w1, gc_in, act, c_prev, c_new, gpre,
+                                  gc_prev, B, C, halves);
+        else T2V_LAUNCH((lstm_step_bwd_fused_k<0, 8>), grid, dim3(512), 0, S_(st), gh, gnext, w1, gc_in, act, c_prev, c_new, gpre, gc_prev, B, C, halves);
+    }
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- non-local block
 // Batched thin GEMM: head dims are 4..64, so no MFMA tile fits; 16x16 output tile per workgroup,
 // K staged through LDS in 16-wide slabs.

@@ -1467,6 +1467,10 @@ def _skinny_ok(M, K, N):
     return M <= 64 and int(lib().t2v_skinny_gemm_splits(M, K, N)) > 0
 
 
+def _lstm_fused_ok(B, K, Cc):
+    return os.environ.get('T2V_NO_LSTM_FUSED', '0') != '1' and bool(lib().t2v_lstm_step_fused_ok(B, K, Cc))
+
+
 def _skinny(x, wp, M, K, N):
     """slab[S][M][N] of partial products x[M][K] . wp[K][N] (`t2v_skinny_gemm_slab`); the consumer sums the S slices."""
     S = int(lib().t2v_skinny_gemm_splits(M, K, N))
@@ -1507,6 +1511,18 @@ class ConvLSTMFn(Function):
         acts = torch.empty((steps, B, 4 * Cc, h, w), device=dev, dtype=torch.float32)
         pre = torch.empty((B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         check(lib().t2v_fill(_p(cs[0]), 0.0, B * CS, _stream()), 't2v_fill')
+        if h == 1 and w == 1 and _lstm_fused_ok(B, Cc, Cc):
+            # 1x1 maps (the TGANv2 generator): GEMM + gate math in ONE launch per step, on the unit-major weight copies
+            wr = torch.empty((2, Cc * 4 * Cc), device=dev, dtype=torch.float32)
+            check(lib().t2v_lstm_pack_major(_p(wpx), _p(wr[0]), Cc, Cc, _stream()), 't2v_lstm_pack_major')
+            if steps > 1:
+                check(lib().t2v_lstm_pack_major(_p(wph), _p(wr[1]), Cc, Cc, _stream()), 't2v_lstm_pack_major')
+            for t in range(steps):
+                check(lib().t2v_lstm_step_fused(_p(x5 if t == 0 else hs[t - 1]), _p(wr[0 if t == 0 else 1]), _p(bias4), _p(cs[t]),
+                                                _p(hs[t]), _p(cs[t + 1]), _p(acts[t]), B, Cc, Cc, _stream()), 't2v_lstm_step_fused')
+            ctx.save_for_backward(x, hs, cs, acts, *params)
+            ctx.steps = steps
+            return hs.squeeze(3)
         if h == 1 and w == 1 and _skinny_ok(B, Cc, 4 * Cc):
             # 1x1 maps (the TGANv2 generator): a step = one 32-row GEMM; wave-per-strip kernel + slab-summing gate kernel
             for t in range(steps):
@@ -1549,8 +1565,19 @@ class ConvLSTMFn(Function):
         gpre = torch.empty((steps, B, 4 * Cc, 1, h, w), device=dev, dtype=torch.float32)
         gh_next = None           # dL/dh_t arriving from step t+1
         gc = None
-        skinny = h == 1 and w == 1 and _skinny_ok(B, 4 * Cc, Cc)
+        fused = h == 1 and w == 1 and _lstm_fused_ok(B, Cc, Cc) and Cc % 64 == 0
+        skinny = not fused and h == 1 and w == 1 and _skinny_ok(B, 4 * Cc, Cc)
         slab, S = None, 0
+        if fused:                                                        # GEMM + gate adjoints in ONE launch per step
+            gcs = torch.empty((2, B, Cc), device=dev, dtype=torch.float32)
+            w1r = torch.empty((4 * Cc * Cc,), device=dev, dtype=torch.float32)
+            if steps > 1:
+                check(lib().t2v_lstm_pack_cols(_p(wph1), _p(w1r), 4 * Cc, Cc, _stream()), 't2v_lstm_pack_cols')
+            for t in range(steps - 1, -1, -1):
+                check(lib().t2v_lstm_step_bwd_fused(_p(ghs[t]), _p(gpre[t + 1]) if t + 1 < steps else None, _p(w1r),
+                                                    _p(gc), _p(acts[t]), _p(cs[t]), _p(cs[t + 1]), _p(gpre[t]), _p(gcs[t & 1]), B, Cc,
+                                                    _stream()), 't2v_lstm_step_bwd_fused')
+                gc = gcs[t & 1]
         for t in range(steps - 1, -1, -1) if skinny else ():
             gcp = torch.empty((B, Cc, h, w), device=dev, dtype=torch.float32)
             check(lib().t2v_lstm_gates_bwd_slab(_p(ghs[t]), _p(slab), S, _p(gc), _p(acts[t]), _p(cs[t]), _p(cs[t + 1]), _p(gpre[t]),
@@ -1558,7 +1585,7 @@ class ConvLSTMFn(Function):
             gc = gcp
             if t > 0:
                 slab, S = _skinny(gpre[t], wph1, B, 4 * Cc, Cc)
-        for t in range(steps - 1, -1, -1) if not skinny else ():
+        for t in range(steps - 1, -1, -1) if not (skinny or fused) else ():
             if gh_next is None:
                 gh = ghs[t]
             else:
