@@ -49,7 +49,8 @@ def pool_scale(tmode):
 def pool_conv_ok(xs, w, stem):
     """True when `pool_conv_group` takes these members: 3x3x3 kernel, channels a multiple of 32, even H / W >= 2, D == 1 or even,
     fp32 mode. (bf16-compute mode keeps the un-pooled layers: measured, the pooled fp32 GEMMs + their two streaming passes lose to
-    the un-pooled bf16 GEMMs — 10.1 vs 9.4 ms per iteration; a bf16 form of the pooled kernels is the open item there.)"""
+    the un-pooled bf16 GEMMs — 9.66 vs 9.19 ms per iteration with every layer pooled, 9.43 with only the DownBlocks' 8x layers, 9.39
+    with only the UpBlocks' transposed form; a bf16 form of the pooled kernels is the open item there.)"""
     TF = _TF()
     if _DISABLED or TF.CONV_PRECISION != 'fp32' or not (1 <= len(xs) <= MAX_GROUPS) or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
         return False
