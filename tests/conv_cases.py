@@ -48,6 +48,10 @@ SINGLE_CASES = [
     ((4, 1, 16, 32, 32), 64, (3, 3, 3)),     # the grey-clip stem at M=65536: conv_stem_kernel<1> (RGB: the Cin=3 case above)
     ((6, 20, 16, 32, 32), 64, (3, 3, 3)),    # Cin=20 at M=98304: generic-K 128x64 tile
     ((2, 5, 2, 5, 7), 8, (3, 3, 3)),         # Cin=5, Cout=8: generic-K 128x32 tile
+    # 1x1x1 maps with Cin >= 64: the weight gradient is the TN-product kernel (conv_wgrad_gemm_kernel)
+    ((37, 192), 136, ()),                    # ragged 128x128 tiles in both directions, one ragged 32-row chunk pair
+    ((1500, 256, 1, 1, 1), 320, (3, 3, 3)),  # k-split (6 tiles -> S = 12), centre tap of a 3x3x3 kernel
+    ((2100, 128), 128, ()),                  # one tile, 16 splits: the many-splits reduce
 ]
 
 
@@ -122,14 +126,14 @@ def fwd_plan(members, cin, cout, k, flags=0):
 
 
 def wgrad_plan(members, cin, cout, k):
-    """('taps'|'cols'|'rows3', S, chunks per split, slab slots, 'reduce'|'reduce_small', workgroups)."""
+    """('taps'|'cols'|'rows3'|'gemm', S, chunks per split, slab slots, 'reduce'|'reduce_small', workgroups)."""
     from txt2vid_amd._lib import lib
     out = (C.c_int32 * 6)()
     kk = k3(k)
     rc = lib().t2v_conv_wgrad_plan(_group_array(members, cin, cout, kk), len(members), cin, cout, kk[0], kk[1], kk[2], out)
     assert rc == 0, rc
     v = list(out)
-    return (('taps', 'cols', 'rows3')[v[0]], v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
+    return (('taps', 'cols', 'rows3', 'gemm')[v[0]], v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
 
 
 def members_of_single(xs):

@@ -7,7 +7,7 @@ import sys
 
 KINDS = {0: 'fwd/dgrad', 1: 'wgrad', 2: 'wgrad-reduce', 3: 'thin', 4: 'splitk-reduce', 5: 'bf16 fwd/dgrad'}
 PLAN0 = {0: 'igemm', 1: 'strip', 2: 'thin', 3: 'linear', 4: 'thin2', 5: 'strip3', 6: 'igemm_bf16', 8: 'strip3_bf16', 9: 'pool_fwd', 10: 'pool_dgrad', 11: 'pool_wgrad', 12: 'stem'}
-WPLAN0 = {0: 'wgrad taps', 1: 'wgrad cols', 2: 'wgrad rows3', 11: 'pool_wgrad'}
+WPLAN0 = {0: 'wgrad taps', 1: 'wgrad cols', 2: 'wgrad rows3', 3: 'wgrad gemm', 11: 'pool_wgrad'}
 
 
 def main(path, steps):

@@ -3638,7 +3638,111 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
     }
 }
 
-struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; bool strided; };
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on 1x1x1 maps (the ConvLSTM's state [B,1024,1,1] with time folded into the batch, nn.Linear, any 3^k kernel whose
+// only live tap is the centre): x [M][Cin] and dL/dy [M][Cout] are row-major with the channels contiguous, so
+// dw[co][ci] = sum_m gy[m][co] * x[m][ci] is a plain TN product. The voxel-major gathers of the per-tap kernel read such operands
+// with a stride of C floats per lane (35 TFLOP/s on the [480 x 4096]^T . [480 x 1024] launch); here a workgroup owns a 128 x 128
+// tile of dw, streams 32-row chunks of both operands with 16-byte loads along the channels, and each wave runs a 2 x 2 block of
+// 32x32x2 MFMA tiles (four LDS reads per four MFMAs). Same chunk table, k-split slab format (one slot: the centre tap) and bias
+// side-sums as the other weight-gradient kernels. Cin % 4 == 0, Cout % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+#define WGM_AP 132
+__global__ __launch_bounds__(256) void conv_wgrad_gemm_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                              const int Cout, const int flags, const int chunks_per_split,
+                                                              float* __restrict__ bias_slab) {
+    __shared__ __attribute__((aligned(16))) float As[WG_BK * WGM_AP];   // gy chunk [m][co]
+    __shared__ __attribute__((aligned(16))) float Bs[WG_BK * WGM_AP];   // x  chunk [m][ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int nci_t = (Cin + 127) / 128;
+    const int co0 = ((int)blockIdx.x / nci_t) * 128, ci0 = ((int)blockIdx.x % nci_t) * 128;
+    const int split = blockIdx.z;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+    const int c4 = (tid & 31) * 4, r8 = tid >> 5;                      // my float4 column, my first row (rows r8 + 8 j)
+    const bool a_ok = co0 + c4 < Cout, b_ok = ci0 + c4 < Cin;
+    const bool do_bias = bias_slab != nullptr && ci0 == 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4], rb[4];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_chunk = [&](int q) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        const int row0 = (q - tab.chunk_start[gi]) * WG_BK + r8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = row0 + 8 * j;
+            const bool v = m < gd.N;
+            ra[j] = (v && a_ok) ? *reinterpret_cast<const float4*>(gd.y + (size_t)m * Cout + co0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 t = (v && b_ok) ? *reinterpret_cast<const float4*>(gd.x + (size_t)m * Cin + ci0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (relu_in) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+            rb[j] = t;
+        }
+    };
+    if (q0 < q1) load_chunk(q0);
+    for (int q = q0; q < q1; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(&As[(r8 + 8 * j) * WGM_AP + c4]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[(r8 + 8 * j) * WGM_AP + c4]) = rb[j];
+            if (do_bias) { bsum.x += ra[j].x; bsum.y += ra[j].y; bsum.z += ra[j].z; bsum.w += ra[j].w; }
+        }
+        __syncthreads();
+        if (q + 1 < q1) load_chunk(q + 1);
+        const float* as = As + wco * 64 + l31;
+        const float* bs = Bs + wci * 64 + l31;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BK / 2; ++k2) {
+            const int krow = (k2 * 2 + hi) * WGM_AP;
+            const float a0 = as[krow], a1 = as[krow + 32], b0 = bs[krow], b1 = bs[krow + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // rows (registers) = co, columns (lanes) = ci: 128-byte row segments
+    float* out = slab + (size_t)split * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wci * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < Cout && ci < Cin) out[(size_t)co * Cin + ci] = acc[i][j][r];
+            }
+        }
+    if (do_bias) {                       // column sums of every gy chunk this split staged: 8 row groups -> one value per channel
+        float* red = As;                 // (the last chunk's reads are behind the loop's closing barrier)
+        *reinterpret_cast<float4*>(&red[r8 * WGM_AP + c4]) = bsum;
+        __syncthreads();
+        if (tid < 128 && co0 + tid < Cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += red[k * WGM_AP + tid];
+            bias_slab[(size_t)split * Cout + co0 + tid] = v;
+        }
+    }
+}
+
+struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; bool strided; bool gemm; };
 
 static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, bool need_ptrs,
                          WGroupTable& tab, WgradPlan& p) {
@@ -3671,6 +3775,10 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     bool anyw = false;
     for (int i = 0; i < ngroups; ++i) anyw = anyw || groups[i].W > 1;
     p.rows3 = (kW == 3) && anyw && Cin >= 64 && maxMC < (1L << 30);   // the 3-tap kernel gathers through 32-bit byte offsets
+    // every member on a 1x1x1 map (only the centre tap lives): the TN-product kernel
+    bool all1 = true;
+    for (int i = 0; i < ngroups; ++i) all1 = all1 && groups[i].D == 1 && groups[i].H == 1 && groups[i].W == 1;
+    p.gemm = all1 && !strided && Cin >= 64 && (Cin % 4) == 0 && (Cout % 4) == 0;
     if (strided && !p.rows3) return false;
     p.strided = strided;
     p.liverows = 0;
@@ -3678,6 +3786,17 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
         if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;
     p.nrows = __builtin_popcount(p.liverows);
     if (p.rows3) p.nlive = p.nrows * 3;            // slab slots (dead dx taps of a live row are written as zeros)
+    if (p.gemm) {                                 // 128 x 128 tiles, one per CU: k-splits only until the chip is covered once
+        const long tiles = (long)((Cout + 127) / 128) * ((Cin + 127) / 128);
+        long S = tiles >= 192 ? 1 : (256 + tiles - 1) / tiles;
+        const long maxS = (nch + 3) / 4;          // at least 4 chunks (128 rows) per split
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+        if (S > tun().wgrad_scap) S = tun().wgrad_scap;
+        p.cps = (int)((nch + S - 1) / S);
+        p.S = (int)((nch + p.cps - 1) / p.cps);
+        return true;
+    }
     const long base = p.rows3 ? (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nrows
                     : (Cin < 64) ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                  : (long)((Cout + 63) / 64) * ((Cin + 63) / 64) * p.nlive;
@@ -3711,15 +3830,16 @@ extern "C" int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* grou
 }
 
 // Launch-plan query (no launch) for t2v_conv_wgrad_grouped[_bias]: out[0] kernel (0 per-tap 64x64 tiles, 1 (tap, ci) column
-// tiles for Cin < 64, 2 three-tap kernel rows), out[1] k-splits S, out[2] 32-voxel chunks per split, out[3] slab slots,
+// tiles for Cin < 64, 2 three-tap kernel rows, 3 the TN product on 1x1x1 maps), out[1] k-splits S, out[2] 32-voxel chunks per split, out[3] slab slots,
 // out[4] reduce kernel (0 per-64-pairs, 1 the many-splits small-weight form), out[5] workgroups of the main launch.
 static void fill_wgrad_plan(int Cin, int Cout, const WgradPlan& p, int32_t* out) {
     const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
-    out[0] = p.rows3 ? 2 : (Cin < 64 ? 1 : 0);
+    out[0] = p.gemm ? 3 : p.rows3 ? 2 : (Cin < 64 ? 1 : 0);
     out[1] = p.S;
     out[2] = p.cps;
     out[3] = p.nlive;
     out[4] = ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0;
+    if (p.gemm) { out[5] = (int32_t)((long)((Cout + 127) / 128) * ((Cin + 127) / 128) * p.S); return; }
     out[5] = (int32_t)((p.rows3 ? tiles * p.nrows : Cin < 64 ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                                               : tiles * p.nlive) * p.S);
 }
@@ -3809,7 +3929,11 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
         plan_[6] = ((flags & T2V_CONV_BF16) && (p.rows3 || Cin >= 64)) ? 1 : 0;       // conv_wgrad3_kernel<true> / conv_wgrad_bf16_kernel
         plan_[7] = p.strided ? 1 : 0;                                                  // dL/dy on the even frames (dstride = 2)
         ProfScope::set_plan(plan_, 8);
-        if (p.rows3) {
+        if (p.gemm && !(flags & T2V_CONV_BF16)) {
+            dim3 grid((unsigned)(((Cout + 127) / 128) * ((Cin + 127) / 128)), 1u, (unsigned)p.S);
+            T2V_LAUNCH_PROF(conv_wgrad_gemm_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, flags, p.cps,
+                            dbias ? bias_part : (float*)nullptr);
+        } else if (p.rows3) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((Cin + 63) / 64)), (unsigned)lrows.n, (unsigned)p.S);
             if (flags & T2V_CONV_BF16)
                 T2V_LAUNCH_PROF(conv_wgrad3_kernel<true>, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,

@@ -2638,9 +2638,9 @@ def conv_group_wgrad_partial(xs5, gys5, wshape, relu_in, sink, wbase, dw, wacc, 
 def _fused_gates_to_sink(sink, gates, x5, gy5, w4shape):
     """Weight gradients of the ConvLSTM's four gates (ONE launch on the side-by-side [4C, C, ...] weight) straight into the
     gates' tap-major sink slots: each gate is a row block of every slab plane. Returns the four gradient views."""
-    src, slab = _wgrad_partial_launch([x5], [gy5], w4shape, False, False, sink)
     Cc = w4shape[1]
     T = w4shape[2] * w4shape[3] * w4shape[4]
+    src, slab = _wgrad_partial_launch([x5], [gy5], w4shape, False, False, sink)
     out = []
     for g, w in enumerate(gates):
         flat, acc = sink.take(w, deferred=True)
