@@ -1958,6 +1958,53 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
     for (int t = 0; t < T2V_MAX_TAPS; ++t)
         if (t < nslots) pp[(size_t)t * M] = acc[t];
 }
+// The same first pass on the matrix pipes (round 3; Cin in {16, 32, 64, 128}): P[t][v] = sum_c w[t][c] x[c][v] is a [taps x Cin] . [Cin x
+// voxels] product with at most 27 rows. A = the weights (row = tap, held in K2 registers per lane for the whole kernel), B = the
+// activations straight from global memory (column = voxel: 32 consecutive voxels per half-wave, one k per half), no LDS at all. A
+// wave owns 64 voxels = two 32x32x2 column tiles; rows (registers) = taps, columns (lanes) = voxels, so the stores are the same
+// 128-byte segments as the VALU form's. Measured 40.9 -> 38 us on the stem's 64 -> 1 data gradient (M = 131 072): the pass is bound by
+// the latency of its channel-strided loads at two waves per SIMD, not by the arithmetic — kept for the LDS and VALU work it drops.
+template <int K2>
+__global__ __launch_bounds__(256) void thin_taps_mfma_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
+                                                             const int nslots, const int flags) {
+    constexpr int Cin = 2 * K2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int DHW = gd.D * gd.H * gd.W, M = gd.N * DHW;
+    const bool relu_in = flags & T2V_CONV_RELU_IN;
+    float a[K2];
+#pragma unroll
+    for (int k2 = 0; k2 < K2; ++k2) a[k2] = l31 < nslots ? wp[l31 * Cin + 2 * k2 + hi] : 0.f;      // Cout == 1: wp[slot][ci]
+    float* pbase = P + (size_t)nslots * (size_t)tab.out_start[gi];
+    const int m_w = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + wave * 64;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int m = m_w + 32 * g + l31;
+        if (m_w + 32 * g >= M) break;                                   // (wave-uniform)
+        const int mc = m < M ? m : M - 1;
+        const int n = mc / DHW, sp = mc - n * DHW;
+        const float* __restrict__ px = gd.x + ((size_t)n * Cin + hi) * DHW + sp;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float b[K2];
+#pragma unroll
+        for (int k2 = 0; k2 < K2; ++k2) b[k2] = px[(size_t)(2 * k2) * DHW];
+#pragma unroll
+        for (int k2 = 0; k2 < K2; ++k2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2], relu_in ? fmaxf(b[k2], 0.f) : b[k2], acc, 0, 0, 0);
+        if (m < M) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (t < nslots) pbase[(size_t)t * M + m] = acc[r];
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable tab, const float* __restrict__ P,
                                                              const float* __restrict__ bias, const int nslots, const int flags) {
     int gi = 0;
@@ -2426,7 +2473,11 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
             {
                 ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
                 ProfScope::set_plan(plan_, 8);
-                T2V_LAUNCH_PROF(thin_taps_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, Cin, nslots, flags);
+                if (Cin == 64) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<32>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 32) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<16>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 16) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<8>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 128) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<64>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
+                else T2V_LAUNCH_PROF(thin_taps_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, Cin, nslots, flags);
             }
             ProfScope prof2(3, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, 2);
             T2V_LAUNCH_PROF(thin_shift_sum_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, ws, bias, nslots, flags);
