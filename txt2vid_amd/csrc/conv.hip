@@ -1961,11 +1961,12 @@ __global__ __launch_bounds__(256) void thin_taps_kernel(const GroupTable tab, co
 // The same first pass on the matrix pipes (round 3; Cin in {16, 32, 64, 128}): P[t][v] = sum_c w[t][c] x[c][v] is a [taps x Cin] . [Cin x
 // voxels] product with at most 27 rows. A = the weights (row = tap, held in K2 registers per lane for the whole kernel), B = the
 // activations straight from global memory (column = voxel: 32 consecutive voxels per half-wave, one k per half), no LDS at all. A
-// wave owns 64 voxels = two 32x32x2 column tiles; rows (registers) = taps, columns (lanes) = voxels, so the stores are the same
-// 128-byte segments as the VALU form's. Measured 40.9 -> 38 us on the stem's 64 -> 1 data gradient (M = 131 072): the pass is bound by
-// the latency of its channel-strided loads at two waves per SIMD, not by the arithmetic — kept for the LDS and VALU work it drops.
+// wave owns 32 voxels = one 32x32x2 column tile (512-thread workgroups); rows (registers) = taps, columns (lanes) = voxels, so the stores are the same
+// 128-byte segments as the VALU form's. Measured on the stem's 64 -> 1 data gradient (M = 131 072): 40.9 us for the VALU form, 38 with 64
+// voxels per wave here, 31 with 32 — the pass is bound by the latency of its channel-strided loads (waves in flight per SIMD), not by
+// the arithmetic.
 template <int K2>
-__global__ __launch_bounds__(256) void thin_taps_mfma_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
+__global__ __launch_bounds__(512) void thin_taps_mfma_kernel(const GroupTable tab, const float* __restrict__ wp, float* __restrict__ P,
                                                              const int nslots, const int flags) {
     constexpr int Cin = 2 * K2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1980,11 +1981,10 @@ __global__ __launch_bounds__(256) void thin_taps_mfma_kernel(const GroupTable ta
 #pragma unroll
     for (int k2 = 0; k2 < K2; ++k2) a[k2] = l31 < nslots ? wp[l31 * Cin + 2 * k2 + hi] : 0.f;      // Cout == 1: wp[slot][ci]
     float* pbase = P + (size_t)nslots * (size_t)tab.out_start[gi];
-    const int m_w = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + wave * 64;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int m = m_w + 32 * g + l31;
-        if (m_w + 32 * g >= M) break;                                   // (wave-uniform)
+    const int m_w = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + wave * 32;        // eight waves x 32 voxels: more loads in flight per SIMD
+    {
+        const int m = m_w + l31;
+        if (m_w >= M) return;                                           // (wave-uniform)
         const int mc = m < M ? m : M - 1;
         const int n = mc / DHW, sp = mc - n * DHW;
         const float* __restrict__ px = gd.x + ((size_t)n * Cin + hi) * DHW + sp;
@@ -2473,10 +2473,10 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
             {
                 ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
                 ProfScope::set_plan(plan_, 8);
-                if (Cin == 64) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<32>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
-                else if (Cin == 32) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<16>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
-                else if (Cin == 16) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<8>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
-                else if (Cin == 128) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<64>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, nslots, flags);
+                if (Cin == 64) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<32>, dim3((unsigned)mt), dim3(512), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 32) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<16>, dim3((unsigned)mt), dim3(512), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 16) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<8>, dim3((unsigned)mt), dim3(512), 0, s, tab, wp, ws, nslots, flags);
+                else if (Cin == 128) T2V_LAUNCH_PROF(thin_taps_mfma_kernel<64>, dim3((unsigned)mt), dim3(512), 0, s, tab, wp, ws, nslots, flags);
                 else T2V_LAUNCH_PROF(thin_taps_kernel, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, ws, Cin, nslots, flags);
             }
             ProfScope prof2(3, 0.0, s, Mtot_, Cin, Cout, taps_, ngroups, 2);
