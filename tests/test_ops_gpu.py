@@ -771,6 +771,40 @@ def test_conv_lstm(hw, C, B):
         close(Pd[k].grad, P[k].grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(70, 40, 3, 3, 3), (64, 96, 1, 3, 3), (33, 20, 1, 1, 1), (128, 64, 3, 3, 3), (8, 5, 3, 3, 3)])
+def test_repack_params_matches_a_fresh_pack(shape):
+    """`repack_params` (the ONE multi-tensor launch after an optimiser step, functional.py) against `t2v_pack_weight[_bf16]` of the same
+    values: forward and mirrored data-gradient layouts, fp32 and bf16, 3^k and 1x1x1 kernels, ragged channel tiles, a member with
+    D == 1 (9 live taps of 27)."""
+    from txt2vid_amd import functional as TF
+    cout, cin, kd, kh, kw = shape
+    torch.manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(shape).to(dev()))
+    geoms = [TF.conv_geom(2, cin, 4, 6, 6, cout, kd, kh, kw)]
+    if kd == 3:
+        geoms.append(TF.conv_geom(2, cin, 1, 6, 6, cout, kd, kh, kw))               # D == 1: only the centre plane of taps is live
+    packed = []
+    for g in geoms:
+        ts = TF._tapset(g.T, g.mask)
+        for mode in (0, 1):
+            packed.append((TF.packed_weight(w, g, mode), lambda dst, g=g, mode=mode: TF.check(TF.lib().t2v_pack_weight(
+                TF._p(w), TF._p(dst), cout, cin, g.T, g.taps_c, len(g.taps), mode, TF._stream()), 'pack')))
+            packed.append((TF.packed_weight_bf16(w, ts, mode), lambda dst, ts=ts, mode=mode: TF.check(TF.lib().t2v_pack_weight_bf16(
+                TF._p(w), TF._p(dst), cout, cin, ts.T, ts.taps_c, len(ts.taps), mode, TF._stream()), 'pack16')))
+    with torch.no_grad():
+        w.copy_(torch.randn(shape).to(dev()))                # new values behind the caches' back ...
+    ptrs = [wp.data_ptr() for wp, _ in packed]
+    TF.repack_params([w])                                    # ... refreshed in place by the multi-tensor launch
+    torch.cuda.synchronize()
+    for (wp, fresh), ptr in zip(packed, ptrs):
+        assert wp.data_ptr() == ptr
+        ref = torch.empty_like(wp)
+        fresh(ref)
+        torch.cuda.synchronize()
+        assert torch.equal(wp.view(torch.int16 if wp.dtype == torch.bfloat16 else torch.int32),
+                           ref.view(torch.int16 if wp.dtype == torch.bfloat16 else torch.int32)), (shape, wp.dtype)
+
+
 def test_losses_and_gp_helpers():
     from txt2vid_amd import functional as TF
     a, b = rnd(1, 6, 1), rnd(2, 6, 1)
