@@ -37,7 +37,8 @@ def _arena_worker(rank, world, port, q):
     opt = Opt()
     sync = tdist.make_grad_sync({'D': arena}, {'D': opt}, world)
     sync('D')
-    q.put((rank, [p.grad.clone() for p in params], opt.grad_scale, arena.numel))
+    # (numpy through the queue: tensors travel as shared-memory handles, which a child that exits first may already have unlinked)
+    q.put((rank, [p.grad.numpy().copy() for p in params], opt.grad_scale, arena.numel))
     dist.destroy_process_group()
 
 
@@ -58,7 +59,7 @@ def _sparse_worker(rank, world, port, q):
         grad_scale = 1.0
     sync = tdist.make_grad_sync({'G': arena}, {'G': Opt()}, world)
     sync('G')
-    q.put((rank, w.grad.clone(), b.grad.clone(), arena.exchanged_bytes(), [p is w for p in arena.params]))
+    q.put((rank, w.grad.numpy().copy(), b.grad.numpy().copy(), arena.exchanged_bytes(), [p is w for p in arena.params]))
     dist.destroy_process_group()
 
 
@@ -78,6 +79,7 @@ def test_structurally_sparse_taps_exchange_world2():
     want = torch.zeros(4, 3, 9)
     want[:, :, 4], want[:, :, 7] = 3.0, 30.0
     for rank, gw, gb, nbytes, order in res:
+        gw, gb = torch.from_numpy(gw), torch.from_numpy(gb)
         assert torch.equal(gw.view(4, 3, 9), want) and torch.equal(gb, torch.arange(5.0) * 2 + 1)
         assert nbytes == 4 * (5 + 4 * 3 * 2) and order == [False, True]
 
@@ -95,6 +97,7 @@ def test_grad_arena_allreduce_world2():
         assert p.exitcode == 0
     for rank, grads, scale, numel in res:
         assert numel == 12 + 5 + 4 and scale == 0.5
+        grads = [torch.from_numpy(g) for g in grads]
         assert torch.equal(grads[0], torch.full((3, 4), 3.0))            # 1 + 2, SUM; the optimiser applies 1/world
         assert torch.equal(grads[1], torch.arange(5.0) * 3)
         assert torch.equal(grads[2], torch.zeros(2, 2))
@@ -145,7 +148,7 @@ def _replica_worker(rank, world, port, q):
     holder.w = strided
     n = tdist.sync_replicas([net, None, holder])
     flat = torch.cat([t.detach().reshape(-1).double() for t in list(net.parameters()) + list(net.buffers()) + [strided]])
-    q.put((rank, seed, n, flat, tdist.rank_world()))
+    q.put((rank, seed, n, flat.numpy().copy(), tdist.rank_world()))
     dist.destroy_process_group()
 
 
@@ -164,7 +167,7 @@ def test_replicas_identical_without_seed_world2():
         assert p.exitcode == 0
     (r0, s0, n0, f0, rw0), (r1, s1, n1, f1, rw1) = res
     assert s0 == s1 and n0 == n1 == 6 + 3 + 1        # conv / bn / linear weight + bias, 3 BatchNorm buffers, the strided tensor
-    assert torch.equal(f0, f1)
+    assert torch.equal(torch.from_numpy(f0), torch.from_numpy(f1))
     assert rw0 == (0, 2) and rw1 == (1, 2)
     random_state = __import__('random').Random(1000)
     assert s0 == random_state.randint(1, 100000)                   # rank 0's draw won
