@@ -26,23 +26,48 @@ def main():
     for i in range(2):
         train_iteration(gan, pool[i % 2], None, optD, optG, losses, prm, dev)
     torch.cuda.synchronize()
+    # fan-in of every autograd node input: an input reached by k >= 2 edges costs k - 1 accumulation launches in the engine
+    orig_backward = torch.Tensor.backward
+
+    def fan_in(root, tag):
+        seen, stack, indeg = set(), [root], collections.Counter()
+        while stack:
+            n = stack.pop()
+            if n is None or id(n) in seen:
+                continue
+            seen.add(id(n))
+            for nxt, idx in n.next_functions:
+                if nxt is not None:
+                    indeg[(id(nxt), idx, type(nxt).__name__)] += 1
+                    stack.append(nxt)
+        multi = collections.Counter()
+        for (_, _, name), k in indeg.items():
+            if k >= 2 and name != 'AccumulateGrad':
+                multi[(name, k)] += 1
+        print('--', tag, ': %d nodes; inputs with fan-in >= 2 (node type, fan-in) x count' % len(seen))
+        for (name, k), c in sorted(multi.items(), key=lambda kv: -kv[1] * (kv[0][1] - 1)):
+            print('   %3d x %-40s fan-in %d  -> %d adds' % (c, name, k, c * (k - 1)))
+
+    def patched(self, *a, **kw):
+        fan_in(self.grad_fn, 'backward of a %s scalar' % (tuple(self.shape),))
+        return orig_backward(self, *a, **kw)
+    torch.Tensor.backward = patched
+    train_iteration(gan, pool[0], None, optD, optG, losses, prm, dev)
+    torch.cuda.synchronize()
+    torch.Tensor.backward = orig_backward
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         train_iteration(gan, pool[0], None, optD, optG, losses, prm, dev)
         torch.cuda.synchronize()
-    evs = [e for e in prof.events() if e.name.startswith('aten::') and e.device_time_total > 0 and not e.cpu_children]
-    sites = collections.Counter()
-    for e in evs:
-        p, chain = e.cpu_parent, []
-        while p is not None:
-            chain.append(p.name)
-            p = p.cpu_parent
-        node = next((n for n in chain if 'Backward' in n or 'AccumulateGrad' in n), None)
-        frame = next((f for f in (e.stack or []) if 'txt2vid_amd' in f), None)
-        sites[(e.name, node or '-', (frame or '-').split('/root/repo/')[-1][:90])] += 1
-    for (name, node, frame), n in sorted(sites.items(), key=lambda kv: -kv[1]):
-        print('%3d  %-22s %-60s %s' % (n, name, node[:60], frame))
-    print('total ATen ops with GPU time:', len(evs))
+    rows = []
+    for e in prof.key_averages(group_by_stack_n=12):
+        if not e.key.startswith('aten::') or getattr(e, 'device_time_total', 0) <= 0:
+            continue
+        frames = [f for f in (e.stack or []) if 'txt2vid_amd' in f or 'autograd' in f]
+        rows.append((e.count, e.key, e.device_time_total, (frames[0] if frames else '-').split('/root/repo/')[-1][:110]))
+    for n, name, us, frame in sorted(rows, key=lambda r: -r[0]):
+        print('%3d  %-24s %8.1f us  %s' % (n, name, us, frame))
+    print('total ATen ops with GPU time:', sum(r[0] for r in rows))
 
 
 if __name__ == '__main__':
