@@ -753,7 +753,6 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
         elif kind == 1:
             name = {0: 'taps', 1: 'cols', 2: 'rows3', 3: 'gemm', 11: 'pool_rows3'}[plan[0]]
             if plan[6] == 1:
-                name = 'taps' if name == 'gemm' else name          # (1x1x1 maps in bf16 mode: the per-tap bf16 kernel, gemm's splits)
                 key = (name, 1, plan[7])
                 assert key in bf_wg, ('bf16 weight-gradient launch covered by no BF16_CASES entry', key, line)
             else:

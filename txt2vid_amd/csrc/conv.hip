@@ -3983,10 +3983,10 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
         ProfScope prof(1, flops, s, p.nchunks * WG_BK, Cin, Cout, live.n, ngroups, p.S);
         int32_t plan_[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
         fill_wgrad_plan(Cin, Cout, p, plan_);
-        plan_[6] = ((flags & T2V_CONV_BF16) && (p.rows3 || Cin >= 64)) ? 1 : 0;       // conv_wgrad3_kernel<true> / conv_wgrad_bf16_kernel
+        plan_[6] = ((flags & T2V_CONV_BF16) && !p.gemm && (p.rows3 || Cin >= 64)) ? 1 : 0;   // conv_wgrad3_kernel<true> / conv_wgrad_bf16_kernel
         plan_[7] = p.strided ? 1 : 0;                                                  // dL/dy on the even frames (dstride = 2)
         ProfScope::set_plan(plan_, 8);
-        if (p.gemm && !(flags & T2V_CONV_BF16)) {
+        if (p.gemm) {                          // (bf16-compute mode too: the fp32 TN product beats the voxel-major bf16 per-tap kernel here)
             dim3 grid((unsigned)(((Cout + 127) / 128) * ((Cin + 127) / 128)), 1u, (unsigned)p.S);
             T2V_LAUNCH_PROF(conv_wgrad_gemm_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, flags, p.cps,
                             dbias ? bias_part : (float*)nullptr);
