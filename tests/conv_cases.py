@@ -45,7 +45,8 @@ SINGLE_CASES = [
     ((16, 128, 4, 4), 256, (3, 3)),          # 2-D, M=256, K=1152: deep split-K
     ((8, 64, 8, 32, 32), 64, (1, 1, 1)),     # 1x1x1 64->64 at M=65536: per-tap weight gradient with the many-splits reduce
     # big 1- / 3-channel 3-D stems run on the narrow-input kernel (conv_stem_kernel): the generic-K tiles they used to reach need other cases
-    ((4, 1, 16, 32, 32), 64, (3, 3, 3)),     # the grey-clip stem at M=65536: conv_stem_kernel<1> (RGB: the Cin=3 case above)
+    ((4, 1, 16, 32, 32), 64, (3, 3, 3)),     # the grey-clip stem at M=65536: conv_stem_mfma_kernel (RGB: the Cin=3 case above, conv_stem_kernel<3>)
+    ((4, 1, 16, 32, 32), 40, (3, 3, 3)),     # Cout % 32 != 0: the lane-per-voxel conv_stem_kernel<1>
     ((6, 20, 16, 32, 32), 64, (3, 3, 3)),    # Cin=20 at M=98304: generic-K 128x64 tile
     ((2, 5, 2, 5, 7), 8, (3, 3, 3)),         # Cin=5, Cout=8: generic-K 128x32 tile
     # 1x1x1 maps with Cin >= 64: the weight gradient is the TN-product kernel (conv_wgrad_gemm_kernel)

@@ -2047,6 +2047,71 @@ __global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable ta
 // arrive through scalar loads (uniform addresses: wp[tap][ci][co .. co+3] as one s_load_dwordx4), four output channels at a time,
 // every store a 256-byte row of consecutive voxels. Algorithmic traffic: 4 * Cin B read + 4 * Cout B written per voxel.
 // ------------------------------------------------------------------------------------------------
+// The grey-clip stem (Cin = 1, Cout a multiple of 32) on the matrix pipes: y[co][v] = sum_t w[t][co] x[v + off_t] is a [Cout x taps] .
+// [taps x voxels] product with K = 27 (padded to 28). A = the weights (rows = channels), B = the shifted input values straight from
+// global memory (columns = 32 consecutive voxels per half-wave, one tap per half), so rows (registers) = channels and columns
+// (lanes) = voxels: every store is a 128-byte run of one channel. Eight waves x 32 voxels per workgroup, no LDS. The lane-per-voxel
+// form below spends 1 728 FMAs + scalar weight loads per lane on what is 28 MFMAs per 32 voxels here; the kernel is then bound by
+// its 256 B of output per voxel.
+__global__ __launch_bounds__(512) void conv_stem_mfma_kernel(const GroupTable tab, const float* __restrict__ wp,
+                                                             const float* __restrict__ bias, const int Cout, const int flags) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+        if (k < tab.n && (int)blockIdx.x >= tab.tile_start[k]) gi = k;
+    const t2v_conv_group& gd = tab.g[gi];
+    const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW;
+    const int M = gd.N * DHW;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int m_w = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + wave * 32;
+    if (m_w >= M) return;                                               // (wave-uniform)
+    const int m = m_w + l31;
+    const bool mv = m < M;
+    const int mm = mv ? m : M - 1;
+    const int n = mm / DHW, sp = mm - n * DHW;
+    const int d = sp / HW, r_ = sp - d * HW;
+    const int h = r_ / W, w_ = r_ - h * W;
+    const float* __restrict__ px = gd.x + (size_t)n * DHW;
+    const bool relu = flags & T2V_CONV_RELU_IN;
+    const bool has_bias = (flags & T2V_CONV_BIAS) && bias != nullptr;
+    const int ntaps = gd.ntaps;
+    const int lt = lane < ntaps ? lane : 0;
+    const int tab_dz = gd.dz[lt], tab_dy = gd.dy[lt], tab_dx = gd.dx[lt];
+    const int tab_w = gd.widx[lt] * Cout;
+    // B operand: lane (voxel l31, k-slot hi) holds x at tap 2 k2 + hi
+    float b[14];
+    int wrow[14];                                                       // float offset of this lane's tap row in wp, -1: padding tap
+#pragma unroll
+    for (int k2 = 0; k2 < 14; ++k2) {
+        const int t0 = 2 * k2, t1 = 2 * k2 + 1;                         // (t1 = 27 is the K padding)
+        const int dz = hi ? __builtin_amdgcn_readlane(tab_dz, t1 < 27 ? t1 : 0) : __builtin_amdgcn_readlane(tab_dz, t0);
+        const int dy = hi ? __builtin_amdgcn_readlane(tab_dy, t1 < 27 ? t1 : 0) : __builtin_amdgcn_readlane(tab_dy, t0);
+        const int dx = hi ? __builtin_amdgcn_readlane(tab_dx, t1 < 27 ? t1 : 0) : __builtin_amdgcn_readlane(tab_dx, t0);
+        const int wr = hi ? __builtin_amdgcn_readlane(tab_w, t1 < 27 ? t1 : 0) : __builtin_amdgcn_readlane(tab_w, t0);
+        const int t = t0 + hi;
+        const bool live = t < ntaps;
+        const int dd = d + dz, hh = h + dy, ww = w_ + dx;
+        const bool ok = live && mv && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const float v = px[ok ? (dd * H + hh) * W + ww : 0];
+        b[k2] = ok ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
+        wrow[k2] = live ? wr : -1;
+    }
+    float* __restrict__ py = gd.y + (size_t)n * Cout * DHW + sp;
+    for (int co0 = 0; co0 < Cout; co0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = has_bias ? bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+        float a[14];
+#pragma unroll
+        for (int k2 = 0; k2 < 14; ++k2) a[k2] = wrow[k2] >= 0 ? wp[wrow[k2] + co0 + l31] : 0.f;     // A: lane (channel l31, k-slot hi)
+#pragma unroll
+        for (int k2 = 0; k2 < 14; ++k2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k2], b[k2], acc, 0, 0, 0);
+        if (mv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) py[(size_t)(co0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * DHW] = acc[r];
+        }
+    }
+}
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, const int Cout, const int flags) {
@@ -2503,7 +2568,8 @@ extern "C" int t2v_conv_fwd_grouped(const t2v_conv_group* groups, int ngroups, i
         for (int i = ngroups; i <= T2V_MAX_GROUPS; ++i) tab.tile_start[i] = (int32_t)mt;
         ProfScope prof(3, flops, s, Mtot_, Cin, Cout, taps_, ngroups, 1);
         ProfScope::set_plan(plan_, 8);
-        if (Cin == 1) T2V_LAUNCH_PROF(conv_stem_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cout, flags);
+        if (Cin == 1 && (Cout % 32) == 0) T2V_LAUNCH_PROF(conv_stem_mfma_kernel, dim3((unsigned)mt), dim3(512), 0, s, tab, wp, bias, Cout, flags);
+        else if (Cin == 1) T2V_LAUNCH_PROF(conv_stem_kernel<1>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cout, flags);
         else T2V_LAUNCH_PROF(conv_stem_kernel<3>, dim3((unsigned)mt), dim3(256), 0, s, tab, wp, bias, Cout, flags);
         return launch_status();
     }
