@@ -843,6 +843,7 @@ def test_iteration_bf16_compute_mode_vs_oracle():
     (64, 1, 4, [8, 16, 32, 64], (2e-2, 5e-2)),              # BASELINE configs[2] at B=4: text-conditioned x bf16 compute
     (64, 1, 32, [8, 16, 32, 64], (2e-2, 5e-2)),             # BASELINE configs[2] AS BENCHMARKED (per-GPU batch 32; also configs[3]'s share)
     (128, 3, 2, [16, 32, 64, 128], (2e-2, 5e-2)),           # BASELINE configs[4] shape at B=2: 16x128x128x3, cond, bf16
+    (128, 3, 16, [16, 32, 64, 128], (2e-2, 5e-2)),          # BASELINE configs[4] at ITS per-GPU batch (128 over 8 GPUs)
 ])
 def test_cond_iteration_bf16_and_fp32_vs_oracle(size, channels, batch, frame_sizes, tol):
     """BASELINE configs[2] and the configs[4] shape (MSRVDC: 16x128x128x3, 2x2 ConvLSTM state, non-local blocks on 64x64 /
