@@ -145,8 +145,7 @@ def test_environment_tunables_move_the_plan():
     assert base['one'][7] == 1                                                          # 1x1x1, K = 8 chunks: never split
     assert base['deep'][7] > 1
     assert base['wbig'][0] == 'rows3' and base['wbig'][1] == 86                          # 768 workgroups aimed at: 86 x 9 = 774
-    assert 700 <= base['wgp'][5] <= 800
-    assert 900 <= _plans_in_child({'T2V_WGRAD_TARGET': '1024'})['wgp'][5] <= 1024            # 114 x 9 = 1026 would start a second round: quantised down
+    assert 900 <= base['wgp'][5] <= 1024                                                # 114 x 9 = 1026 would start a second round: quantised down
     # tile thresholds
     assert _plans_in_child({'T2V_TILE256_MIN': '1'})['small'][:4] == ['strip3', 256, 64, 16]
     assert _plans_in_child({'T2V_TILE128_MIN': '1', 'T2V_TILE256_MIN': '100000'})['small'][:4] == ['strip3', 128, 64, 32]
@@ -160,7 +159,7 @@ def test_environment_tunables_move_the_plan():
     # weight-gradient split count
     assert _plans_in_child({'T2V_WGRAD_SCAP': '64'})['wbig'][1] == 64
     assert _plans_in_child({'T2V_WGRAD_TARGET': '512'})['wbig'][5] <= 600
-    assert _plans_in_child({'T2V_WGRAD_NOQ': '1', 'T2V_WGRAD_TARGET': '1024'})['wgp'][5] == 1026
+    assert _plans_in_child({'T2V_WGRAD_NOQ': '1'})['wgp'][5] == 1026
     assert _plans_in_child({'T2V_WGRAD_TARGET': '3072'})['wbig'][1] == 256              # capped by T2V_WGRAD_SCAP
 
 
