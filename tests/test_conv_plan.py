@@ -144,7 +144,7 @@ def test_environment_tunables_move_the_plan():
     assert base['mid'][:4] == ['strip3', 64, 64, 32] and base['mid'][7] == 1             # 384 tiles of 64: no split
     assert base['one'][7] == 1                                                          # 1x1x1, K = 8 chunks: never split
     assert base['deep'][7] > 1
-    assert base['wbig'][0] == 'rows3' and base['wbig'][1] == 86                          # 768 workgroups aimed at: 86 x 9 = 774
+    assert base['wbig'][0] == 'rows3' and base['wbig'][1] == 113                         # one round: 113 x 9 = 1017 workgroups
     assert 900 <= base['wgp'][5] <= 1024                                                # 114 x 9 = 1026 would start a second round: quantised down
     # tile thresholds
     assert _plans_in_child({'T2V_TILE256_MIN': '1'})['small'][:4] == ['strip3', 256, 64, 16]
