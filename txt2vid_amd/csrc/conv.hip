@@ -2226,7 +2226,7 @@ struct Tunables {
     long force_splits;     // T2V_FORCE_S         (0)  > 0: this split-K count for every forward / data-gradient launch
     bool strip;            // T2V_NO_STRIP unset       strip (three-dx-taps-per-row) kernels enabled
     bool occ_pad;          // T2V_NO_OCC_PAD unset     resident-workgroup choice of the 256-voxel tile (occupancy_pad)
-    long wgrad_target;     // T2V_WGRAD_TARGET    (0)  weight-gradient workgroups to aim at; 0: 768
+    long wgrad_target;     // T2V_WGRAD_TARGET    (0)  weight-gradient workgroups to aim at; 0: 1024 = one round of resident workgroups
     long wgrad_scap;       // T2V_WGRAD_SCAP    (256)  upper bound of the weight-gradient k-split count
     bool wgrad_quantise;   // T2V_WGRAD_NOQ unset      drop a nearly empty last round of weight-gradient workgroups
     long wgrad_min_cps;    // T2V_WGRAD_MINCPS    (4)  fewest 32-voxel chunks a weight-gradient k-split may own
@@ -3927,7 +3927,7 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     // mid-size and the generator's layers), so ONE round: the fewest k-splits, i.e. the smallest slab (50 instead of 113 MB on the
     // stem) and half the reduce time, at the same or a better kernel time.
     const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
-    const long wg_target = wg_env ? wg_env : 768;     // (768 vs 1024 after the 4-chunk minimum: -0.03 ms per iteration, a quarter less slab)
+    const long wg_target = wg_env ? wg_env : 1024;
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     const long mincps = tun().wgrad_min_cps > 0 ? tun().wgrad_min_cps : 8;
     long maxS = (nch + mincps - 1) / mincps;      // at least 4 chunks (128 voxels) per split (8 -> 4: -0.10 ms per iteration, the ~25 small launches are latency chains)
