@@ -3927,6 +3927,8 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
     // mid-size and the generator's layers), so ONE round: the fewest k-splits, i.e. the smallest slab (50 instead of 113 MB on the
     // stem) and half the reduce time, at the same or a better kernel time.
     const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
+    // (768 instead of 1024 — a quarter less slab — was worth 0.02 ms on the benchmark's pyramid launches and cost the full-clip D pass
+    // 0.2 ms: its weight-gradient launches want whole rounds, 3.26 vs 3.05 ms; the default stays)
     const long wg_target = wg_env ? wg_env : 1024;
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;      // (the tiles of a big weight fill the chip on their own)
     const long mincps = tun().wgrad_min_cps > 0 ? tun().wgrad_min_cps : 8;
