@@ -1,7 +1,8 @@
 """North-star target line: "MFMA-roofline fraction on the TGANv2 3D-conv discriminator forward+backward at 64x64x16".
 
 `d_fwdbwd_roofline` runs the Resnet3D discriminator (resnet3d.py:6-57) forward + full backward (data and weight
-gradients) on one un-subsampled clip batch [B,1,16,64,64], fp32, and reports
+gradients, written the way the training step writes them: into the model's flat arena through `functional.GradSink`) on one
+un-subsampled clip batch [B,1,16,64,64], fp32, and reports
   * conv kernels only: executed MAC flops / summed kernel time (HIP events around each launch), vs 157.3 TFLOP/s;
   * all-in: the same flops / wall time of forward+backward (pointwise, pooling, attention and launch gaps included).
 """
@@ -27,11 +28,17 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
     x = (torch.rand(batch, 1, frames, size, size) * 2 - 1).to(dev)
     torch.random.set_rng_state(rng)
 
+    # the backward pass as the training step runs it (gan/trainer.py TrainStep): weight / bias gradients land in the model's flat
+    # arena through the gradient sink — bias sums ride in the weight-gradient kernels, ONE reduce launch per pass
+    from ..dist import model_arena
+    sink = TF.GradSink([model_arena(D, TF.copy_into)])
+    old_sink = TF.set_grad_sink(sink)
+
     def fwd_bwd():
-        for p in D.parameters():
-            p.grad = None
+        TF.grad_sink_reset()
         u, _, _ = D(x=x)
         TF.vec_sum(u.reshape(-1)).backward()
+        TF.grad_sink_flush()
 
     for _ in range(2):
         fwd_bwd()
@@ -47,6 +54,7 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
     torch.cuda.synchronize()
     out = (C.c_double * 18)()
     lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
+    TF.set_grad_sink(old_sink)
     out[0] += out[15]                   # (bf16-compute mode: its GEMM launches count as forward / data-gradient work)
     out[1] += out[16]
     out[2] += out[17]
@@ -55,7 +63,7 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
     ig_fl += out[10] / iters
     flops, conv_ms = ig_fl + wg_fl, ig_ms + wg_ms + red_ms
     P = PEAK_FP32_MFMA_TFLOPS
-    return {'workload': 'Resnet3D D forward+backward, x=[%d,1,%d,%d,%d] fp32, attention %s' % (batch, frames, size, size,
+    return {'workload': 'Resnet3D D forward+backward (parameter gradients through the gradient sink, as in the training step), x=[%d,1,%d,%d,%d] fp32, attention %s' % (batch, frames, size, size,
                                                                                           'on' if attn else 'off'),
             'conv_tflop_per_pass': flops / 1e12,
             'conv_kernels': {'ms': conv_ms, 'tflops': flops / conv_ms / 1e9, 'frac_of_fp32_mfma_peak': flops / conv_ms / 1e9 / P,
