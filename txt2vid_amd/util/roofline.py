@@ -35,6 +35,8 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
     old_sink = TF.set_grad_sink(sink)
 
     def fwd_bwd():
+        for p in D.parameters():         # (what the optimiser step does between two passes: a kept p.grad would make autograd ADD
+            p.grad = None                # the arena view it is handed to the arena view it already holds)
         TF.grad_sink_reset()
         u, _, _ = D(x=x)
         TF.vec_sum(u.reshape(-1)).backward()
