@@ -1775,7 +1775,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GroupTable tab
             if (k < tab.n && i >= tab.out_start[k]) gi = k;
         const long li = i - tab.out_start[gi];
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + i];
+#pragma unroll 8
+        for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + i];      // (unrolled: 8 loads in flight, summed in order)
         if (has_bias) {
             const int DHW = tab.g[gi].D * tab.g[gi].H * tab.g[gi].W;
             v += bias[(li / DHW) % Cout];
