@@ -2345,7 +2345,9 @@ extern "C" int t2v_adam(float* p, const float* g, float* m, float* v, int64_t n,
 // device-side table to keep in sync, and a captured HIP graph keeps the pointers in its kernel node). Block b works on
 // elements [4096 c, 4096 (c+1)) of tensor j, where begin[j] <= b < begin[j+1] and c = b - begin[j].
 #define ADAM_MT 64
+#ifndef ADAM_CHUNK
 #define ADAM_CHUNK 4096
+#endif
 struct AdamBatch {
     float* p[ADAM_MT]; const float* g[ADAM_MT]; float* m[ADAM_MT]; float* v[ADAM_MT];
     int n[ADAM_MT]; int begin[ADAM_MT + 1]; int njobs;
