@@ -443,7 +443,7 @@ def main():
         'config': {'workload': workload,
                    'global_batch': gb, 'per_gpu_batch': args.batch, 'parallelism': 'dp%d' % world,
                    'as_written_tflop_per_step': gf * gb / 1e3 if gf else None},
-        'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (%d graphs/step)' % (4 if txt is not None else 3),
+        'final_losses': {'lossD': lD, 'lossG': lG}, 'launch_mode': 'eager' if graphed is None else 'hip-graph replay (%d graphs/step)' % (graphed.n_graphs + (1 if txt is not None else 0)),
         'as_written_tflops': gf * gb * args.steps / dt / 1e3 if gf else None,
     }
     if grad_sync is not None:

@@ -6,6 +6,7 @@ Random draws follow the reference order on the HOST generators (SURVEY §7 "RNG 
 phase (trainer.py:157-158), z (trainer.py:221, drawn on the CPU and copied), 3x Subsample in G,
 gen_perm (numpy), 4x GP alpha (losses.py:140-145), gen_perm for real_pred (trainer.py:247).
 """
+import os
 import sys
 
 import torch
@@ -161,7 +162,7 @@ def train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=Fa
 class GraphedTrainStep(object):
     """HIP-graph replay of the training iteration (unconditional path): after `warmup` eager iterations
     the three parts of `TrainStep` are captured once (shared memory pool) and every later iteration is
-    3 graph launches + the eager gradient exchange between them. All per-iteration randomness is drawn
+    3 graph launches + the eager gradient exchange between them (one process: ONE graph for the whole iteration). All per-iteration randomness is drawn
     on the host in the reference's order and uploaded into fixed buffers before the replay
     (`functional.StaticDraws`); the batch is copied into a fixed input buffer."""
 
@@ -176,6 +177,7 @@ class GraphedTrainStep(object):
         # conditional path: the sentence code is computed outside the graphs (its sequence length varies) into a fixed buffer
         self.cond = torch.empty((batch_shape[0], cond_dim), device=device, dtype=torch.float32) if cond_dim else None
         self.graphs = None
+        self.n_graphs = 0                    # graphs per iteration of the last capture (1 without a gradient exchange, else 3)
         self.n = 0
         # warm-up and capture run on ONE side stream (the autograd graph's AccumulateGrad nodes remember
         # the stream they were created on; capture must see the same one)
@@ -196,6 +198,18 @@ class GraphedTrainStep(object):
         # thread-local capture mode: the data loader's pin-memory thread keeps issuing pinned allocations and H2D copies
         # while this thread captures; in the default (global) mode any such call invalidates the capture
         mode = 'thread_local'
+        if gs is None and os.environ.get('T2V_THREE_GRAPHS') is None:      # (T2V_THREE_GRAPHS: developer A/B switch)
+            # one process, no gradient exchange between the parts: the whole iteration is ONE graph (two replay launches fewer)
+            with torch.cuda.graph(g1, stream=self.side, capture_error_mode=mode):
+                self.ts.part_d(self.x, self.cond)
+                self.ts.part_g()
+                self.ts.part_end()
+            torch.cuda.synchronize()
+            self.graphs = (g1,)
+            self.n_graphs = 1
+            if self.ts.grad_sink is not None:
+                self.ts.grad_sink.frozen += 1
+            return
         with torch.cuda.graph(g1, stream=self.side, capture_error_mode=mode):
             self.ts.part_d(self.x, self.cond)
             if gs is not None:
@@ -214,6 +228,7 @@ class GraphedTrainStep(object):
             self.ts.part_end()
         torch.cuda.synchronize()
         self.graphs = (g1, g2, g3)
+        self.n_graphs = 3
         if self.ts.grad_sink is not None:
             self.ts.grad_sink.frozen += 1        # the graphs bake in the sink's slab addresses and table slots
 
@@ -251,12 +266,13 @@ class GraphedTrainStep(object):
                 cur.wait_stream(self.side)
             else:
                 self.graphs[0].replay()
-                if self.grad_sync is not None:
-                    self.grad_sync.exchange('D')
-                self.graphs[1].replay()
-                if self.grad_sync is not None:
-                    self.grad_sync.exchange('G')
-                self.graphs[2].replay()
+                if len(self.graphs) == 3:                 # data-parallel: the two exchanges sit between the captured parts
+                    if self.grad_sync is not None:
+                        self.grad_sync.exchange('D')
+                    self.graphs[1].replay()
+                    if self.grad_sync is not None:
+                        self.grad_sync.exchange('G')
+                    self.graphs[2].replay()
             self.n += 1
         finally:
             TF.set_draws(old)
