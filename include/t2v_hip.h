@@ -305,6 +305,8 @@ int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S, const flo
    math of t2v_lstm_gates, fused. `wr` is the unit-major copy of the packed weight, wr[u][k/4][g*4 + j][k%4] = w[k][g*C + 4u + j]
    (t2v_lstm_pack_major, K*4C floats), so that a workgroup's four hidden units are one contiguous stream. act is [B][4C] (i,f,c,o),
    h / c_prev / c_new are [B][C]. t2v_lstm_step_fused_ok: B <= 32, K % 128 == 0, C % 4 == 0 (else the slab pair above). */
+/* out[g*n + i] = src_g[i] for four same-length vectors (the ConvLSTM's gate biases, conv_lstm.py:19-26, packed side by side). */
+int t2v_concat4(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* stream);
 int t2v_lstm_step_fused_ok(int B, int K, int C);
 int t2v_lstm_pack_major(const float* w, float* wr, int K, int C, void* stream);
 int t2v_lstm_step_fused(const float* x, const float* wr, const float* bias, const float* c_prev, float* h, float* c_new,

@@ -155,6 +155,7 @@ SIGNATURES = {
     't2v_skinny_gemm_slab': [_P, _P, _P, _I, _I, _I, _P],
     't2v_lstm_gates_slab': [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     't2v_lstm_gates_bwd_slab': [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    't2v_concat4': [_P, _P, _P, _P, _P, _I, _P],
     't2v_lstm_step_fused_ok': [_I, _I, _I],
     't2v_lstm_pack_major': [_P, _P, _I, _I, _P],
     't2v_lstm_step_fused': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

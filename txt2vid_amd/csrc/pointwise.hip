@@ -913,6 +913,19 @@ extern "C" int t2v_lstm_gates_bwd_slab(const float* gh, const float* slab, int S
     return launch_status();
 }
 
+// out[g*n + i] = src_g[i], g = 0..3: the four gate biases side by side in one launch (was four 4-us copies per forward pass)
+__global__ void concat4_k(const float* a, const float* b, const float* c, const float* d, float* out, int n) {
+    GRID_STRIDE(i, 4L * n) {
+        const int g = (int)(i / n), r = (int)(i - (long)g * n);
+        const float* src = g == 0 ? a : g == 1 ? b : g == 2 ? c : d;
+        out[i] = src[r];
+    }
+}
+extern "C" int t2v_concat4(const float* a, const float* b, const float* c, const float* d, float* out, int n, void* st) {
+    if (!a || !b || !c || !d || !out || n < 1) return T2V_EINVAL;
+    T2V_LAUNCH(concat4_k, dim3(nblocks(4L * n)), dim3(256), 0, S_(st), a, b, c, d, out, n);
+    return launch_status();
+}
 // ---- one launch per recurrence step: GEMM + gate math fused (replaces skinny_gemm_slab + lstm_gates_slab, 17.5 -> ~7 us per step).
 // A workgroup owns FOUR hidden units = 16 of the 4C gate columns (i,f,c,o of each unit), so the gate math needs nothing from any other
 // workgroup. Its 16 weight columns live contiguously in the "unit-major" copy  wr[u][k/4][g*4 + j][k%4] = wp[k][g*C + 4u + j]  (lstm_pack_major_k,

@@ -1504,8 +1504,7 @@ class ConvLSTMFn(Function):
         wpx = packed_fused(wx5, ts, 0)
         wph = packed_fused(wh5, ts, 0)
         bias4 = torch.empty((4 * Cc,), device=dev, dtype=torch.float32)
-        for g in range(4):
-            _copy2d(bx[g], 0, Cc, bias4, g * Cc, Cc, 1, Cc)
+        check(lib().t2v_concat4(_p(_c(bx[0])), _p(_c(bx[1])), _p(_c(bx[2])), _p(_c(bx[3])), _p(bias4), Cc, _stream()), 't2v_concat4')
         hs = torch.empty((steps, B, Cc, 1, h, w), device=dev, dtype=torch.float32)
         cs = torch.empty((steps + 1, B, Cc, h, w), device=dev, dtype=torch.float32)
         acts = torch.empty((steps, B, 4 * Cc, h, w), device=dev, dtype=torch.float32)
