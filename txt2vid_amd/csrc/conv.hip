@@ -1220,8 +1220,14 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     const int Dq = tm ? Dn + 1 : 1, Hq = Hn + 1, Wq = Wn + 1;                 // the padded-grid planes
     const int HWn = Hn * Wn, Vn = Dn * HWn;
     const int HWq = Hq * Wq, Vq = Dq * HWq;
-    const int M = gd.N * Vq;
+    // rows run over THIS class pair's part of the padded grid: an odd-parity class only lives on the first D' / H' positions of its
+    // axis (its padded index 2a + 1 must stay inside the box-summed tensor), so its rows are (De, He, Wq) with De = D' / He = H' —
+    // the unbox pass never reads the rest. The tile table counts tiles of the full padded grid: the surplus workgroups leave at once.
+    const int De = (tm && ct) ? Dn : Dq, He = cy ? Hn : Hq;
+    const int HWe = He * Wq, Ve = De * HWe;
+    const int M = gd.N * Ve;
     const int m0 = (tile - tab.tile_start[gi]) * BM;
+    if (m0 >= M) return;                                         // (uniform)
     // kernel rows of this class pair: dz in {-1,+1} (ct = 0) or {0} (ct = 1; also tmode 0), dy likewise
     const int ndz = (tm && ct == 0) ? 2 : 1, ndy = cy == 0 ? 2 : 1;
     const int nrow = ndz * ndy;
@@ -1241,17 +1247,17 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     {
         const int m_a = m0 + ma_l;
         if (m_a < M) {
-            const int n = m_a / Vq, sp = m_a - n * Vq;
-            s_at = sp / HWq;
-            const int r = sp - s_at * HWq;
+            const int n = m_a / Ve, sp = m_a - n * Ve;
+            s_at = sp / HWe;
+            const int r = sp - s_at * HWe;
             s_a = r / Wq;
             s_b = r - s_a * Wq;
             s_n = (uint32_t)n;
         }
         if (m0 < M) {                            // left neighbour of the tile's first voxel: same row, b - 1 (only read when b >= 1)
-            const int n = m0 / Vq, sp = m0 - n * Vq;
-            h_at = sp / HWq;
-            const int r = sp - h_at * HWq;
+            const int n = m0 / Ve, sp = m0 - n * Ve;
+            h_at = sp / HWe;
+            const int r = sp - h_at * HWe;
             h_a = r / Wq;
             h_b = r - h_a * Wq - 1;
             h_n = (uint32_t)n;
@@ -1388,11 +1394,12 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     // plane bytes, in a kernel whose 32 KB of output per 2-8 barrier rounds make it store-bound.
     const int m = m0 + wm * WM + l31;
     if (m < M) {
-        const int n = m / Vq, sp = m - n * Vq;
-        const int at = sp / HWq, r2 = sp - at * HWq;
+        const int n = m / Ve, spe = m - n * Ve;
+        const int at = spe / HWe, r2 = spe - at * HWe;
         const int a = r2 / Wq, b = r2 - a * Wq;
-        const bool row_ok = (ct == 0 || at < Dn) && (cy == 0 || a < Hn);
-        const bool ok1 = row_ok && b < Wn;
+        const int sp = (at * Hq + a) * Wq + b;                   // position in the PADDED plane (what pool_unbox_k indexes)
+        constexpr bool row_ok = true;                            // (every row of the class grid is read)
+        const bool ok1 = b < Wn;
         const size_t plane = (size_t)gd.N * C * Vq;
         float* p0 = gd.y + ((size_t)blockIdx.z * 8 + (size_t)((ct * 2 + cy) * 2 + 0)) * plane + (size_t)n * C * Vq + sp;
         float* p1 = p0 + plane;
