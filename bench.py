@@ -72,6 +72,7 @@ def synthetic_batches(batch, n, seed, dev, size=64, channels=1):
         # generated in HBM by t2v_synth_clips (bit-identical to the host items ds[i]: tests/test_data_gpu.py)
         vids, _, _ = ds.device_batch(range(i * batch, (i + 1) * batch), dev)         # [B,T,C,H,W]
         out.append(TF.video_to_channel_first(vids))                                   # [B,C,T,H,W]
+    ds.check_device_draws()
     return out
 
 
@@ -131,20 +132,102 @@ def cpu_baseline(threads, budget_s=45.0):
             'steps_per_sec': 1.0 / dt}
 
 
-def extra_record(flags):
-    """Run `python bench.py <flags>` as a child (no CPU baseline, no roofline passes) and return the fields of its JSON line that
-    identify and size the measurement; an error string if it failed."""
+_LAUNCHER_ENV = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK', 'ROLE_NAME',
+                 'ROLE_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')
+
+
+def child_env():
+    """The environment of a child bench job: this process's, minus what a `torch.distributed.run` parent put there for THIS rank
+    (the child is a whole job of its own: `python bench.py --gpus N` starts its own ranks on its own port)."""
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCHER_ENV and not k.startswith('TORCHELASTIC_')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return env
+
+
+def extra_record(flags, timeout=600):
+    """Run `python bench.py <flags>` as a child JOB (no CPU baseline, no roofline passes; with `--gpus N` it starts its own N ranks)
+    and return the fields of its JSON line that identify and size the measurement; an error string if it failed or timed out.
+    A child job cannot take this process's headline down: a rank that raises or hangs in there only loses the extra record
+    (the child's whole process group is killed at the timeout)."""
+    import signal
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_roofline', '--no_d_roofline', '--no_extra', '--no_hbm']
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-        line = [l for l in p.stdout.decode(errors='replace').splitlines() if l.startswith('{')]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=child_env(), start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)                  # the exact process group this call started
+            p.communicate()
+            return {'error': 'child job exceeded %d s and was killed' % timeout}
+        line = [l for l in so.decode(errors='replace').splitlines() if l.startswith('{')]
         if p.returncode != 0 or not line:
-            return {'error': 'child exited %d: %s' % (p.returncode, p.stderr.decode(errors='replace')[-300:])}
+            return {'error': 'child exited %d: %s' % (p.returncode, se.decode(errors='replace')[-300:])}
         r = json.loads(line[-1])
-        return {k: r.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_losses', 'launch_mode')}
+        keys = ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'final_losses', 'launch_mode',
+                'allreduce_ms_per_step', 'allreduce', 'rccl_ranks', 'roofline', 'hbm_bound')
+        return {k: r[k] for k in keys if k in r}
     except Exception as e:                                    # never let the extra record take the headline down
         return {'error': repr(e)[:300]}
+
+
+def sampling_record(gan, batch, dev, iters=20):
+    """The metric's second half (eval-mode generated [B,C,16,S,S] videos/s): the calls of `trainer.test`
+    (txt2vid/gan/trainer.py:44-90 -> txt2vid_amd/gan/trainer.py:test) minus the PNG writer — eval-mode generator, one latent per
+    clip, no sub-sampling, last level only — on the models of the timed run."""
+    gan.gen.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                z = torch.randn(batch, gan.gen.latent_size).to(dev)
+                out = gan(z, cond=None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                z = torch.randn(batch, gan.gen.latent_size).to(dev)
+                out = gan(z, cond=None)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters
+        shape = list(out[0].shape)
+    finally:
+        gan.gen.train()
+    return {'videos_per_s': batch / dt, 'ms_per_batch': dt * 1e3, 'batch': batch, 'clip': shape, 'launch_mode': 'eager',
+            'gflop_per_video_as_written': 9.95, 'tflops_as_written': 9.95 * batch / dt / 1e3,
+            'what': 'eval-mode generator through trainer.test\'s calls (no PNG writer), z drawn on the host per batch as there'}
+
+
+def cli_record(batch, iters=60, timeout=420):
+    """ms per iteration of the REAL command line loop (`python -m txt2vid_amd.train.gan`, the reference's flags: synthetic
+    Moving-MNIST clips through the DataLoader + pinned prefetcher + HIP-graph replay, losses read one iteration late), beside
+    the bench loop's `ms_per_step`. Child process; parsed from the loop's own `sec/iter` log line (rolling mean of the last 20)."""
+    import re
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='t2v_cli_')
+    cfg = os.path.join(tmp, 'synth.json')
+    with open(cfg, 'w') as f:
+        json.dump({'class': 'txt2vid.data.my_dataset', 'args': {'data': 'synthetic', 'num_frames': 16, 'length': batch * (iters + 4)}}, f)
+    cmd = [sys.executable, '-m', 'txt2vid_amd.train.gan', '--data', cfg, '--num_channels', '1', '--cuda', '--frame_sizes', '8', '16', '32', '64',
+           '--D_names', 'video', '--G_lr', '0.0002', '--D_lr', '0.0002', '--D_beta1', '0.5', '--D_beta2', '.999', '--G_beta1', '0.5',
+           '--G_beta2', '.999', '--D_loss', 'txt2vid.gan.losses.RSGANLoss', '--init_method', 'xavier', '--discrim_steps', '1', '--seed', '100',
+           '--gp_lambda', '.5', '--subsample_input', '--workers', '4', '--log_period', '20', '--G', 'txt2vid.models.tganv2.gen.MultiScaleGen',
+           '--D', 'txt2vid.models.tganv2.discrim.MultiScaleDiscrim', '--dont_use_sent', '--batch_size', str(batch), '--epochs', '1',
+           '--out', os.path.join(tmp, 'out'), '--out_samples', os.path.join(tmp, 'samples'), '--max_iters', str(iters),
+           '--save_model_period', '0', '--save_example_period', '0']
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=child_env())
+        out = p.stdout.decode(errors='replace')
+        m = re.findall(r'Iter (\d+),.*? - ([0-9.]+) sec/iter; ([0-9.]+) sec/batch load', out)
+        if p.returncode != 0 or not m:
+            return {'error': 'CLI exited %d: %s' % (p.returncode, out[-300:])}
+        it, sec, load = m[-1]
+        return {'ms_per_iter': float(sec) * 1e3, 'wait_for_batch_ms': float(load) * 1e3, 'at_iteration': int(it), 'batch': batch,
+                'what': 'python -m txt2vid_amd.train.gan (reference flags, synthetic clips, 4 loader workers, graph replay), mean of the last 20 iterations'}
+    except Exception as e:
+        return {'error': repr(e)[:300]}
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def self_launch(n):
@@ -470,6 +553,14 @@ def main():
         from txt2vid_amd.util.roofline import d_fwdbwd_roofline
         log('D forward+backward roofline pass')
         res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
+    if rank == 0 and world == 1 and not args.no_extra and not args.cond and not bf16 and default_shape:
+        log('sampling (eval-mode generator) and the CLI loop')
+        try:
+            res['sampling'] = sampling_record(gan, args.batch, dev)
+        except Exception as e:                                    # side measurements never take the headline down
+            res['sampling'] = {'error': repr(e)[:300]}
+        if not args.eager:
+            res['cli_ms_per_iter'] = cli_record(args.batch)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond and default_shape:
         log('timing the CPU oracle on %d host threads' % host_threads())
         res['cpu_baseline'] = cpu_baseline(host_threads())
@@ -489,38 +580,22 @@ def main():
                 res['hbm_bound']['pmc'] = 'profiles/r03_pmc_hbm.json (rocprofv3 FETCH_SIZE / WRITE_SIZE per launch of the same micro-benchmark)'
         except Exception as e:                                    # never let a side measurement take the headline down
             res['hbm_bound'] = {'error': repr(e)[:300]}
-    if world > 1 and not args.no_extra and not args.cond and not bf16 and default_shape and not args.eager:
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()     # the headline is complete: nothing below takes part in a collective of THIS job
+    if world > 1 and rank == 0 and not args.no_extra and not args.cond and not bf16 and default_shape and not args.eager:
         # BASELINE configs[3] (the scaling config: text-conditioned, bf16 compute, per-GPU batch 32, RCCL data parallel) as an EXTRA
-        # record beside the configs[1] value: the same ranks, after the headline's timed region — never part of `value`
-        log('extra record: BASELINE configs[3] on the same %d ranks' % world)
+        # record beside the configs[1] value — never part of `value`. It runs as a CHILD JOB with its own ranks (the other ranks of
+        # this job have left by now): a rank of it that raises or hangs costs the extra record, never the headline line below.
+        log('extra record: BASELINE configs[3] as a child job on %d ranks' % world)
         del R, gan, optD, optG, graphed, grad_sync, pool
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        rec = None
-        try:
-            TF.set_conv_precision('bf16')
-            R3 = timed_run(args, True, args.size, args.channels, 10, 3, rank, world, dev, lambda m: log('[configs[3]] ' + m))
-            t3 = torch.tensor([R3.dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-            ex3 = torch.tensor([R3.exchange['D'], R3.exchange['G']], device=dev, dtype=torch.float64)
-            dist.all_reduce(ex3, op=dist.ReduceOp.MAX)
-            dt3 = float(t3.item())
-            rec = {'value': gb * 10 / dt3, 'unit': 'videos/s', 'ms_per_step': dt3 / 10 * 1e3, 'steps': 10, 'warmup': R3.warmup, 'n_gpus': world,
-                   'dtype': 'bf16 compute, f32 storage + accumulation (pooled conv2 layers: fp32 GEMMs)',
-                   'allreduce_ms_per_step': float(ex3.sum().item()) / 10,
-                   'config': {'workload': 'BASELINE configs[3]: text-conditioned TGANv2 16x64x64x1, per-GPU batch %d, bf16 compute, data parallel '
-                                          'over %d ranks' % (args.batch, world), 'global_batch': gb, 'parallelism': 'dp%d' % world},
-                   'final_losses': {'lossD': R3.lD, 'lossG': R3.lG}}
-        except Exception as e:
-            rec = {'error': repr(e)[:300]}
-        finally:
-            TF.set_conv_precision('fp32')
-        res.setdefault('extra_records', {})['configs[3]'] = rec
+        res.setdefault('extra_records', {})['configs[3]'] = extra_record(
+            ['--gpus', str(world), '--cond', '--bf16', '--batch', str(args.batch), '--steps', '10', '--warmup', '3'], timeout=420)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -447,6 +447,10 @@ int t2v_pyramid_gather(const float* x, float* y, int B, int C, int T, int H, int
 /* ---- layout glue: the permutes / slices between the reference's tensor layouts --------------------
  * (torch.stack/permute/view of models/tganv2/gen.py:75-119, torch.cat of resnet3d.py:53) */
 int t2v_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int64_t cols, void* stream);
+/* fp32 <-> bf16 stream (round to nearest even) for the opt-in bf16 gradient exchange of the data-parallel path (SURVEY §8(e);
+ * the exchange the reference's call sites txt2vid/gan/trainer.py:240-241,262-263 imply under one process per GPU).
+ * dir 0: dst (bf16) <- src (fp32); dir 1: dst (fp32) <- src (bf16); n elements, 16-byte aligned pointers. */
+int t2v_cast_bf16(const void* src, void* dst, int64_t n, int dir, void* stream);
 int t2v_permute01(const float* x, float* y, int64_t A, int64_t B, int64_t inner, void* stream);   /* [A,B,i]->[B,A,i]   */
 int t2v_permute12(const float* x, float* y, int64_t A, int64_t B, int64_t C, int64_t inner, void* stream); /* [A,B,C,i]->[A,C,B,i] */
 /* merged-frames [b*T, inner]: keep samples ::2 and frames bt::2 (gen.py:98-109); adjoint=1 scatters y into x */

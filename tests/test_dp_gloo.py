@@ -171,3 +171,129 @@ def test_replicas_identical_without_seed_world2():
     assert rw0 == (0, 2) and rw1 == (1, 2)
     random_state = __import__('random').Random(1000)
     assert s0 == random_state.randint(1, 100000)                   # rank 0's draw won
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from txt2vid_amd import dist as tdist
+    tdist.init_from_env('gloo')
+    g = torch.Generator()
+    g.manual_seed(5 + rank)
+    w = torch.nn.Parameter(torch.zeros(4, 3, 3, 3))               # structurally sparse weight: taps 4 and 7 live
+    b = torch.nn.Parameter(torch.zeros(37))                       # (an odd count: the compact part must still start aligned)
+    gw = torch.zeros(4, 3, 9)
+    gw[:, :, 4] = torch.randn(4, 3, generator=g)
+    gw[:, :, 7] = torch.randn(4, 3, generator=g)
+    w.grad = gw.view(4, 3, 3, 3).clone()
+    b.grad = torch.randn(37, generator=g)
+    arena = tdist.GradArena([w, b], live_taps={w: [4, 7]}, exchange_dtype=torch.bfloat16)
+
+    class Opt(object):
+        grad_scale = 1.0
+    sync = tdist.make_grad_sync({'G': arena}, {'G': Opt()}, world)
+    sync.time_exchanges(True)
+    sync('G')
+    ms = sync.exchange_ms()
+    q.put((rank, w.grad.numpy().copy(), b.grad.numpy().copy(), gw.numpy().copy(), arena.exchanged_bytes(), ms))
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_world2():
+    """The opt-in half-size exchange (SURVEY §8(e) "optionally reduce in bf16"; GradArena(exchange_dtype=torch.bfloat16) /
+    T2V_GRAD_EXCHANGE=bf16): ONE collective over [dense | live taps] in bf16. The replicas receive bit-identical gradients, each
+    within bf16 rounding of the fp32 sum (|err| <= 2^-8 (|a| + |b| + |a + b|)), dead taps stay exactly zero, the bytes halve —
+    and the exchange is timed on host arenas too (GradSync.time_exchanges / exchange_ms)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, w0, b0, g0, n0, ms0), (r1, w1, b1, g1, n1, ms1) = res
+    assert (w0 == w1).all() and (b0 == b1).all()                                 # replicas identical, bit for bit
+    assert n0 == n1 == 2 * (37 + 4 * 3 * 2)
+    want = torch.from_numpy(g0) + torch.from_numpy(g1)
+    got = torch.from_numpy(w0).view(4, 3, 9)
+    bound = 2.0 ** -8 * (torch.from_numpy(g0).abs() + torch.from_numpy(g1).abs() + want.abs()) + 1e-12
+    assert ((got - want).abs() <= bound).all()
+    dead = [t for t in range(9) if t not in (4, 7)]
+    assert (got[:, :, dead] == 0).all()
+    assert ms0['n'] == 1 and ms0['G'] > 0 and ms1['n'] == 1 and ms0['D'] == 0.0
+
+
+def _shared_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from txt2vid_amd import dist as tdist
+    tdist.init_from_env('gloo')
+    # --end2end under data parallelism (train/gan.py): the text encoder's parameters sit in BOTH models' arenas
+    dis, gen, enc = torch.nn.Linear(3, 2), torch.nn.Linear(3, 4), torch.nn.Linear(5, 3)
+    for m in (dis, gen, enc):
+        for p in m.parameters():
+            torch.nn.init.constant_(p, 0.5)
+
+    class Opt(object):
+        grad_scale = 1.0
+    arenas = {'D': tdist.model_arena([dis, enc]), 'G': tdist.model_arena([gen, enc])}
+    sync = tdist.make_grad_sync(arenas, {'D': Opt(), 'G': Opt()}, world)
+    x = torch.full((2, 5), float(rank + 1))
+    out = {}
+    for it in range(2):                                               # two iterations: the aliases of the first must not leak into the second
+        # D step: backward through dis(enc(x)) -> exchange 'D' -> p.grad of the encoder aliases the D arena
+        for m in (dis, enc):
+            m.zero_grad(set_to_none=True)
+        dis(enc(x)).sum().backward()
+        sync('D')
+        out['D%d' % it] = [p.grad.clone() for p in list(dis.parameters()) + list(enc.parameters())]
+        d_alias = [p.grad.data_ptr() for p in enc.parameters()]
+        # G step (cond_gan.py:90-118 zeroes G's and the encoder's gradients first): a fresh gradient for the encoder
+        for m in (gen, enc):
+            m.zero_grad(set_to_none=True)
+        (gen(enc(x)) * 2.0).sum().backward()
+        assert all(p.grad.data_ptr() != a for p, a in zip(enc.parameters(), d_alias))          # not written into the D arena
+        keep = arenas['D'].flat.clone()
+        sync('G')
+        assert torch.equal(arenas['D'].flat, keep)                                               # the G exchange leaves D's arena alone
+        out['G%d' % it] = [p.grad.clone() for p in list(gen.parameters()) + list(enc.parameters())]
+    q.put((rank, {k: [t.numpy().copy() for t in v] for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_end2end_shared_encoder_in_both_arenas_world2():
+    """with --end2end the sentence encoder's parameters are members of the D arena AND the G arena. After the D
+    exchange their p.grad aliases D's arena; the G step's zero_grad drops the alias, its backward produces fresh gradients and
+    the G exchange sums THOSE — both exchanges give the all-rank sums, on both iterations, and neither arena is written through
+    the other's views."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # reference: the same two backward passes per rank, summed by hand
+    want = {}
+    for rank in range(2):
+        dis, gen, enc = torch.nn.Linear(3, 2), torch.nn.Linear(3, 4), torch.nn.Linear(5, 3)
+        for m in (dis, gen, enc):
+            for p in m.parameters():
+                torch.nn.init.constant_(p, 0.5)
+        x = torch.full((2, 5), float(rank + 1))
+        dis(enc(x)).sum().backward()
+        gD = [p.grad.clone() for p in list(dis.parameters()) + list(enc.parameters())]
+        enc.zero_grad(set_to_none=True)
+        (gen(enc(x)) * 2.0).sum().backward()
+        gG = [p.grad.clone() for p in list(gen.parameters()) + list(enc.parameters())]
+        for k, g in (('D', gD), ('G', gG)):
+            want[k] = [a + b for a, b in zip(want[k], g)] if k in want else g
+    for rank, out in res:
+        for it in range(2):
+            for k in ('D', 'G'):
+                for got, w in zip(out['%s%d' % (k, it)], want[k]):
+                    assert torch.allclose(torch.from_numpy(got), w), (rank, k, it)

@@ -96,3 +96,50 @@ def test_arena_gather_copies_dense_gradients_into_tap_major_slots():
     arena.gather()
     torch.cuda.synchronize()
     assert torch.equal(arena.views()[[i for i, q in enumerate(arena.params) if q is w][0]], g * 3)
+
+
+def test_bf16_exchange_casts_and_one_launch_tap_pack():
+    """The device side of the opt-in bf16 gradient exchange: t2v_cast_bf16 rounds like torch (round to nearest even, a NaN stays a
+    NaN) for counts with a tail, and an arena with a bf16 exchange buffer packs / widens its [dense | live taps] halves in
+    place (the collective itself is rehearsed over gloo in tests/test_dp_gloo.py)."""
+    import torch
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.dist import GradArena
+    dev = 'cuda:0'
+    g = torch.Generator(device='cpu')
+    g.manual_seed(3)
+    x = (torch.randn(100003, generator=g) * 3).to(dev)
+    x[5], x[6], x[7] = float('nan'), float('inf'), -0.0
+    arena = GradArena([torch.nn.Parameter(torch.zeros(100003, device=dev))], TF.copy_into, exchange_dtype=torch.bfloat16)
+    arena.flat.copy_(x)
+    arena._cast(arena.flat, arena.half[:100003], True)
+    want = x.to(torch.bfloat16)
+    torch.cuda.synchronize()
+    got = arena.half[:100003]
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    ok = ~torch.isnan(want)
+    assert torch.equal(got[ok].view(torch.int16), want[ok].view(torch.int16))
+    arena._cast(arena.half[:100003], arena.flat, False)
+    torch.cuda.synchronize()
+    assert torch.equal(arena.flat[ok], want[ok].float())
+    # tap-major weights: the live rows go to the compact buffer (and back) in one multi-job launch per direction
+    ws = [torch.nn.Parameter(TF.tap_major(torch.zeros(8, 6, 3, 3, device=dev))) for _ in range(9)]          # 9 jobs: two launches of <= 8
+    b = torch.nn.Parameter(torch.zeros(5, device=dev))
+    a2 = GradArena([b] + ws, TF.copy_into, live_taps={w: [4] for w in ws}, exchange_dtype=torch.bfloat16)
+    vals = [torch.randn(8, 6, 3, 3, generator=g).to(dev) for _ in ws]
+    for w, v in zip(ws, vals):
+        w.grad = TF.tap_major(v.clone())
+    b.grad = torch.ones(5, device=dev)
+    a2.gather()
+    a2._taps(True)
+    torch.cuda.synchronize()
+    for i, v in enumerate(vals):
+        assert torch.equal(a2.compact[i * 48:(i + 1) * 48].view(8, 6), v[:, :, 1, 1])
+    a2.compact.mul_(2.0)
+    a2._taps(False)
+    torch.cuda.synchronize()
+    views = dict(zip([id(p) for p in a2.params], a2.views()))
+    for w, v in zip(ws, vals):
+        got = views[id(w)]
+        assert torch.equal(got[:, :, 1, 1], 2 * v[:, :, 1, 1]) and torch.equal(got[:, :, 0, 0], v[:, :, 0, 0])
+    assert a2.exchanged_bytes() == 2 * (5 + 9 * 48)

@@ -1,6 +1,11 @@
 """Loss-curve parity over many iterations (BASELINE.json north_star: "loss curves matching reference within 1e-3 over 100 steps").
 
-  python tools/parity_steps.py [steps=100] [out.json]
+  python tools/parity_steps.py [steps=100] [out.json] [--cond]
+
+`--cond`: the TEXT-CONDITIONED loop (BASELINE configs[2] recipe at B=4: Bi-LSTM sentence codes of fresh captions every iteration,
+cat(z, cond), 2-D + 3-D non-local blocks, second D head, mismatched-caption loss, GP with interpolated codes;
+txt2vid/gan/cond_gan.py:34-87,90-118) — teacher-forced in fp32 (bound 1e-3) AND in bf16-compute mode (the separately stated
+bound |dlossD| < 2e-2, |dlossG| < 5e-2 of tests/test_models_gpu.py::test_cond_iteration_bf16_and_fp32_vs_oracle).
 
 The CPU oracle (pinned to the real reference by tests/test_oracle_golden.py) free-runs `steps` G+D iterations of the
 unconditional config-1 recipe at B=4 (RSGAN + GP 0.5, Adam 2e-4 (0.5, 0.999), sub-sampled pyramid 8/16/32/64). Two instances
@@ -30,9 +35,85 @@ from txt2vid_amd.gan.trainer import train_iteration  # noqa: E402
 from txt2vid_amd.util.misc import limit_host_threads  # noqa: E402
 
 
+def main_cond(steps, out):
+    """Text-conditioned loop, teacher-forced: fp32 and bf16-compute instances against the free-running fp32 oracle."""
+    from txt2vid_amd import functional as TF
+    limit_host_threads()
+    dev = TM.DEV
+    V, B = 21, 4
+    inst = {'fp32': TM._make_cond(V), 'bf16': TM._make_cond(V)}
+    PT = O.recipe_state(O.text_encoder_shapes(V))
+    tr = O.OracleTrainer(O.recipe_state(O.gen_shapes(num_channels=1, width=64, height=64, cond_dim=256, cond_variant=True)),
+                         O.recipe_state(O.resnet3d_shapes('single_discrim.module.', 1, 64, 256)),
+                         d_prefix='single_discrim.module.', frame_sizes=[8, 16, 32, 64])
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    tg = torch.Generator()
+    tg.manual_seed(77)
+    bounds = {'fp32': (1e-3, 1e-3), 'bf16': (2e-2, 5e-2)}
+    rows = []
+    t_start = time.time()
+    for it in range(steps):
+        x = (torch.rand(B, 16, 1, 64, 64) * 2 - 1).permute(0, 2, 1, 3, 4).contiguous()
+        tokens = torch.randint(4, V, (B, 8), generator=tg)
+        tokens[:, 0], tokens[:, -1] = 1, 2
+        state = (torch.get_rng_state(), np.random.get_state(), random.getstate())
+
+        def rewind():
+            torch.set_rng_state(state[0])
+            np.random.set_state(state[1])
+            random.setstate(state[2])
+        row = {'it': it}
+        for mode in ('fp32', 'bf16'):
+            gan, optD, optG, losses, prm = inst[mode]
+            old = TF.set_conv_precision(mode)
+            try:
+                TM._sync_from_oracle(tr, gan, optD, optG)
+                with torch.no_grad():
+                    _, _, cond = gan.cond_encoder.encode(tokens.to(dev), [8] * B)
+                lD, lG, _, _ = train_iteration(gan, x.to(dev), cond.detach(), optD, optG, losses, prm, dev)
+                row[mode] = [float(lD), float(lG)]
+            finally:
+                TF.set_conv_precision(old)
+            rewind()
+        with torch.no_grad():
+            cond_o = O.text_encode(PT, tokens, [8] * B)
+        lD_o, lG_o = tr.step(x, cond=cond_o)
+        row['oracle'] = [lD_o, lG_o]
+        rows.append(row)
+        print('it %3d  oracle D %.6f G %.6f | fp32 dD %.2e dG %.2e | bf16 dD %.2e dG %.2e   (%.0f s)'
+              % (it, lD_o, lG_o, abs(row['fp32'][0] - lD_o), abs(row['fp32'][1] - lG_o), abs(row['bf16'][0] - lD_o), abs(row['bf16'][1] - lG_o),
+                 time.time() - t_start), flush=True)
+    res = {'protocol': 'text-conditioned configs[2] recipe at B=4 (fresh 8-token captions every iteration, Bi-LSTM sentence codes, RSGAN + GP 0.5, '
+                       'Adam 2e-4 (0.5, 0.999), pyramid 8/16/32/64), seeds 7 / 77, fp32 oracle free-running on the host, HIP instances '
+                       'teacher-forced (weights, BN buffers, Adam moments from the oracle before every iteration); see tools/parity_steps.py --cond',
+           'steps': steps, 'oracle_loss_range': {'lossD': [min(r['oracle'][0] for r in rows), max(r['oracle'][0] for r in rows)],
+                                                 'lossG': [min(r['oracle'][1] for r in rows), max(r['oracle'][1] for r in rows)]}}
+    ok = True
+    for mode in ('fp32', 'bf16'):
+        dD = [abs(r[mode][0] - r['oracle'][0]) for r in rows]
+        dG = [abs(r[mode][1] - r['oracle'][1]) for r in rows]
+        res[mode] = {'bound': {'lossD': bounds[mode][0], 'lossG': bounds[mode][1]}, 'max_abs_lossD_error': max(dD), 'max_abs_lossG_error': max(dG),
+                     'mean_abs_lossD_error': float(np.mean(dD)), 'mean_abs_lossG_error': float(np.mean(dG)),
+                     'steps_within_bound': int(sum(a < bounds[mode][0] and b < bounds[mode][1] for a, b in zip(dD, dG))),
+                     'steps_within_1e-3': int(sum(a < 1e-3 and b < 1e-3 for a, b in zip(dD, dG)))}
+        ok = ok and res[mode]['steps_within_bound'] == steps
+    res['curve'] = rows
+    print(json.dumps({k: v for k, v in res.items() if k != 'curve'}))
+    if out:
+        with open(out, 'w') as f:
+            json.dump(res, f, indent=1)
+    if not ok:
+        raise SystemExit('a teacher-forced loss left its bound')
+
+
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    out = sys.argv[2] if len(sys.argv) > 2 else None
+    argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+    steps = int(argv[0]) if len(argv) > 0 else 100
+    out = argv[1] if len(argv) > 1 else None
+    if '--cond' in sys.argv:
+        return main_cond(steps, out)
     limit_host_threads()
     dev = TM.DEV
     forced = TM._make_uncond()

@@ -188,6 +188,7 @@ SIGNATURES = {
     't2v_adam_tick': [_P, _F, _F, _P],
     't2v_pyramid_gather': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     't2v_copy2d': [_P, _L, _P, _L, _L, _L, _P],
+    't2v_cast_bf16': [_P, _P, _L, _I, _P],
     't2v_permute01': [_P, _P, _L, _L, _L, _P],
     't2v_permute12': [_P, _P, _L, _L, _L, _L, _P],
     't2v_subsample_frames': [_P, _P, _L, _L, _L, _L, _L, _I, _I, _P, _P],

@@ -15,6 +15,31 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// In-kernel timeline stamps: a DIAGNOSTIC build only (-DT2V_STAMPS, tools/stamps.py); the product library has none of it.
+// One record of 16 x u64 per wave: [0] entry, [1] loop start, [2] loop end, [3] exit (s_memtime ticks), [4..8] summed ticks of
+// the stage / first barrier / load issue / MFMA loop / second barrier phases, [9] rounds, [10] HW_ID, [11] XCC_ID, [12] s_memrealtime at entry.
+#ifdef T2V_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ unsigned int g_stamps_cap = 0;
+extern "C" int t2v_stamps_set(void* buf, unsigned int cap_records) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_cap), &cap_records, sizeof(cap_records)) != hipSuccess) return -1;
+    return 0;
+}
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(v) const unsigned long long v = stamp_now()
+#define STAMP_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(v)
+#define STAMP_ACC(acc, a, b)
+#endif
+
 // XCD-aware workgroup remap (bijective for any count): the dispatcher deals workgroups round-robin over the 8
 // XCDs, each with a private L2; id -> slot such that the workgroups of ONE XCD own a contiguous range of slots,
 // so that neighbours in the slot order (adjacent voxel tiles sharing halos, the taps of one k-split) share an L2.
@@ -799,6 +824,10 @@ template <int BM, int BKT, int WAVES_CO, bool VECB>
 __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ slab,
                                                                 const int Cin, const int Cout, const int flags, const int nsplit) {
+#ifdef T2V_STAMPS
+    const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();
+#endif
+    STAMP(t_entry);
     constexpr int BN = 64, WAVES_M = 4 / WAVES_CO;
     constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
     constexpr int NCO = WCO / 32, NM = WM / 32;
@@ -966,14 +995,27 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
 
     if (tid < BKT) As[tid * AP + BM + 3] = 0.f;          // the zero column (staging never writes past column BM + 1)
     if (q0 < q1) load_round(q0);
+#ifdef T2V_STAMPS
+    unsigned long long st_stage = 0, st_bar1 = 0, st_load = 0, st_mfma = 0, st_bar2 = 0;
+#endif
+#ifdef T2V_ABLATION      // developer ablations (wrong results): which phase of a round costs what (T2V_DEBUG_FLAGS)
+    const bool ab_noload = flags & 64, ab_nostage = flags & 128, ab_nobar = flags & 256, ab_nomfma = flags & 512, ab_nostore = flags & 1024;
+#else
+    constexpr bool ab_noload = false, ab_nostage = false, ab_nobar = false, ab_nomfma = false, ab_nostore = false;
+#endif
+    STAMP(t_loop0);
     for (int q = q0; q < q1; ++q) {
-        stage();
-        __syncthreads();
-        if (q + 1 < q1) load_round(q + 1);
+        STAMP(ta);
+        if (!ab_nostage || q == q0) stage();
+        STAMP(tb);
+        if (!ab_nobar || q == q0) __syncthreads();
+        STAMP(tc);
+        if (q + 1 < q1 && !ab_noload) load_round(q + 1);
+        STAMP(td);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            if (d < ndx) {
+            if (d < ndx && !ab_nomfma) {
                 const int dx = ndx == 3 ? d - 1 : 0;
                 const float* bs = Bs + d * (BKT * BN) + wco * WCO + l31;
                 // a lane whose voxel sits at a row end reads this tap from the all-zero column instead of masking every
@@ -1001,10 +1043,32 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        STAMP(te);
+        if (!ab_nobar) __syncthreads();
+        STAMP(tf);
+        STAMP_ACC(st_stage, ta, tb); STAMP_ACC(st_bar1, tb, tc); STAMP_ACC(st_load, tc, td); STAMP_ACC(st_mfma, td, te); STAMP_ACC(st_bar2, te, tf);
     }
+    STAMP(t_loop1);
+    if (ab_nostore && acc[0][0][0] != 12345.678f) return;
     igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi, yds, gd.yoff,
                                      gd.Dy * HW, HW);
+#ifdef T2V_STAMPS
+    {
+        STAMP(t_exit);
+        const unsigned int rec = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+        if (g_stamps && rec < g_stamps_cap && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)rec * 16;
+            o[0] = t_entry; o[1] = t_loop0; o[2] = t_loop1; o[3] = t_exit;
+            o[4] = st_stage; o[5] = st_bar1; o[6] = st_load; o[7] = st_mfma; o[8] = st_bar2;
+            o[9] = (unsigned long long)(q1 - q0);
+            o[10] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+            o[11] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+            o[12] = t_real;
+            o[13] = (unsigned long long)gi;
+            o[14] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2365,7 +2429,7 @@ static bool strip_fits32(const GroupTable& tab, int Cin) {
 struct ConvVariant { bool strip; int ks; bool s3; };
 static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM, int BN, int BKT, int Cin, int Cout, int flags) {
     ConvVariant v{false, 1, false};
-    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && tun().strip && !(flags & (64 | 128)) && strip_ok(tab) && strip_fits32(tab, Cin)) {
+    if (p.fast && (BKT == 32 || BM == 256) && (Cin % BKT) == 0 && tun().strip && strip_ok(tab) && strip_fits32(tab, Cin)) {
         v.strip = true;
         // tiles with 64 output channels (64 / 128 voxels x 32 channels, 256 voxels x 16 channels): all three dx taps per barrier
         // round (conv_igemm_strip3_kernel; +12-15 % over one dx per round on every one of them); 128 x 32 keeps the per-dx form

@@ -2522,6 +2522,39 @@ extern "C" int t2v_copy2d(const float* src, int64_t src_ld, float* dst, int64_t 
     T2V_LAUNCH(copy2d_k, dim3(nblocks(rows * cols)), dim3(256), 0, S_(st), src, (long)src_ld, dst, (long)dst_ld, (long)rows, (long)cols);
     return launch_status();
 }
+// fp32 <-> bf16 streams for the opt-in bf16 gradient exchange (txt2vid_amd.dist, SURVEY §8(e) "optionally reduce in bf16"):
+// round-to-nearest-even through the hardware convert (a NaN stays a NaN); 8 elements per thread where the count allows.
+__global__ void cast_f32_bf16_k(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
+    const long n8 = n >> 3;
+    GRID_STRIDE(i, n8) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+        bf8 o;
+        o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+        o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+        reinterpret_cast<bf8*>(dst)[i] = o;
+    }
+    GRID_STRIDE(j, n - (n8 << 3)) dst[(n8 << 3) + j] = (__bf16)src[(n8 << 3) + j];
+}
+__global__ void cast_bf16_f32_k(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
+    const long n8 = n >> 3;
+    GRID_STRIDE(i, n8) {
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+        const bf8 v = reinterpret_cast<const bf8*>(src)[i];
+        reinterpret_cast<float4*>(dst)[2 * i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+    }
+    GRID_STRIDE(j, n - (n8 << 3)) dst[(n8 << 3) + j] = (float)src[(n8 << 3) + j];
+}
+// dir 0: bf16 dst <- fp32 src; dir 1: fp32 dst <- bf16 src. Both pointers 16-byte aligned (32 for the fp32 side).
+extern "C" int t2v_cast_bf16(const void* src, void* dst, int64_t n, int dir, void* st) {
+    if (!src || !dst || n < 1 || (dir != 0 && dir != 1)) return T2V_EINVAL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return T2V_EINVAL;
+    long nb = nblocks((n + 7) / 8);
+    if (dir == 0) T2V_LAUNCH(cast_f32_bf16_k, dim3(nb), dim3(256), 0, S_(st), (const float*)src, (__bf16*)dst, (long)n);
+    else T2V_LAUNCH(cast_bf16_f32_k, dim3(nb), dim3(256), 0, S_(st), (const __bf16*)src, (float*)dst, (long)n);
+    return launch_status();
+}
 // x[A][B][inner] -> y[B][A][inner]
 __global__ void permute01_k(const float* x, float* y, long A, long B, long inner) {
     const long n = A * B * inner;

@@ -198,6 +198,8 @@ class SyntheticMovingDigits(torch.utils.data.Dataset):
         if dev.type != 'cuda':
             raise RuntimeError('device_batch generates on the GPU: the HIP path has no CPU fallback (index the dataset instead)')
         idx = indices if isinstance(indices, torch.Tensor) else torch.as_tensor(list(indices), dtype=torch.int64)
+        if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= len(self)):       # (host indices: checked for free)
+            raise IndexError('device_batch: indices must lie in [0, %d)' % len(self))
         idx = idx.to(device=dev, dtype=torch.int64).contiguous()
         B = int(idx.numel())
         T, S, Cc = self.num_frames, self.size, self.channels
@@ -216,6 +218,16 @@ class SyntheticMovingDigits(torch.utils.data.Dataset):
         check(lib().t2v_synth_clips(C.c_void_p(idx.data_ptr()), B, int(self.seed), T, Cc, S, ids, C.c_void_p(vids.data_ptr()),
                                     C.c_void_p(toks.data_ptr()), C.c_void_p(self._err.data_ptr()), _stream()), 't2v_synth_clips')
         return vids, toks, [8] * B
+
+    def check_device_draws(self):
+        """Raise if any clip generated by `device_batch` since the last check ran out of its draw sequence (the kernel flags it
+        in a device word and falls back to digit / motion / position 0: the clip would silently differ from the host item).
+        One 4-byte read-back: called once per epoch by `DeviceSyntheticLoader`, and by whoever builds a batch pool."""
+        err = getattr(self, '_err', None)
+        if err is not None and int(err.item()) != 0:
+            err.zero_()
+            raise RuntimeError('t2v_synth_clips: a clip exhausted its random draws (device flag set): device batches are not '
+                               'bit-identical to the host dataset')
 
 
 class DeviceSyntheticLoader(object):
@@ -246,6 +258,7 @@ class DeviceSyntheticLoader(object):
         order = self.epoch_order()
         for k in range(len(self)):
             yield self.dataset.device_batch(order[k * self.batch_size:(k + 1) * self.batch_size], self.device)
+        self.dataset.check_device_draws()                            # (one read-back per epoch: flagged, not hidden)
 
 
 def collate_fn(data):

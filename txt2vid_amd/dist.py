@@ -90,7 +90,14 @@ class GradArena(object):
     [1024,1024,3,3] weights (302 of G's 345 MB) ever receives a gradient. Such parameters sit at the end of the arena and
     only their live taps, packed into a compact buffer, take part in the all-reduce."""
 
-    def __init__(self, params, copy_fn=None, live_taps=None):
+    def __init__(self, params, copy_fn=None, live_taps=None, exchange_dtype=None):
+        """`exchange_dtype`: None / torch.float32 = exchange the fp32 arena as it is; torch.bfloat16 (or the environment's
+        T2V_GRAD_EXCHANGE=bf16) = the opt-in half-size exchange: the arena is rounded to bf16 into one buffer, ONE all_reduce(SUM)
+        runs on it and the sums are widened back into the fp32 arena (SURVEY §8(e) "optionally reduce in bf16"). Every rank
+        receives the same bf16 sums, so the replicas stay bit-identical; the gradients carry 8 significant bits."""
+        if exchange_dtype is None and os.environ.get('T2V_GRAD_EXCHANGE', '').lower() in ('bf16', 'bfloat16'):
+            exchange_dtype = torch.bfloat16
+        self.exchange_dtype = exchange_dtype if exchange_dtype in (torch.bfloat16,) else None
         params = [p for p in params if p.requires_grad]
         live_taps = live_taps or {}
         sparse_ids = {id(p) for p in live_taps}
@@ -117,6 +124,10 @@ class GradArena(object):
             self.sparse.append((self.offsets[len(dense) + len(self.sparse)], rows, T, taps, m, not p.is_contiguous()))
             m += rows * len(taps)
         self.compact = torch.zeros(m, device=p0.device, dtype=p0.dtype) if m else None
+        self.half = None
+        if self.exchange_dtype is not None:
+            self.half_dense = (self.numel_dense + 7) // 8 * 8             # (the compact part starts 16-byte aligned)
+            self.half = torch.zeros(self.half_dense + m, device=p0.device, dtype=self.exchange_dtype)
 
     def views(self):
         """One view per parameter with the parameter's own shape AND strides (tap-major master weights keep their layout: the
@@ -144,15 +155,32 @@ class GradArena(object):
                 T = 1
                 for d in v.shape[2:]:
                     T *= int(d)
-                rows = v.numel() // T         # arena memory [T][Cout*Cin] <- gradient memory [Cout*Cin][T]
-                for t in range(T):
-                    TF._copy2d(g, t, T, v, t * rows, 1, rows, 1)
+                rows = v.numel() // T         # arena memory [T][Cout*Cin] <- gradient memory [Cout*Cin][T]: ONE transpose launch
+                dst = torch.as_strided(self.flat, (T * rows,), (1,), v.storage_offset())
+                TF.check(TF.lib().t2v_permute01(g.data_ptr(), dst.data_ptr(), rows, T, 1, TF._stream()), 't2v_permute01')
             else:
                 v.copy_(g)                    # stride-aware (any other layout pair; CPU)
 
     def _taps(self, pack):
-        """live taps: arena -> compact (pack) or compact -> arena (unpack); strided column copies."""
-        for off, rows, T, taps, coff, tap_major in self.sparse:
+        """live taps: arena -> compact (pack) or compact -> arena (unpack). Tap-major masters ([T][rows] in memory: a live tap is
+        one contiguous run — every ConvLSTM weight of the generator) go in ONE multi-job launch per direction on the GPU
+        (t2v_multi, 8 runs per launch); anything else takes the strided column copies."""
+        if self.flat.is_cuda and self.copy_fn is not None and any(e[5] for e in self.sparse):
+            from . import functional_multi as FM
+            jobs = []
+            for off, rows, T, taps, coff, tap_major in self.sparse:
+                if not tap_major:
+                    continue
+                for j, t in enumerate(taps):
+                    a = self.flat[off + t * rows:off + (t + 1) * rows]
+                    b = self.compact[coff + j * rows:coff + (j + 1) * rows]
+                    src_, dst_ = (a, b) if pack else (b, a)
+                    jobs.append(dict(a=src_, out=dst_, n=1, d0=rows, d1=0, d2=rows))       # out[0, 0:rows] = a[0, 0:rows]
+            FM._mj(FM.MJ_SLICECOLS, jobs)
+            rest = [e for e in self.sparse if not e[5]]
+        else:
+            rest = self.sparse
+        for off, rows, T, taps, coff, tap_major in rest:
             if tap_major:                     # [T][rows] in memory: a live tap is one contiguous run
                 for j, t in enumerate(taps):
                     a = self.flat[off + t * rows:off + (t + 1) * rows]
@@ -177,8 +205,33 @@ class GradArena(object):
                 else:
                     src[:, t].copy_(dst[:, j])
 
+    def _cast(self, src, dst, to_half):
+        if src.is_cuda:
+            from ._ops import lib, check, _stream
+            check(lib().t2v_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), 0 if to_half else 1, _stream()), 't2v_cast_bf16')
+        else:
+            dst.copy_(src)                                           # (CPU rehearsal over gloo: torch's round-to-nearest-even)
+
+    def _all_reduce_half(self):
+        """The opt-in bf16 exchange: [dense | live taps] rounded into one bf16 buffer, ONE collective, widened back."""
+        nd, m = self.numel_dense, (self.compact.numel() if self.compact is not None else 0)
+        if m:
+            self._taps(True)
+            self._cast(self.compact, self.half[self.half_dense:], True)
+        if nd:
+            self._cast(self.flat[:nd], self.half[:nd], True)
+        dist.all_reduce(self.half, op=dist.ReduceOp.SUM)
+        if nd:
+            self._cast(self.half[:nd], self.flat[:nd], False)
+        if m:
+            self._cast(self.half[self.half_dense:], self.compact, False)
+            self._taps(False)
+
     def all_reduce(self):
         if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self.half is not None:
+            self._all_reduce_half()
             return
         if not self.sparse:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
@@ -190,7 +243,7 @@ class GradArena(object):
         self._taps(False)
 
     def exchanged_bytes(self):
-        return 4 * (self.numel_dense + (self.compact.numel() if self.compact is not None else 0))
+        return (2 if self.half is not None else 4) * (self.numel_dense + (self.compact.numel() if self.compact is not None else 0))
 
     def scatter_as_grads(self):
         """Point every p.grad at its (reduced) arena slice; the optimiser applies `1/world` itself."""
@@ -198,7 +251,7 @@ class GradArena(object):
             p.grad = v
 
 
-def model_arena(modules, copy_fn=None):
+def model_arena(modules, copy_fn=None, exchange_dtype=None):
     """GradArena over the parameters of one module (or a list of modules); modules that know which kernel taps of their
     convolution weights can ever receive a gradient (`structurally_live_taps()`) have only those exchanged."""
     if not isinstance(modules, (list, tuple)):
@@ -208,7 +261,7 @@ def model_arena(modules, copy_fn=None):
         params += list(m.parameters())
         if hasattr(m, 'structurally_live_taps'):
             live.update(m.structurally_live_taps())
-    return GradArena(params, copy_fn, live_taps=live)
+    return GradArena(params, copy_fn, live_taps=live, exchange_dtype=exchange_dtype)
 
 
 class GradSync(object):
@@ -232,11 +285,16 @@ class GradSync(object):
         self.timing = [] if on else None
 
     def exchange_ms(self):
-        """Total milliseconds of the exchanges recorded since `time_exchanges(True)`, per model: {'D': ms, 'G': ms, 'n': exchanges}."""
+        """Total milliseconds of the exchanges recorded since `time_exchanges(True)`, per model: {'D': ms, 'G': ms, 'n': exchanges}.
+        (Host arenas — the gloo rehearsal on CPU tensors — are timed with the host clock around the blocking collective.)"""
         out = {'D': 0.0, 'G': 0.0, 'n': 0}
         for which, e0, e1 in self.timing or ():
-            e1.synchronize()
-            out[which] = out.get(which, 0.0) + e0.elapsed_time(e1)
+            if e1 is None:
+                ms = e0
+            else:
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+            out[which] = out.get(which, 0.0) + ms
             out['n'] += 1
         return out
 
@@ -248,6 +306,12 @@ class GradSync(object):
             self.arenas[which].all_reduce()
             e1.record()
             self.timing.append((which, e0, e1))
+            return
+        if self.timing is not None:
+            import time
+            t0 = time.perf_counter()
+            self.arenas[which].all_reduce()
+            self.timing.append((which, (time.perf_counter() - t0) * 1e3, None))
             return
         self.arenas[which].all_reduce()
 
