@@ -1973,36 +1973,133 @@ __global__ __launch_bounds__(256) void mj_softmax_k(const MultiBatch tb, const i
         for (int i = lane; i < n; i += 64) po[i] = pq[i] * (pg[i] - s) - pg[i] * u;
     }
 }
-// batched thin GEMM (see bmm_k): n = batch, d0 = M, d1 = N, d2 = K, f0 = ta, f1 = tb; a = A, b = B, out = C
-__global__ __launch_bounds__(256) void mj_bmm_k(const MultiBatch tb) {
-    __shared__ float As[16][17], Bs[16][17];
-    const int ji = mj_find(tb);
-    const t2v_multi_job& q = tb.j[ji];
+// batched GEMM of the non-local block (layers.py:28-33,60-65: theta^T phi, g beta^T and their adjoints): n = batch, d0 = M, d1 = N,
+// d2 = K, f0 = ta, f1 = tb; a = A, b = B, out = C (row-major [M][N]). Round 4: on the fp32 matrix cores. A workgroup owns a 64 x 64
+// tile of one batch entry (four waves, one 32x32 v_mfma_f32_32x32x2_f32 accumulator each: rows = M in registers, columns = N on
+// lanes, so the stores are 128-byte runs of C); K goes through LDS in chunks of 16 as As[k][m] / Bs[k][n], each operand read from
+// global memory along ITS contiguous axis (m or n when the transposition flag makes that the inner one, k otherwise) and zero
+// filled past the edges — any M, N, K. (The 16 x 16 one-output-per-thread tiles this replaces ran the discriminator's full-
+// resolution block at ~10 TFLOP/s: 0.39 ms per forward + backward pass at B = 32.)
+#define BMM_P 68      // LDS row pitch (64 + 4: the k-major writes of a k-contiguous operand are 2-way conflicted at worst)
+#define BMM_KS_MIN_K 128
+// KS: the K-SPLIT form for products with few output tiles and a long reduction (the adjoints: dg = do . beta is 64 x 256 per
+// sample over K = 1024): a workgroup owns a 32 x 32 tile, its four waves each reduce a QUARTER of K into their own accumulator
+// (staging their own chunks in a wave-private part of the LDS tiles) and the four partial tiles are summed through LDS in a
+// fixed order — 4x the waves in flight where the 64 x 64 form would leave half the chip idle walking K at memory latency.
+__host__ __device__ static inline bool bmm_use_ks(long M, long N, long K, long batch) {
+    return K >= BMM_KS_MIN_K && ((M + 63) / 64) * ((N + 63) / 64) * batch < 1024;
+}
+template <bool KS>
+__device__ __forceinline__ void mj_bmm_body(const t2v_multi_job& q, int lb, float* As, float* Bs) {
+    constexpr int TM = KS ? 32 : 64;                  // tile edge
     const int M = q.d0, N = q.d1, K = q.d2, ta = q.f0, tb_ = q.f1;
-    const int tn = (N + 15) / 16, tm = (M + 15) / 16;
-    int lb = (int)blockIdx.x - tb.begin[ji];
+    const int tn = (N + TM - 1) / TM, tm = (M + TM - 1) / TM;
     const int bx = lb % tn; lb /= tn;
     const int by = lb % tm;
     const int b = lb / tm;
-    const float* a = (const float*)q.a + (long)b * M * K;
-    const float* bb = (const float*)q.b + (long)b * K * N;
-    float* c = (float*)q.out + (long)b * M * N;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int row = by * 16 + ty, col = bx * 16 + tx;
-    float acc = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        {
-            int r = by * 16 + ty, k = k0 + tx;
-            As[ty][tx] = (r < M && k < K) ? (ta ? a[(long)k * M + r] : a[(long)r * K + k]) : 0.f;
-            int kk = k0 + ty, cc = bx * 16 + tx;
-            Bs[ty][tx] = (kk < K && cc < N) ? (tb_ ? bb[(long)cc * K + kk] : bb[(long)kk * N + cc]) : 0.f;
+    const float* __restrict__ a = (const float*)q.a + (long)b * M * K;
+    const float* __restrict__ bb = (const float*)q.b + (long)b * K * N;
+    float* __restrict__ c = (float*)q.out + (long)b * M * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = KS ? 0 : (wave & 1), wn = KS ? 0 : (wave >> 1);
+    const int m0 = by * TM, n0 = bx * TM;
+    // staging coordinates. 64 x 64 form: the workgroup stages one 16-deep chunk, 4 elements per thread and operand — inner-
+    // contiguous operand (A stored [K][M], B stored [K][N]): lane = inner index, k = tid / 64 + 4 j; k-contiguous operand
+    // (A [M][K], B [N][K]): k = tid % 16, row = tid / 16 + 16 j. KS form: every WAVE stages its own chunk of its own K range
+    // (32 rows x 16 k = 8 elements per lane and operand): inner-contiguous: lane & 31 = inner index, k = lane / 32 + 2 j;
+    // k-contiguous: k = lane % 16, row = lane / 16 + 4 j.
+    const int t_ = KS ? lane : tid;
+    const int ik = KS ? (t_ >> 5) : (t_ >> 6), ii = KS ? (t_ & 31) : (t_ & 63);
+    const int kk = t_ & 15, kr = t_ >> 4;
+    constexpr int NJ = KS ? 8 : 4, KSTEP = KS ? 2 : 4, RSTEP = KS ? 4 : 16;
+    // K range of this wave (KS) / of the workgroup
+    const int kq = KS ? (((K + 3) / 4 + 15) / 16) * 16 : K;
+    const int kbeg = KS ? wave * kq : 0;
+    const int kend = KS ? (kbeg + kq < K ? kbeg + kq : K) : K;
+    float* as = As + (KS ? wave * 16 * 36 : 0);
+    float* bs = Bs + (KS ? wave * 16 * 36 : 0);
+    constexpr int P = KS ? 36 : BMM_P;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ra[NJ], rb[NJ];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (ta) {
+                const int k = k0 + ik + KSTEP * j, m = m0 + ii;
+                ra[j] = (k < kend && m < M) ? a[(long)k * M + m] : 0.f;
+            } else {
+                const int k = k0 + kk, m = m0 + kr + RSTEP * j;
+                ra[j] = (k < kend && m < M) ? a[(long)m * K + k] : 0.f;
+            }
+            if (!tb_) {
+                const int k = k0 + ik + KSTEP * j, n = n0 + ii;
+                rb[j] = (k < kend && n < N) ? bb[(long)k * N + n] : 0.f;
+            } else {
+                const int k = k0 + kk, n = n0 + kr + RSTEP * j;
+                rb[j] = (k < kend && n < N) ? bb[(long)n * K + k] : 0.f;
+            }
+        }
+    };
+    const int nch = KS ? kq / 16 : (K + 15) / 16;     // (KS: the same trip count for every wave — the loop holds workgroup barriers)
+    load(kbeg);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int k0 = kbeg + ch * 16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (ta) as[(ik + KSTEP * j) * P + ii] = ra[j]; else as[kk * P + kr + RSTEP * j] = ra[j];
+            if (!tb_) bs[(ik + KSTEP * j) * P + ii] = rb[j]; else bs[kk * P + kr + RSTEP * j] = rb[j];
         }
         __syncthreads();
+        if (ch + 1 < nch) load(k0 + 16);                         // (in flight during the MFMAs)
+        const float* pa = as + hi * P + wm * 32 + l31;
+        const float* pb = bs + hi * P + wn * 32 + l31;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += As[ty][k] * Bs[k][tx];
+        for (int k2 = 0; k2 < 8; ++k2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k2 * 2 * P], pb[k2 * 2 * P], acc, 0, 0, 0);
         __syncthreads();
     }
-    if (row < M && col < N) c[(long)row * N + col] = acc;
+    if constexpr (KS) {
+        // the four partial 32 x 32 tiles -> LDS [wave][reg][lane]; thread (wave w, lane l) then owns registers 4w .. 4w+3 of lane l
+        float* red = As;                                         // 4 x 16 x 64 floats = 16 KB (As + Bs hold 2 x 4 x 16 x 36 = 18 KB)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        const int n = n0 + l31;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float v = red[(0 * 16 + r) * 64 + lane];
+            v += red[(1 * 16 + r) * 64 + lane];
+            v += red[(2 * 16 + r) * 64 + lane];
+            v += red[(3 * 16 + r) * 64 + lane];
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < M && n < N) c[(long)m * N + n] = v;
+        }
+    } else {
+        const int n = n0 + wn * 32 + l31;
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M) c[(long)m * N + n] = acc[r];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void mj_bmm_k(const MultiBatch tb) {
+    constexpr int HALF = 4 * 16 * 36 > 16 * BMM_P ? 4 * 16 * 36 : 16 * BMM_P;
+    __shared__ float lds[2 * HALF];                              // ONE object: the K-split reduce reuses both halves as one buffer
+    float* As = lds;
+    float* Bs = lds + HALF;
+    static_assert(2 * HALF >= 4 * 16 * 64, "the partial tiles fit the staging tiles");
+    const int ji = mj_find(tb);
+    const t2v_multi_job& q = tb.j[ji];
+    const int lb = (int)blockIdx.x - tb.begin[ji];
+    if (bmm_use_ks(q.d0, q.d1, q.d2, q.n)) mj_bmm_body<true>(q, lb, As, Bs);        // (uniform per job)
+    else mj_bmm_body<false>(q, lb, As, Bs);
 }
 extern "C" int64_t t2v_multi_ws_floats(int op, const t2v_multi_job* jobs, int njobs) {
     if (!jobs || njobs < 1 || njobs > MJ_MAX) return T2V_EINVAL;
@@ -2064,7 +2161,9 @@ extern "C" int t2v_multi(int op, const t2v_multi_job* jobs, int njobs, const flo
                 nb = (q.n * q.d0 + MJ_CHUNK - 1) / MJ_CHUNK; break;
             case T2V_MJ_BMM:
                 if (!q.b || !q.out || q.d0 < 1 || q.d1 < 1 || q.d2 < 1) return T2V_EINVAL;
-                nb = (long)((q.d1 + 15) / 16) * ((q.d0 + 15) / 16) * q.n; break;
+                nb = bmm_use_ks(q.d0, q.d1, q.d2, q.n) ? (long)((q.d1 + 31) / 32) * ((q.d0 + 31) / 32) * q.n
+                                                        : (long)((q.d1 + 63) / 64) * ((q.d0 + 63) / 64) * q.n;
+                break;
             default: return T2V_EINVAL;
         }
         tb.j[i] = q;

@@ -256,6 +256,11 @@ class UpBlock(nn.Module):
         return x
 
 
+import os as _os
+SKIP_POOLS_FIRST = _os.environ.get('T2V_NO_SKIP_POOLS_FIRST') is None        # developer A/B switch (see down_block_levels)
+SKIP_POOLS_FIRST_MIN_VOXELS = 16384       # below this a block's launches are latency-bound: the two extra small launches cost more
+
+
 def downsample_cfg(x):
     """kernel / stride / padding of `DownSample` for this tensor — layers.py:202-215."""
     k, s, p = [1, 1, 1], [1, 1, 1], [0, 0, 0]
@@ -303,8 +308,10 @@ class DownBlock(nn.Module):
     def forward(self, x):
         m = self.main.inner_module
         if isinstance(m[1], Conv3d) and isinstance(m[3], Conv3d):
-            h = TF.relu_conv(x, m[1].weight, m[1].bias)            # ReLU fused into the conv gather
             idm = self.main.identity_map
+            if x.is_cuda and isinstance(idm[0], Conv3d):
+                return down_block_levels(self, [x])[0]             # a group of one: the same launches as the multi-level pass
+            h = TF.relu_conv(x, m[1].weight, m[1].bias)            # ReLU fused into the conv gather
             if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample) and TF.pool_conv_ok([h], m[3].weight, False):
                 # conv2 -> DownSample as ONE pooled convolution; the skip path's pooling adds it in its launch (as `down_block_levels`)
                 z = TF.pool_conv_group([h], m[3].weight, m[3].bias, relu_in=True, stem=False)[0]
@@ -321,6 +328,20 @@ def down_block_levels(block, xs):
     """DownBlock over a list of pyramid levels, layer by layer: each convolution is one grouped launch."""
     m = block.main.inner_module
     idm = block.main.identity_map
+    cfgs = [downsample_cfg(x) for x in xs]
+    if SKIP_POOLS_FIRST and isinstance(idm[1], DownSample) and isinstance(m[4], DownSample) and isinstance(idm[0], Conv3d) and \
+            tuple(idm[0].weight.shape[2:]) == (1, 1, 1) and not any(any(p) for _, _, p in cfgs) and \
+            sum(x.numel() // x.shape[1] for x in xs) >= SKIP_POOLS_FIRST_MIN_VOXELS and TF.pool_conv_ok(xs, m[3].weight, False):
+        # Round 4: the skip path `conv1x1x1 -> DownSample` (layers.py:233-238) runs as DownSample -> conv1x1x1. A 1x1x1 convolution
+        # acts per voxel and un-padded average pooling is linear, so the two commute value for value up to summation order (bias
+        # included: the mean of a constant); the convolution then runs on an EIGHTH of the voxels, its two adjoints likewise, and
+        # the pooling moves C_in channels instead of C_out. The block's input feeds two consumers: a grouped fork sums their
+        # gradients in one launch (as in the stem). Only where the block's tensors are big enough for the saved work to show.
+        xa, xb = TF.fork_group(xs)
+        hs = TF.conv_group(xa, m[1].weight, m[1].bias, relu_in=True)
+        zs = TF.pool_conv_group(hs, m[3].weight, m[3].bias, relu_in=True, stem=False)
+        ss = TF.conv_group(TF.avg_pool3d_group(xb, cfgs), idm[0].weight, idm[0].bias)
+        return TF.add_group(zs, ss)
     # main conv1 and the skip conv read the same tensors: one Function, so their data gradients land in one buffer
     hs, ss = TF.conv_multi_group(xs, [(m[1].weight, m[1].bias, True), (idm[0].weight, idm[0].bias, False)])
     if isinstance(idm[1], DownSample) and isinstance(m[4], DownSample) and TF.pool_conv_ok(hs, m[3].weight, False):
