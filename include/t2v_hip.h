@@ -170,7 +170,7 @@ int t2v_wgrad_reduce_multi(const void* table /* device t2v_wgrad_dest[ndest] */,
  * fwd  out[8]: kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv, 3 thin linear, 4 thin two-pass, 5 strip GEMM with
  *              all three dx taps per barrier round), BM, BN, K chunk,
  *              FAST, VECB, KS, split-K S.   (groups[].x / .y may be NULL)
- * wgrad out[6]: kernel (0 per-tap tiles, 1 (tap,ci) column tiles, 2 three-tap rows, 3 TN product on 1x1x1 maps — fp32 in bf16-compute mode too), S, chunks per split, slab slots,
+ * wgrad out[6]: kernel (0 per-tap tiles, 1 (tap,ci) column tiles, 2 three-tap rows, 3 TN product on 1x1x1 maps — fp32 in bf16-compute mode too, 4 the streaming kernel for <= 31 (tap, ci) columns), S, chunks per split, slab slots,
  *              reduce kernel (0 / 1 = many-splits small-weight form), workgroups of the main launch. */
 int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out);
 int t2v_conv_wgrad_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, int32_t* out);

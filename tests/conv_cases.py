@@ -53,6 +53,10 @@ SINGLE_CASES = [
     ((37, 192), 136, ()),                    # ragged 128x128 tiles in both directions, one ragged 32-row chunk pair
     ((1500, 256, 1, 1, 1), 320, (3, 3, 3)),  # k-split (6 tiles -> S = 12), centre tap of a 3x3x3 kernel
     ((2100, 128), 128, ()),                  # one tile, 16 splits: the many-splits reduce
+    # narrow inputs, <= 31 (tap, ci) columns: the streaming weight-gradient kernel (conv_wgrad_thin_kernel)
+    ((3, 3, 10, 12), 40, (3, 3)),            # Cin=3 x 9 taps = 27 columns (ci > 0), ragged channel tile, extents not powers of two
+    ((5, 2, 3, 6, 6), 64, (1, 1, 1)),        # 2 columns, voxels per sample (108) a multiple of 4 but no power of two
+    ((3, 1, 3, 5, 7), 33, (3, 3, 3)),        # voxels per sample (105) NOT a multiple of 4: the four-byte gather path of dL/dy
 ]
 
 
@@ -88,6 +92,7 @@ GROUPED_CASES = [
     ('down0_conv2_B32_8members', 64, 128, (3, 3, 3), d_step_members(32, 1), True),   # M=49152, 64->128
     ('down1_conv2_B32_8members', 128, 256, (3, 3, 3), d_step_members(32, 2), True),  # M=7680 (ragged T), 128->256
     ('small_ragged_group', 64, 64, (3, 3, 3), [(4, 2, 16, 16), (2, 4, 8, 8), (1, 1, 5, 3)], False),
+    ('stem_conv1_B32_8members', 1, 64, (3, 3, 3), d_step_members(32, 0), False),      # M=393216, Cin=1: stem kernels, streaming weight gradient
 ]
 
 
@@ -127,14 +132,14 @@ def fwd_plan(members, cin, cout, k, flags=0):
 
 
 def wgrad_plan(members, cin, cout, k):
-    """('taps'|'cols'|'rows3'|'gemm', S, chunks per split, slab slots, 'reduce'|'reduce_small', workgroups)."""
+    """('taps'|'cols'|'rows3'|'gemm'|'thin', S, chunks per split, slab slots, 'reduce'|'reduce_small', workgroups)."""
     from txt2vid_amd._lib import lib
     out = (C.c_int32 * 6)()
     kk = k3(k)
     rc = lib().t2v_conv_wgrad_plan(_group_array(members, cin, cout, kk), len(members), cin, cout, kk[0], kk[1], kk[2], out)
     assert rc == 0, rc
     v = list(out)
-    return (('taps', 'cols', 'rows3', 'gemm')[v[0]], v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
+    return (('taps', 'cols', 'rows3', 'gemm', 'thin')[v[0]], v[1], v[2], v[3], ('reduce', 'reduce_small')[v[4]], v[5])
 
 
 def members_of_single(xs):

@@ -41,7 +41,7 @@ for bm, bn in ((128, 32), (128, 64), (64, 64)):
 ALL_FWD |= {('stem', 256, 1, 0, 0, 0, 0), ('stem', 256, 3, 0, 0, 0, 0),          # conv_stem_kernel<1 / 3>: the clips' first convolution
             ('thin', 256, 1, 0, 0, 0, 0), ('thin', 256, 4, 0, 0, 0, 0), ('thin2', 256, 1, 0, 0, 0, 0),
             ('linear', 0, 1, 0, 0, 0, 0), ('linear', 0, 4, 0, 0, 0, 0)}
-ALL_WGRAD = set(itertools.product(('taps', 'cols', 'rows3', 'gemm'), ('reduce', 'reduce_small')))
+ALL_WGRAD = set(itertools.product(('taps', 'cols', 'rows3', 'gemm', 'thin'), ('reduce', 'reduce_small')))
 
 
 def test_every_forward_instantiation_is_reached_by_a_parity_case():

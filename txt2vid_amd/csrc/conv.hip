@@ -2302,13 +2302,14 @@ struct Tunables {
     long wgrad_scap;       // T2V_WGRAD_SCAP    (256)  upper bound of the weight-gradient k-split count
     bool wgrad_quantise;   // T2V_WGRAD_NOQ unset      drop a nearly empty last round of weight-gradient workgroups
     long wgrad_min_cps;    // T2V_WGRAD_MINCPS    (4)  fewest 32-voxel chunks a weight-gradient k-split may own
+    bool wgrad_thin;       // T2V_NO_WGRAD_THIN unset  the streaming kernel for narrow inputs (<= 31 (tap, ci) columns)
 };
 static long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 static const Tunables& tun() {
     static const Tunables t = {env_long("T2V_TILE128_MIN", 768), env_long("T2V_TILE256_MIN", 512), env_long("T2V_NOSPLIT_CHUNKS", 8),
                                env_long("T2V_FORCE_S", 0), getenv("T2V_NO_STRIP") == nullptr, getenv("T2V_NO_OCC_PAD") == nullptr,
                                env_long("T2V_WGRAD_TARGET", 0), env_long("T2V_WGRAD_SCAP", 256), getenv("T2V_WGRAD_NOQ") == nullptr,
-                               env_long("T2V_WGRAD_MINCPS", 4)};
+                               env_long("T2V_WGRAD_MINCPS", 4), getenv("T2V_NO_WGRAD_THIN") == nullptr};
     return t;
 }
 
@@ -3269,6 +3270,225 @@ __global__ __launch_bounds__(256) void conv_wgrad_cols_kernel(const WGroupTable 
 
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient for NARROW inputs (round 4): (live taps) x Cin <= 31 columns in all — the clips' first convolution (Cin = 1:
+// 27 columns) and the stem's 1x1x1 skip convolution (1 column). The launch is a STREAM over dL/dy (256 B per voxel for 27 x 64
+// outputs): the column-tile kernel above moves it in 32-voxel chunks with 16 four-byte gathers per lane and two barriers per
+// 16 MFMAs (85 us for the 8 discriminator-step members = 1.2 TB/s; 0.42 ms per pass on full clips). Here a round is 128 voxels:
+// dL/dy arrives as 16-byte loads along the voxels (8 per lane) and goes to LDS as [co][voxel] rows of pitch 132, the shifted /
+// masked input values of the (tap, ci) columns are computed once per voxel and column, and the MFMA k slots are assigned so that
+// a lane's 32 operand values are CONTIGUOUS in its row (slot (k2, hi) <-> voxel hi*32 + k2 of the wave's half: 8 ds_read_b128
+// per operand instead of 32 ds_read_b32; any slot <-> voxel bijection is a valid contraction order as long as both operands
+// use it). Column 31 holds 1 on valid voxels: its accumulator column IS the bias gradient. Waves: 2 (co halves) x 2 (voxel
+// halves, summed through LDS at the end). Same chunk table, k-split slab and bias slab as the other weight-gradient kernels.
+// ------------------------------------------------------------------------------------------------
+#define WT_P 132
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+                                                              const int Cout, const int T, const int kH, const int kW,
+                                                              const int flags, const int chunks_per_split, const LiveTaps live,
+                                                              float* __restrict__ bias_slab) {
+    __shared__ __attribute__((aligned(16))) float As[64 * WT_P];   // dL/dy tile [co][voxel]
+    __shared__ __attribute__((aligned(16))) float Bs[32 * WT_P];   // column tile [col][voxel]
+    __shared__ int s_col[32];                                      // (dz+1) | (dy+1) << 2 | (dx+1) << 4 | ci << 8, or -1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wco = wave & 1, wk = wave >> 1;
+    const int co0 = (int)blockIdx.x * 64;
+    const int split = blockIdx.z;
+    const int ncols = live.n * Cin;
+    const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
+    const int kD = T / (kH * kW);
+    if (tid < 32) {
+        int info = -1;
+        if (tid < ncols) {
+            const int slot = tid / Cin, ci = tid - slot * Cin;
+            const int t = live.t[slot];
+            const int dz = t / (kH * kW) - kD / 2, dy = (t / kW) % kH - kH / 2, dx = t % kW - kW / 2;
+            info = (dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4) | (ci << 8);
+        }
+        s_col[tid] = info;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunks = tab.chunk_start[tab.n];
+    const int q0 = split * chunks_per_split;
+    int q1 = q0 + chunks_per_split;
+    if (q1 > nchunks) q1 = nchunks;
+
+    // ---- member state (scalars), as in the other weight-gradient kernels
+    int g_i = -1, g_begin = 0, g_end = 0;
+    int gD = 1, gH = 1, gW = 1, gHW = 1, gDHW = 1, gM = 0, g_lw = 0, g_lhw = 0, g_ldhw = 0;
+    bool g_pow2 = false;
+    __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_y = g_x;
+    auto enter_group = [&](int q) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 1; k < T2V_MAX_GROUPS; ++k)
+            if (k < tab.n && q >= tab.chunk_start[k]) gi = k;
+        const t2v_conv_group& gd = tab.g[gi];
+        g_i = gi;
+        g_begin = tab.chunk_start[gi];
+        g_end = tab.chunk_start[gi + 1];
+        gD = gd.D; gH = gd.H; gW = gd.W; gHW = gH * gW; gDHW = gD * gHW; gM = gd.N * gDHW;
+        g_pow2 = ((gD & (gD - 1)) | (gH & (gH - 1)) | (gW & (gW - 1))) == 0;
+        g_lw = __builtin_ctz(gW);
+        g_lhw = g_lw + __builtin_ctz(gH);
+        g_ldhw = g_lhw + __builtin_ctz(gD);
+        g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)gM * (uint32_t)Cin * 4u), 0x00020000);      // (host: M * C < 2^30)
+        g_y = __builtin_amdgcn_make_buffer_rsrc((void*)gd.y, 0, (int)((uint32_t)gM * (uint32_t)Cout * 4u), 0x00020000);
+    };
+    // staging coordinates: dL/dy as 8 x (4 voxels of one channel) per thread; columns as 16 x (one voxel, one column) per thread
+    const int a_co = tid >> 5, a_vq = (tid & 31) * 4;
+    const int b_v = tid & 127, b_cg = tid >> 7;
+    float4 ra[8];
+    float rb[16];
+    int rnd_chunks = 0;                        // 32-voxel chunks of the pending round
+    auto load_round = [&](int q) {
+        if (q >= g_end || g_i < 0) enter_group(q);                  // (uniform)
+        int R = g_end - q;
+        if (R > q1 - q) R = q1 - q;
+        if (R > 4) R = 4;
+        rnd_chunks = R;
+        const int DHW = gDHW, HW = gHW, W = gW, H = gH, D = gD;
+        const uint32_t uDHW = (uint32_t)DHW;
+        const int mbase = (q - g_begin) * WG_BK;
+        auto split_m = [&](int m, int& n, int& sp) {
+            if (g_pow2) { n = m >> g_ldhw; sp = m & (DHW - 1); }
+            else { n = gM < (1 << 24) ? fast_div(m, DHW, 1.0f / (float)DHW) : m / DHW; sp = m - n * DHW; }
+        };
+        // ---- dL/dy: voxels a_vq .. a_vq + 3 of channels co0 + a_co + 8 p
+        {
+            const int m = mbase + a_vq;
+            const bool in_round = a_vq < R * WG_BK;
+            if ((DHW & 3) == 0) {                                   // (uniform) the four voxels share a sample and a 16-byte line
+                int n, sp;
+                split_m(m, n, sp);
+                const bool mv = in_round && m < gM;
+                const uint32_t base = mv ? (uint32_t)(n * DHW) * (uint32_t)Cout + (uint32_t)sp : 0u;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int co = co0 + a_co + 8 * p;
+                    const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        g_y, (base + (uint32_t)(co < Cout ? co : Cout - 1) * uDHW) * 4u, 0, 0));
+                    ra[p] = (mv && co < Cout) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                uint32_t base[4];
+                bool mv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int n, sp;
+                    split_m(m + e, n, sp);
+                    mv[e] = in_round && m + e < gM;
+                    base[e] = mv[e] ? (uint32_t)(n * DHW) * (uint32_t)Cout + (uint32_t)sp : 0u;
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int co = co0 + a_co + 8 * p;
+                    const uint32_t cc = (uint32_t)(co < Cout ? co : Cout - 1) * uDHW;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_y, (base[e] + cc) * 4u, 0, 0));
+                        v[e] = (mv[e] && co < Cout) ? v[e] : 0.f;
+                    }
+                    ra[p] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        // ---- columns cg + 2 j of voxel b_v
+        {
+            const int m = mbase + b_v;
+            const bool mv = b_v < R * WG_BK && m < gM;
+            int n, sp;
+            split_m(mv ? m : 0, n, sp);
+            int d, h, w_;
+            if (g_pow2) { d = sp >> g_lhw; h = (sp >> g_lw) & (H - 1); w_ = sp & (W - 1); }
+            else {
+                const bool small = gM < (1 << 24);
+                d = small ? fast_div(sp, HW, 1.0f / (float)HW) : sp / HW;
+                const int r = sp - d * HW;
+                h = small ? fast_div(r, W, 1.0f / (float)W) : r / W;
+                w_ = r - h * W;
+            }
+            const uint32_t xb = (uint32_t)(n * DHW) * (uint32_t)Cin + (uint32_t)sp;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = b_cg + 2 * j;
+                const int info = s_col[c];
+                const int dz = (info & 3) - 1, dy = ((info >> 2) & 3) - 1, dx = ((info >> 4) & 3) - 1, ci = (info >> 8) & 0xffff;
+                const bool ok = mv && info >= 0 && (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H &&
+                                (unsigned)(w_ + dx) < (unsigned)W;
+                const uint32_t off = ok ? xb + (uint32_t)ci * uDHW + (uint32_t)(dz * HW + dy * W + dx) : 0u;
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, off * 4u, 0, 0));
+                rb[j] = ok ? fmaxf(v, relu_floor) : 0.f;
+                if (c == 31) rb[j] = mv ? 1.f : 0.f;                // the ones column: sum of dL/dy = the bias gradient
+            }
+        }
+    };
+
+    __syncthreads();                       // s_col
+    int q = q0;
+    if (q < q1) load_round(q);
+    while (q < q1) {
+        const int R = rnd_chunks;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(&As[(a_co + 8 * p) * WT_P + a_vq]) = ra[p];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Bs[(b_cg + 2 * j) * WT_P + b_v] = rb[j];
+        __syncthreads();
+        q += R;
+        if (q < q1) load_round(q);
+        {
+            const float* pa = As + (wco * 32 + l31) * WT_P + wk * 64 + hi * 32;
+            const float* pb = Bs + l31 * WT_P + wk * 64 + hi * 32;
+            float4 a4[8], b4[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a4[i] = *reinterpret_cast<const float4*>(pa + 4 * i);
+                b4[i] = *reinterpret_cast<const float4*>(pb + 4 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[i].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[i].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[i].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[i].w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the two voxel halves meet in LDS (fixed order: half 0 + half 1)
+    float* red = As;                           // 2 waves x 16 x 64 floats
+    if (wk == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wco * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(wco * 16 + r) * 64 + lane];
+        const int col = l31;
+        if (col < ncols) {
+            const int slot = col / Cin, ci = col - slot * Cin;
+            float* ps = slab + ((size_t)split * live.n + slot) * Cout * Cin + ci;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < Cout) ps[(size_t)co * Cin] = acc[r];
+            }
+        } else if (col == 31 && bias_slab != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < Cout) bias_slab[(size_t)split * Cout + co] = acc[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradient, kW = 3: one workgroup computes the three taps dx = -1, 0, +1 of one (dz, dy) kernel row.
 // They multiply the SAME dL/dy tile and x rows that differ by a one-voxel shift, so dL/dy is staged once and x
 // once as a 34-column strip (the 32 voxels of the chunk plus one on either side, by linear index); the three taps
@@ -3936,7 +4156,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_gemm_kernel(const WGroupTable 
     }
 }
 
-struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; bool strided; bool gemm; };
+struct WgradPlan { int S, cps; uint32_t live; int nlive; long nchunks; bool rows3; uint32_t liverows; int nrows; bool strided; bool gemm; bool thin; };
 
 static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int kD, int kH, int kW, bool need_ptrs,
                          WGroupTable& tab, WgradPlan& p) {
@@ -3980,6 +4200,22 @@ static bool build_wtable(const t2v_conv_group* groups, int ngroups, int Cin, int
         if ((p.live >> (r * kW)) & 7u) p.liverows |= 1u << r;
     p.nrows = __builtin_popcount(p.liverows);
     if (p.rows3) p.nlive = p.nrows * 3;            // slab slots (dead dx taps of a live row are written as zeros)
+    // narrow inputs: every (live tap, ci) column fits ONE 32-column tile with a spare column for the bias sums (conv_wgrad_thin_kernel)
+    p.thin = !p.rows3 && !p.gemm && !strided && Cin < 64 && (long)p.nlive * Cin <= 31 && tun().wgrad_thin;
+    if (p.thin) {
+        // a stream over dL/dy: three workgroups per CU (LDS) in ONE round, rounds of 128 voxels (4 chunks), at least 2 rounds per split
+        const long tiles = (Cout + 63) / 64;
+        long S = (768 + tiles - 1) / tiles;
+        const long maxS = (nch + 7) / 8;
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+        if (S > 1024) S = 1024;
+        long cps = (nch + S - 1) / S;
+        cps = (cps + 3) / 4 * 4;                  // whole rounds
+        p.cps = (int)cps;
+        p.S = (int)((nch + cps - 1) / cps);
+        return true;
+    }
     if (p.gemm) {                                 // 128 x 128 tiles, one per CU: k-splits only until the chip is covered once
         const long tiles = (long)((Cout + 127) / 128) * ((Cin + 127) / 128);
         long S = tiles >= 192 ? 1 : (256 + tiles - 1) / tiles;
@@ -4027,16 +4263,17 @@ extern "C" int64_t t2v_conv_wgrad_grouped_slab_floats(const t2v_conv_group* grou
 }
 
 // Launch-plan query (no launch) for t2v_conv_wgrad_grouped[_bias]: out[0] kernel (0 per-tap 64x64 tiles, 1 (tap, ci) column
-// tiles for Cin < 64, 2 three-tap kernel rows, 3 the TN product on 1x1x1 maps), out[1] k-splits S, out[2] 32-voxel chunks per split, out[3] slab slots,
+// tiles for Cin < 64, 2 three-tap kernel rows, 3 the TN product on 1x1x1 maps, 4 the narrow-input streaming kernel), out[1] k-splits S, out[2] 32-voxel chunks per split, out[3] slab slots,
 // out[4] reduce kernel (0 per-64-pairs, 1 the many-splits small-weight form), out[5] workgroups of the main launch.
 static void fill_wgrad_plan(int Cin, int Cout, const WgradPlan& p, int32_t* out) {
     const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
-    out[0] = p.gemm ? 3 : p.rows3 ? 2 : (Cin < 64 ? 1 : 0);
+    out[0] = p.gemm ? 3 : p.rows3 ? 2 : p.thin ? 4 : (Cin < 64 ? 1 : 0);
     out[1] = p.S;
     out[2] = p.cps;
     out[3] = p.nlive;
     out[4] = ((long)Cout * Cin <= 16384 && p.S >= 16) ? 1 : 0;
     if (p.gemm) { out[5] = (int32_t)((long)((Cout + 127) / 128) * ((Cin + 127) / 128) * p.S); return; }
+    if (p.thin) { out[5] = (int32_t)((long)((Cout + 63) / 64) * p.S); return; }
     out[5] = (int32_t)((p.rows3 ? tiles * p.nrows : Cin < 64 ? (long)((Cout + 63) / 64) * (((long)p.nlive * Cin + 63) / 64)
                                                               : tiles * p.nlive) * p.S);
 }
@@ -4138,6 +4375,10 @@ static int wgrad_impl(const t2v_conv_group* groups, int ngroups, int Cin, int Co
             else
                 T2V_LAUNCH_PROF(conv_wgrad3_kernel<false>, grid, dim3(256), 0, s, tab, slab, Cin, Cout, kD, kH, flags, p.cps, lrows,
                                 dbias ? bias_part : (float*)nullptr);
+        } else if (Cin < 64 && p.thin) {
+            dim3 grid((unsigned)((Cout + 63) / 64), 1u, (unsigned)p.S);
+            T2V_LAUNCH_PROF(conv_wgrad_thin_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
+                            dbias ? bias_part : (float*)nullptr);
         } else if (Cin < 64) {
             dim3 grid((unsigned)(((Cout + 63) / 64) * ((live.n * Cin + 63) / 64)), 1u, (unsigned)p.S);
             T2V_LAUNCH_PROF(conv_wgrad_cols_kernel, grid, dim3(256), 0, s, tab, slab, Cin, Cout, T, kH, kW, flags, p.cps, live,
