@@ -144,14 +144,15 @@ def child_env():
     return env
 
 
-def extra_record(flags, timeout=600):
+def extra_record(flags, timeout=600, roofline=False):
     """Run `python bench.py <flags>` as a child JOB (no CPU baseline, no roofline passes; with `--gpus N` it starts its own N ranks)
     and return the fields of its JSON line that identify and size the measurement; an error string if it failed or timed out.
     A child job cannot take this process's headline down: a rank that raises or hangs in there only loses the extra record
     (the child's whole process group is killed at the timeout)."""
     import signal
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_roofline', '--no_d_roofline', '--no_extra', '--no_hbm']
+    cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--no_cpu_baseline', '--no_d_roofline', '--no_extra', '--no_hbm'] + \
+        ([] if roofline else ['--no_roofline'])
     try:
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=child_env(), start_new_session=True)
         try:
@@ -568,7 +569,9 @@ def main():
         # BASELINE configs[2] (text-conditioned, Bi-LSTM sentence codes, non-local blocks on, bf16 compute) as an EXTRA record of the
         # same line: measured by a child process after this one's timed region, never part of `value`
         log('extra record: BASELINE configs[2] (child process)')
-        res['extra_records'] = {'configs[2]': extra_record(['--cond', '--bf16', '--batch', str(args.batch), '--steps', '10', '--warmup', '3'])}
+        # (with its own `roofline` object: the bf16 GEMM launches over their own time against the dense bf16 matrix peak the line states)
+        res['extra_records'] = {'configs[2]': extra_record(['--cond', '--bf16', '--batch', str(args.batch), '--steps', '10', '--warmup', '3'],
+                                                           roofline=True)}
     if rank == 0 and world == 1 and prof and not args.no_hbm and default_shape and not args.cond and not bf16:
         # the HBM-bound sub-operations, each in isolation at the benchmark's shapes: GB/s on algorithmic bytes vs ~8 TB/s
         from txt2vid_amd.util.roofline import hbm_bound_lines

@@ -26,6 +26,10 @@ CASES = {
     'ragged8': (64, 64, (3, 3, 3), cc.d_step_members(32, 1)),
     'uniform': (64, 64, (3, 3, 3), [(12, 16, 16, 16)]),
     'gen128': (128, 128, (3, 3), [(512, 1, 8, 8)]),
+    # the deep discriminator blocks: a few hundred voxels in all, K of several thousand (split-K launches)
+    'deep_d3': (512, 1024, (3, 3, 3), cc.d_step_members(32, 4)),
+    'deep_d2': (256, 512, (3, 3, 3), cc.d_step_members(32, 3)),
+    'deep_d2c1': (256, 256, (3, 3, 3), cc.d_step_members(32, 3)),
 }
 
 
@@ -42,6 +46,7 @@ def main():
         cin, cout, k, members = CASES[name]
         xs = [torch.randn(n, cin, d, h, w, device=dev) for n, d, h, w in members]
         wt = torch.nn.Parameter(torch.randn(cout, cin, *cc.k3(k), device=dev) * 0.05)
+        print('   plan:', cc.fwd_plan(members, cin, cout, k))
         for _ in range(3):
             TF.conv_group_raw(xs, wt, None, True, 0)
         torch.cuda.synchronize()

@@ -420,8 +420,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
     const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
     const int ntaps = gd.ntaps;
 
+    const int lane_t = lane < ntaps ? lane : 0;
+    const int tab_tdz = gd.dz[lane_t], tab_tdy = gd.dy[lane_t], tab_tdx = gd.dx[lane_t];
     if (tid < ntaps) {
-        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        s_off[tid] = tab_tdz * HW + tab_tdy * W + tab_tdx;
         s_widx[tid] = gd.widx[tid];
     }
 
@@ -435,8 +437,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GroupTable tab, c
         int d = sp / HW, r = sp - d * HW;
         int h = r / W, w_ = r - h * W;
         xbase = (size_t)n * Cin * DHW + sp;
-        for (int t = 0; t < ntaps; ++t) {
-            int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
+        for (int t = 0; t < ntaps; ++t) {            // (per-lane table copies + v_readlane: see conv_igemm_strip3_kernel)
+            int dd = d + __builtin_amdgcn_readlane(tab_tdz, t), hh = h + __builtin_amdgcn_readlane(tab_tdy, t),
+                ww = w_ + __builtin_amdgcn_readlane(tab_tdx, t);
             if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) tapmask |= 1u << t;
         }
     }
@@ -631,7 +634,10 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
     // per-tap tables held one entry per LANE (read back with v_readlane at the wave-uniform tap index: no LDS round trip
     // and no wait in the chunk loop): byte offset of row tap r inside x, packed-weight slot of tap t
     const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
-    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    // (the mask loops below read these per-lane copies with v_readlane: indexing the kernel-argument tables with the loop counter
+    // made hipcc issue a global_load_sbyte + s_waitcnt vmcnt(0) PER ITERATION — 9 x 2 dependent loads = most of a ~4 us prologue)
+    const int tab_rdz = gd.dz[lane_r * ndx], tab_rdy = gd.dy[lane_r * ndx];
+    const int tab_roff = (tab_rdz * HW + tab_rdy * W) * 4;
     const int tab_widx = gd.widx[lane_t];
     // buffer descriptors (wave-uniform: kernel arguments only). All gathers use 32-bit byte offsets — the host only selects
     // this kernel when every member's M * Cin * 4 fits 32 bits — with the channel stride in the scalar offset.
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
             const int h = r / W;
             xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
             }
         }
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
             const int h = r / W;
             xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
             }
         }
@@ -872,7 +878,10 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     const int nrow = ntaps / ndx;
 
     const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
-    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    // (the mask loops below read these per-lane copies with v_readlane: indexing the kernel-argument tables with the loop counter
+    // made hipcc issue a global_load_sbyte + s_waitcnt vmcnt(0) PER ITERATION — 9 x 2 dependent loads = most of a ~4 us prologue)
+    const int tab_rdz = gd.dz[lane_r * ndx], tab_rdy = gd.dy[lane_r * ndx];
+    const int tab_roff = (tab_rdz * HW + tab_rdy * W) * 4;
     const int tab_widx = gd.widx[lane_t];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * DHW) * (uint32_t)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, -1, 0x00020000);
@@ -892,7 +901,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
             const int h = r / W;
             xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
             }
         }
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
             const int h = r / W;
             xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
             }
         }
@@ -1519,8 +1528,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const GroupTable t
     const int M = gd.N * DHW;
     const int m0 = (tile - tab.tile_start[gi]) * BM, co0 = blockIdx.y * BN;
     const int ntaps = gd.ntaps;
+    const int lane_t = lane < ntaps ? lane : 0;      // (per-lane table copies + v_readlane in the mask loop: see conv_igemm_strip3_kernel)
+    const int tab_tdz = gd.dz[lane_t], tab_tdy = gd.dy[lane_t], tab_tdx = gd.dx[lane_t];
     if (tid < ntaps) {
-        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        s_off[tid] = tab_tdz * HW + tab_tdy * W + tab_tdx;
         s_widx[tid] = gd.widx[tid];
     }
     // activation staging: thread -> (voxel, group of KPT consecutive channels)
@@ -1534,7 +1545,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const GroupTable t
         const int h = r / W, w_ = r - h * W;
         xbase = (size_t)n * Cin * DHW + sp;
         for (int t = 0; t < ntaps; ++t) {
-            const int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
+            const int dd = d + __builtin_amdgcn_readlane(tab_tdz, t), hh = h + __builtin_amdgcn_readlane(tab_tdy, t),
+                      ww = w_ + __builtin_amdgcn_readlane(tab_tdx, t);
             if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) tapmask |= 1u << t;
         }
     }
@@ -1664,7 +1676,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
     const int nrow = ntaps / ndx;
 
     const int lane_r = lane < nrow ? lane : 0, lane_t = lane < ntaps ? lane : 0;
-    const int tab_roff = (gd.dz[lane_r * ndx] * HW + gd.dy[lane_r * ndx] * W) * 4;
+    // (the mask loops below read these per-lane copies with v_readlane: indexing the kernel-argument tables with the loop counter
+    // made hipcc issue a global_load_sbyte + s_waitcnt vmcnt(0) PER ITERATION — 9 x 2 dependent loads = most of a ~4 us prologue)
+    const int tab_rdz = gd.dz[lane_r * ndx], tab_rdy = gd.dy[lane_r * ndx];
+    const int tab_roff = (tab_rdz * HW + tab_rdy * W) * 4;
     const int tab_widx = gd.widx[lane_t];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * DHW) * (uint32_t)Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpb, 0, -1, 0x00020000);
@@ -1683,7 +1698,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
             const int h = r / W;
             xbase = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask |= 1u << t;
             }
         }
@@ -1695,7 +1710,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_strip3_kernel(const Group
             const int h = r / W;
             xbase_h = (uint32_t)n * (uint32_t)Cin * (uint32_t)DHW + (uint32_t)sp;
             for (int t = 0; t < nrow; ++t) {
-                const int dd = d + gd.dz[t * ndx], hh = h + gd.dy[t * ndx];
+                const int dd = d + __builtin_amdgcn_readlane(tab_rdz, t), hh = h + __builtin_amdgcn_readlane(tab_rdy, t);
                 if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H) rowmask_h |= 1u << t;
             }
         }
@@ -1884,8 +1899,11 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GroupTable tab, co
     const int M = gd.N * DHW;
     const int ntaps = gd.ntaps;
     for (int i = tid; i < nslots * Cin * Cout; i += 256) sw[i] = wp[i];
+    __shared__ int s_d3[T2V_MAX_TAPS];     // (dz+1) | (dy+1) << 2 | (dx+1) << 4: the tap loop reads LDS, not the kernel arguments
     if (tid < ntaps) {
-        s_off[tid] = gd.dz[tid] * HW + gd.dy[tid] * W + gd.dx[tid];
+        const int dz = gd.dz[tid], dy = gd.dy[tid], dx = gd.dx[tid];
+        s_off[tid] = dz * HW + dy * W + dx;
+        s_d3[tid] = (dz + 1) | ((dy + 1) << 2) | ((dx + 1) << 4);
         s_widx[tid] = gd.widx[tid];
     }
     __syncthreads();
@@ -1900,7 +1918,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GroupTable tab, co
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.f;
     for (int t = 0; t < ntaps; ++t) {
-        const int dd = d + gd.dz[t], hh = h + gd.dy[t], ww = w_ + gd.dx[t];
+        const int d3 = s_d3[t];
+        const int dd = d + (d3 & 3) - 1, hh = h + ((d3 >> 2) & 3) - 1, ww = w_ + ((d3 >> 4) & 3) - 1;
         if (!((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)) continue;
         const float* p = px + (ptrdiff_t)s_off[t];
         const float* wt = sw + (size_t)s_widx[t] * Cin * Cout;
@@ -2089,21 +2108,27 @@ __global__ __launch_bounds__(256) void thin_shift_sum_kernel(const GroupTable ta
     const t2v_conv_group& gd = tab.g[gi];
     const int D = gd.D, H = gd.H, W = gd.W, HW = H * W, DHW = D * HW, M = gd.N * DHW;
     const int m = ((int)blockIdx.x - tab.tile_start[gi]) * 256 + (int)threadIdx.x;
+    const int ntaps = gd.ntaps;
+    // per-lane copies of the tap tables, read back with v_readlane (indexing the kernel arguments per tap cost one dependent
+    // byte load + wait per table access); loaded before any lane leaves
+    const int lane_t = ((int)threadIdx.x & 63) < ntaps ? ((int)threadIdx.x & 63) : 0;
+    const int tab_tdz = gd.dz[lane_t], tab_tdy = gd.dy[lane_t], tab_tdx = gd.dx[lane_t], tab_tw = gd.widx[lane_t];
     if (m >= M) return;
     const int n = m / DHW, sp = m - n * DHW;
     const int d = sp / HW, r = sp - d * HW;
     const int h = r / W, w_ = r - h * W;
     const float* __restrict__ pp = P + (size_t)nslots * (size_t)tab.out_start[gi] + m;
     float acc = 0.f;
-    const int ntaps = gd.ntaps;
     float pv[T2V_MAX_TAPS];
 #pragma unroll
     for (int t = 0; t < T2V_MAX_TAPS; ++t) {             // all (unconditional, clamped) loads first ...
         const int tt = t < ntaps ? t : 0;
-        const int dd = d + gd.dz[tt], hh = h + gd.dy[tt], ww = w_ + gd.dx[tt];
+        const int tdz = __builtin_amdgcn_readlane(tab_tdz, tt), tdy = __builtin_amdgcn_readlane(tab_tdy, tt),
+                  tdx = __builtin_amdgcn_readlane(tab_tdx, tt);
+        const int dd = d + tdz, hh = h + tdy, ww = w_ + tdx;
         const bool ok = t < ntaps && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-        const int off = ok ? gd.dz[tt] * HW + gd.dy[tt] * W + gd.dx[tt] : 0;
-        const float v = pp[(size_t)gd.widx[tt] * M + off];
+        const int off = ok ? tdz * HW + tdy * W + tdx : 0;
+        const float v = pp[(size_t)__builtin_amdgcn_readlane(tab_tw, tt) * M + off];
         pv[t] = ok ? v : 0.f;
     }
 #pragma unroll
@@ -3811,6 +3836,8 @@ __global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const WGroupTable 
 
     int g_i = -1, g_begin = 0, g_end = 0;
     int g_tm = 0, gHn = 1, gWn = 1, gHWn = 1, gVn = 1, gM = 0, gHp = 1, gWp = 2, gVp = 2;
+    int g_lw = 0, g_lhw = 0, g_lv = 0;       // log2 of the pooled extents (every shape of the model is a power of two: shift decode)
+    bool g_pow2 = false;
     __amdgpu_buffer_rsrc_t g_x = __builtin_amdgcn_make_buffer_rsrc((void*)tab.g[0].x, 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t g_y = g_x;
     auto enter_group = [&](int q) {
@@ -3826,6 +3853,10 @@ __global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const WGroupTable 
         const int Dn = g_tm ? gd.D / 2 : 1;
         gHn = gd.H / 2; gWn = gd.W / 2; gHWn = gHn * gWn; gVn = Dn * gHWn;
         gM = gd.N * gVn;
+        g_pow2 = ((Dn & (Dn - 1)) | (gHn & (gHn - 1)) | (gWn & (gWn - 1))) == 0;
+        g_lw = __builtin_ctz(gWn);
+        g_lhw = g_lw + __builtin_ctz(gHn);
+        g_lv = g_lhw + __builtin_ctz(Dn);
         gHp = gd.H + 1; gWp = gd.W + 2;
         gVp = (g_tm ? gd.D + 1 : 1) * gHp * gWp;
         g_x = __builtin_amdgcn_make_buffer_rsrc((void*)gd.x, 0, (int)((uint32_t)(gd.N * gVp) * (uint32_t)Cin * 4u), 0x00020000);
@@ -3836,13 +3867,22 @@ __global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const WGroupTable 
         if (q >= g_end || g_i < 0) enter_group(q);                  // (uniform)
         const int m = (q - g_begin) * WG_BK + ml;                   // pooled voxel (n, e, i, j)
         const bool mv = m < gM;
-        const bool small = gM < (1 << 24);
-        const int n = small ? fast_div(m, gVn, 1.0f / (float)gVn) : m / gVn;
-        const int sp = m - n * gVn;
-        const int e = small ? fast_div(sp, gHWn, 1.0f / (float)gHWn) : sp / gHWn;
-        const int r = sp - e * gHWn;
-        const int i = small ? fast_div(r, gWn, 1.0f / (float)gWn) : r / gWn;
-        const int j = r - i * gWn;
+        int n, sp, e, i, j;
+        if (g_pow2) {                                               // (uniform)
+            n = m >> g_lv;
+            sp = m & (gVn - 1);
+            e = sp >> g_lhw;
+            i = (sp >> g_lw) & (gHn - 1);
+            j = sp & (gWn - 1);
+        } else {
+            const bool small = gM < (1 << 24);
+            n = small ? fast_div(m, gVn, 1.0f / (float)gVn) : m / gVn;
+            sp = m - n * gVn;
+            e = small ? fast_div(sp, gHWn, 1.0f / (float)gHWn) : sp / gHWn;
+            const int r = sp - e * gHWn;
+            i = small ? fast_div(r, gWn, 1.0f / (float)gWn) : r / gWn;
+            j = r - i * gWn;
+        }
         const bool vc = mv && (g_tm != 0 || dz == 0);               // members without a time axis only have the dz = 0 rows
         const uint32_t gbase = mv ? (uint32_t)(n * gVn) * (uint32_t)Cout + (uint32_t)sp : 0u;
         const uint32_t xb = vc ? (uint32_t)(n * gVp) * (uint32_t)Cin +
