@@ -82,20 +82,23 @@ def pmc_traffic():
     process). The profile names the commit whose conv.hip it measured; when the kernel source has changed since, the
     figure is dropped (None) rather than reported stale. Returns (bytes, note) or (None, None)."""
     try:
-        path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-        if not os.path.exists(path):
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+        if not found:
             return None, None
+        path = found[-1]                                       # the newest round's passes
+        name = 'profiles/' + os.path.basename(path)
         d = json.load(open(path))
         import hashlib
         src = open(os.path.join(ROOT, 'txt2vid_amd', 'csrc', 'conv.hip'), 'rb').read()
         if d.get('conv_hip_sha1') != hashlib.sha1(src).hexdigest():
-            return None, 'profiles/r03_pmc_traffic.json was measured on an older conv.hip (sha1 %s): dropped' % d.get('conv_hip_sha1', '?')[:10]
+            return None, '%s was measured on an older conv.hip (sha1 %s): dropped' % (name, d.get('conv_hip_sha1', '?')[:10])
         for k, v in d['kernels'].items():
             if 'conv_igemm_strip3' in k and v.get('FETCH_SIZE_KB_per_launch') and v.get('WRITE_SIZE_KB_per_launch'):
                 b = (v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024.0
-                return b, ('profiles/r03_pmc_traffic.json: %s, HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 PMC passes; '
+                return b, ('%s: %s, HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 PMC passes; '
                            'average over its forward and masked data-gradient launches); algorithmic %.1f MB; FETCH_SIZE may under-count '
-                           'streaming reads by up to 2x on gfx950' % (k, d['algorithmic_bytes_per_launch']['strip3<64> fwd / dgrad (x + y + w)'] / 1e6))
+                           'streaming reads by up to 2x on gfx950' % (name, k, d['algorithmic_bytes_per_launch']['strip3<64> fwd / dgrad (x + y + w)'] / 1e6))
     except Exception:
         pass
     return None, None
@@ -578,9 +581,10 @@ def main():
         log('HBM-bound kernels in isolation')
         try:
             res['hbm_bound'] = hbm_bound_lines(device=dev, batch=args.batch)
-            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')
-            if os.path.exists(pmc):
-                res['hbm_bound']['pmc'] = 'profiles/r03_pmc_hbm.json (rocprofv3 FETCH_SIZE / WRITE_SIZE per launch of the same micro-benchmark)'
+            import glob
+            pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm.json')))
+            if pmc:
+                res['hbm_bound']['pmc'] = 'profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE per launch of the same micro-benchmark)' % os.path.basename(pmc[-1])
         except Exception as e:                                    # never let a side measurement take the headline down
             res['hbm_bound'] = {'error': repr(e)[:300]}
     if world > 1:

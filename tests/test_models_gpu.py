@@ -690,7 +690,7 @@ def test_benchmark_iteration_B32_vs_oracle(tmp_path, monkeypatch):
             launched.add(key)
             assert key in checked_fwd, ('launched at B=32 but in no op-level parity case', key, line)
         elif kind == 1:
-            key = ({0: 'taps', 1: 'cols', 2: 'rows3', 3: 'gemm', 11: 'pool_rows3'}[plan[0]], ('reduce', 'reduce_small')[plan[4]])
+            key = ({0: 'taps', 1: 'cols', 2: 'rows3', 3: 'gemm', 4: 'thin', 11: 'pool_rows3'}[plan[0]], ('reduce', 'reduce_small')[plan[4]])
             launched.add(key)
             assert key in checked_wgrad, key
     # the stem's second convolution runs in its pooled form (box-sum + stride-2 GEMMs), the other big layers on the strip kernels
@@ -758,7 +758,7 @@ def test_benchmark_iteration_B32_bf16_launch_plans_are_covered(tmp_path, monkeyp
             key = (kinds[plan[0]],) + tuple(plan[1:7])
             assert key in checked_fwd, key
         elif kind == 1:
-            name = {0: 'taps', 1: 'cols', 2: 'rows3', 3: 'gemm', 11: 'pool_rows3'}[plan[0]]
+            name = {0: 'taps', 1: 'cols', 2: 'rows3', 3: 'gemm', 4: 'thin', 11: 'pool_rows3'}[plan[0]]
             if plan[6] == 1:
                 key = (name, 1, plan[7])
                 assert key in bf_wg, ('bf16 weight-gradient launch covered by no BF16_CASES entry', key, line)

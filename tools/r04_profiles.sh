@@ -4,7 +4,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/r04
-rm -rf $O; mkdir -p $O
+mkdir -p $O; rm -rf $O/trace $O/pmc_* $O/trace_*
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_d_roofline --no_extra > $O/trace.log 2>&1 && echo "trace ok"
 rc=$?

@@ -170,5 +170,20 @@ def hbm_bound_lines(device=None, batch=32, iters=20):
     gz = [torch.randn(sh[0], 64, sh[2] // 2, sh[3] // 2, sh[4] // 2, generator=g).to(dev) for sh in shapes]
     planes = pool_dgrad_raw(gz, shapes, tm, torch.randn(64, 64, 3, 3, 3, generator=g).to(dev) * 0.05)
     us = timed(lambda: unbox_raw(planes, shapes, tm, masks=hs))
-    line('pool_unbox_k', sum(p.numel() for p in planes) * 4 + 2 * nb_in, us, 'adjoint of the box-sum: reads the class planes and the ReLU mask, writes dL/dr')
+
+    def plane_entries_read(sh, tmode):
+        """Class-plane entries pool_unbox_k reads for one member: an odd-parity class only lives on the first D' / H' / W' grid
+        positions of its axis, and a tmode-2 member reads D' time positions of either time class (the padded planes'
+        full extent over-counted the algorithmic bytes)."""
+        n, c, d, h, w = sh
+        dn, hn, wn = (d // 2 if tmode else 1), h // 2, w // 2
+        tot = 0
+        for ct in ((0, 1) if tmode else (0,)):
+            dt = 1 if tmode == 0 else (dn if (tmode == 2 or ct) else dn + 1)
+            for cy in (0, 1):
+                for cx in (0, 1):
+                    tot += dt * (hn if cy else hn + 1) * (wn if cx else wn + 1)
+        return n * c * tot
+    nb_planes = sum(plane_entries_read(sh, t) for sh, t in zip(shapes, tm)) * 4
+    line('pool_unbox_k', nb_planes + 2 * nb_in, us, 'adjoint of the box-sum: reads the class-plane entries it needs and the ReLU mask, writes dL/dr')
     return out
