@@ -279,6 +279,11 @@ int t2v_bn_train_fwd_up(const float* x, const float* gamma, const float* beta, f
                         int64_t* num_batches_tracked, void* stream);
 int t2v_bn_train_bwd_up(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, float* gx,
                         float* ggamma, float* gbeta, float* ws, int N, int C, int H, int W, int relu, void* stream);
+/* the two adjoints above (`up` = 0 / 1; S = H * W) with gx = BatchNorm's input gradient + gx_add (may be NULL): the gradient
+   the same input received from its other consumer — the UpBlock's skip path, the next level behind a RenderBlock's map
+   (layers.py:152-195, 245-259) — is summed by this pass. */
+int t2v_bn_train_bwd_add(const float* gy, const float* x, const float* y, const float* stats, const float* gamma, const float* gx_add,
+                         float* gx, float* ggamma, float* gbeta, float* ws, int N, int C, int H, int W, int up, int relu, void* stream);
 int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta,
                 float* y, int N, int C, int64_t S, float eps, int relu, void* stream);
 

@@ -148,6 +148,7 @@ SIGNATURES = {
     't2v_bn_train_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     't2v_bn_train_fwd_up': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P],
     't2v_bn_train_bwd_up': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    't2v_bn_train_bwd_add': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't2v_bn_eval': [_P, _P, _P, _P, _P, _P, _I, _I, _L, _F, _I, _P],
     't2v_lstm_gates': [_P, _P, _P, _P, _P, _I, _L, _P],
     't2v_lstm_gates_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P],

@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256) void bn_apply_merge_k(const float* x, const fl
 template <bool UP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_merge_k(const float* gy, const float* x, const float* y, const float* stats,
                                                             const float* gamma, const float* part, int split, float* gx,
-                                                            float* ggamma, float* gbeta, int N, int C, long S, int relu, int W) {
+                                                            float* ggamma, float* gbeta, int N, int C, long S, int relu, int W,
+                                                            const float* __restrict__ add = nullptr) {
+    // add: the gradient the input received from its OTHER consumers (t2v_bn_train_bwd_add): summed in here, no add launch
     const int c = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < split; ++k) { s1 += part[((size_t)c * split + k) * 2]; s2 += part[((size_t)c * split + k) * 2 + 1]; }
@@ -650,7 +652,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_merge_k(const float* gy, con
         const size_t idx = ((size_t)nn * C + c) * S + sp;
         const float g = bn_gy<UP>(gy, y, idx, sp, W, relu);
         const float xh = (x[idx] - mean) * istd;
-        gx[idx] = k0 * (g - a1 - xh * a2);
+        const float v = k0 * (g - a1 - xh * a2);
+        gx[idx] = add ? v + add[idx] : v;
     }
 }
 static int bn_slices(int N, int C, long S) {           // workgroups per channel of the fused second passes
@@ -742,6 +745,27 @@ extern "C" int t2v_bn_train_bwd(const float* gy, const float* x, const float* y,
     T2V_LAUNCH(bn_bwd_part_k<false>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, (long)S, relu, sp, 1);
     T2V_LAUNCH(bn_bwd_apply_merge_k<false>, dim3(C, bn_slices(N, C, (long)S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
                ggamma, gbeta, N, C, (long)S, relu, 1);
+    return launch_status();
+}
+// t2v_bn_train_bwd / t2v_bn_train_bwd_up (`up`) with gx = (BatchNorm input gradient) + gx_add: the block input of an UpBlock /
+// the abstract map in front of a RenderBlock feeds the BatchNorm AND another consumer (layers.py:152-195, tganv2/gen.py:
+// 107-116); the other consumer's gradient is summed into this pass instead of by a separate add launch of the autograd engine.
+extern "C" int t2v_bn_train_bwd_add(const float* gy, const float* x, const float* y, const float* stats, const float* gamma,
+                                    const float* gx_add, float* gx, float* ggamma, float* gbeta, float* ws, int N, int C, int H,
+                                    int W, int up, int relu, void* st) {
+    if (!gy || !x || !stats || !gamma || !gx || !ggamma || !gbeta || !ws || N < 1 || C < 1 || H < 1 || W < 1) return T2V_EINVAL;
+    if (relu && !y) return T2V_EINVAL;
+    const long S = (long)H * W;
+    const int sp = bn_split(N, C, S);
+    if (up) {
+        T2V_LAUNCH(bn_bwd_part_k<true>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, S, relu, sp, W);
+        T2V_LAUNCH(bn_bwd_apply_merge_k<true>, dim3(C, bn_slices(N, C, S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
+                   ggamma, gbeta, N, C, S, relu, W, gx_add);
+    } else {
+        T2V_LAUNCH(bn_bwd_part_k<false>, dim3(C, sp), dim3(256), 0, S_(st), gy, x, y, stats, ws, N, C, S, relu, sp, 1);
+        T2V_LAUNCH(bn_bwd_apply_merge_k<false>, dim3(C, bn_slices(N, C, S)), dim3(256), 0, S_(st), gy, x, y, stats, gamma, ws, sp, gx,
+                   ggamma, gbeta, N, C, S, relu, 1, gx_add);
+    }
     return launch_status();
 }
 extern "C" int t2v_bn_eval(const float* x, const float* rm, const float* rv, const float* gamma, const float* beta, float* y,

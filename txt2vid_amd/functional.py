@@ -1455,11 +1455,64 @@ class BatchNormAct(Function):
         return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, counter=None, up=False):
+class BatchNormActFork(Function):
+    """Training-mode `BatchNormAct` of a tensor that ALSO feeds a second consumer (an UpBlock's input: BatchNorm + skip path,
+    layers.py:152-195; the map in front of a RenderBlock: BatchNorm + the next level): returns (y, x') with x' an alias of x for
+    the other consumer. The adjoint receives both gradients at once and the BatchNorm backward pass adds the alias's gradient
+    while it writes dL/dx (`t2v_bn_train_bwd_add`): no add launch of the autograd engine, no add launch at all."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, momentum, eps, relu, counter, up):
+        x = _c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        S = x.numel() // (N * Cc)
+        if x.dim() != 4:
+            raise ValueError('BatchNorm2d takes [N,C,H,W] inputs')
+        ctx.up, ctx.relu = bool(up), relu
+        stats = torch.empty((2 * Cc,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, S)),), device=x.device, dtype=torch.float32)
+        H, W = x.shape[2], x.shape[3]
+        if up:
+            y = torch.empty((N, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+            check(lib().t2v_bn_train_fwd_up(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, H, W,
+                                            momentum, eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd_up')
+        else:
+            y = torch.empty_like(x)
+            check(lib().t2v_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(rmean), _p(rvar), _p(ws), N, Cc, S,
+                                         momentum, eps, int(relu), _p(counter), _stream()), 't2v_bn_train_fwd')
+        ctx.save_for_backward(x, y, stats, gamma)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, g2):
+        x, y, stats, gamma = ctx.saved_tensors
+        if g is None:                                   # (only the alias was used)
+            return (g2,) + (None,) * 9
+        g = _c(g)
+        g2 = _c(g2) if g2 is not None else None
+        N, Cc, H, W = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.empty_like(gamma)
+        gb = torch.empty_like(gamma)
+        ws = torch.empty((int(lib().t2v_bn_ws_floats(N, Cc, H * W)),), device=x.device, dtype=torch.float32)
+        check(lib().t2v_bn_train_bwd_add(_p(g), _p(x), _p(y), _p(stats), _p(gamma), _p(g2), _p(gx), _p(gg), _p(gb), _p(ws), N, Cc, H, W,
+                                         int(ctx.up), int(ctx.relu), _stream()), 't2v_bn_train_bwd_add')
+        return gx, gg, gb, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, rmean, rvar, training, momentum=0.1, eps=1e-5, relu=False, counter=None, up=False, fork=False):
     """`counter`: the module's int64 `num_batches_tracked` buffer, incremented by the same launch in training mode.
-    `up`: the result goes through a nearest x2 up-sampling in the same launches (UpBlock's BN-ReLU-Up head)."""
+    `up`: the result goes through a nearest x2 up-sampling in the same launches (UpBlock's BN-ReLU-Up head).
+    `fork`: returns (y, x') — x' an alias of the input for its OTHER consumer, whose gradient the BatchNorm adjoint sums in its
+    own pass (`BatchNormActFork`; eval mode / 3-D inputs: x' is x itself)."""
     if counter is not None and (counter.dtype != torch.int64 or not counter.is_cuda):
         raise TypeError('num_batches_tracked must be an int64 device tensor')
+    if fork:
+        if training and x.dim() == 4 and x.requires_grad and torch.is_grad_enabled():
+            return BatchNormActFork.apply(x, gamma, beta, rmean, rvar, momentum, eps, relu, counter, up)
+        return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter, up), x
     return BatchNormAct.apply(x, gamma, beta, rmean, rvar, training, momentum, eps, relu, counter, up)
 
 

@@ -46,11 +46,13 @@ class Linear(nn.Linear):
 class BatchNorm2d(nn.BatchNorm2d):
     """Training-mode batch statistics / eval-mode running statistics, optional fused ReLU."""
 
-    def forward(self, x, relu=False, up=False):
+    def forward(self, x, relu=False, up=False, fork=False):
+        """`fork`: returns (y, x') — x' is x for its second consumer (functional.BatchNormActFork)."""
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('only the default BatchNorm2d configuration is on the hot path')
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, relu, counter=self.num_batches_tracked if self.training else None, up=up)
+                                 self.momentum, self.eps, relu, counter=self.num_batches_tracked if self.training else None, up=up,
+                                 fork=fork)
 
 
 class ReLU(nn.Module):
@@ -231,12 +233,15 @@ class UpBlock(nn.Module):
 
     def forward(self, x):
         m = self.main.inner_module
+        # (the block input feeds the BatchNorm and the skip path: the BatchNorm adjoint sums the skip path's gradient in its own pass)
         if isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample) and isinstance(m[3], Conv2d) and TF.up_conv_ok(x, m[3].weight):
             # Up -> conv3x3 without the up-sampled tensor: 9 taps per INPUT pixel (a quarter of the MACs), functional_pool.py
             _check_same_conv(m[3])
-            h = TF.up_conv(m[0](x, relu=True), m[3].weight, m[3].bias)
+            h, x = m[0](x, relu=True, fork=True)
+            h = TF.up_conv(h, m[3].weight, m[3].bias)
         elif isinstance(m[0], BatchNorm2d) and isinstance(m[2], Upsample):
-            h = m[3](m[0](x, relu=True, up=True))                                      # BN+ReLU+Up fused
+            h, x = m[0](x, relu=True, up=True, fork=True)                              # BN+ReLU+Up fused
+            h = m[3](h)
         else:
             h = m[0](x, relu=True) if isinstance(m[0], BatchNorm2d) else m[1](m[0](x))
             h = m[3](m[2](h))
@@ -367,6 +372,11 @@ class RenderBlock(nn.Module):
         self.conv = which_conv(in_channels, out_channels, kernel_size=3, padding=1)
         self.final = Tanh()
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """`fork`: returns (image, x') — x' is the map for the next level (its gradient joins the BatchNorm adjoint's pass)."""
+        if fork and isinstance(self.bn, BatchNorm2d):
+            h, x = self.bn(x, relu=True, fork=True)
+            return self.final(self.conv(h)), x
         h = self.bn(x, relu=True) if isinstance(self.bn, BatchNorm2d) else self.activation(self.bn(x))
-        return self.final(self.conv(h))
+        r = self.final(self.conv(h))
+        return (r, x) if fork else r

@@ -84,7 +84,10 @@ class MultiScaleGen(nn.Module):
             x = self.abstract_blocks[i](x)
             abstract.append(x)
             if i == len(self.render_blocks) - 1 or self.training or (output_blocks is not None and i in output_blocks):
-                r = self.render_blocks[i](x)
+                if i + 1 < len(self.render_blocks):
+                    r, x = self.render_blocks[i](x, fork=True)               # the map also feeds the next level
+                else:
+                    r = self.render_blocks[i](x)
                 rendered.append(TF.frames_to_video(r, num_frames))           # [b,C,T,H,W]
         if return_abstract_maps:
             return rendered, abstract
