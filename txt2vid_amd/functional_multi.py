@@ -16,7 +16,7 @@ from ._ops import lib, check, _c, _p, _stream
  MJ_RELU_MASK, MJ_ROWSUM, MJ_ROWBCAST, MJ_ADD, MJ_CATLERP, MJ_CATCOLS, MJ_SLICECOLS, MJ_EMBEDCOLS) = range(1, 19)
 
 
-def _mj(op, jobs, scalar=None, dot_out=None):
+def _mj(op, jobs, scalar=None, dot_out=None, dot_accum=False):
     """jobs: list of dicts with keys a b c out out2 (tensors) and n d0 d1 d2 f0 f1 (ints)."""
     from ._lib import MultiJob
     for at in range(0, len(jobs), 8):
@@ -31,7 +31,7 @@ def _mj(op, jobs, scalar=None, dot_out=None):
                 setattr(a, key, q.get(key, 0))
         ws = None
         if op == MJ_DOT:
-            arr[0].out, arr[0].f0 = dot_out.data_ptr(), (1 if at > 0 else 0)
+            arr[0].out, arr[0].f0 = dot_out.data_ptr(), (1 if (at > 0 or dot_accum) else 0)
             ws = torch.empty((int(lib().t2v_multi_ws_floats(op, arr, len(part))),), device=dot_out.device, dtype=torch.float32)
         check(lib().t2v_multi(op, arr, len(part), _p(scalar), _p(ws), _stream()), 't2v_multi')
 
@@ -54,6 +54,11 @@ class AddG(Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        if torch.is_grad_enabled() and any(g is not None and g.requires_grad for g in gs):
+            # recorded backward (the gradient penalty's sweep): dL/dy feeds BOTH summands' adjoints — a grouped fork, so that the
+            # second backward sums the two contributions of all members in one launch (not one engine add per member)
+            a, b = _fork_some(list(gs))
+            return tuple(a) + tuple(b)
         return tuple(gs) + tuple(gs)
 
 
@@ -276,7 +281,11 @@ class BmmG(Function):
 
     @staticmethod
     def forward(ctx, cfgs, n, *ABs):
-        As, Bs = [_c(t) for t in ABs[:n]], [_c(t) for t in ABs[n:]]
+        # 4n tensors: the last 2n are autograd ALIASES of the operands (ForkG), saved for the adjoint in their place — a recorded
+        # adjoint (the gradient penalty's sweep) then hangs its products on the aliases, and the fork sums the operands' two
+        # gradient contributions for all members in one launch (otherwise: one engine add per operand and member)
+        aliased = len(ABs) == 4 * n
+        As, Bs = [_c(t) for t in ABs[:n]], [_c(t) for t in ABs[n:2 * n]]
         jobs, Cs = [], []
         for A, B, (ta, tb) in zip(As, Bs, cfgs):
             M, N, K = _bmm_dims(A, B, ta, tb)
@@ -284,8 +293,12 @@ class BmmG(Function):
             Cs.append(Cm)
             jobs.append(dict(a=A, b=B, out=Cm, n=A.shape[0], d0=M, d1=N, d2=K, f0=int(ta), f1=int(tb)))
         _mj(MJ_BMM, jobs)
-        ctx.save_for_backward(*As, *Bs)
+        if aliased:
+            ctx.save_for_backward(*[_c(t) for t in ABs[2 * n:]])
+        else:
+            ctx.save_for_backward(*As, *Bs)
         ctx.cfg = (cfgs, n)
+        ctx.aliased = aliased
         ctx.set_materialize_grads(False)
         return tuple(Cs)
 
@@ -312,7 +325,7 @@ class BmmG(Function):
             c = tuple((not cfgs[i][0], False) if not cfgs[i][1] else (True, cfgs[i][0]) for i in lb)
             for i, r in zip(lb, BmmG.apply(c, len(lb), *(X + Y))):
                 dBs[i] = r
-        return (None, None) + tuple(dAs) + tuple(dBs)
+        return (None, None) + tuple(dAs) + tuple(dBs) + ((None,) * (2 * n) if ctx.aliased else ())
 
 
 class SoftmaxG(Function):
@@ -321,13 +334,25 @@ class SoftmaxG(Function):
         xs = [_c(x) for x in xs]
         ys = [torch.empty_like(x) for x in xs]
         _mj(MJ_SOFTMAX, [dict(a=x, out=y, n=x.numel() // x.shape[-1], d0=x.shape[-1]) for x, y in zip(xs, ys)])
-        ctx.save_for_backward(*ys)
+        # outputs: ys for the consumers, then n ALIASES of them that the adjoint saves: a recorded adjoint (gradient penalty) hangs
+        # its use of y on the alias, and this node sums the two gradients of all members in one launch (AddG) itself
+        al = [y.view_as(y) for y in ys]
+        ctx.save_for_backward(*al)
         ctx.set_materialize_grads(False)
-        return tuple(ys)
+        return tuple(ys) + tuple(al)
 
     @staticmethod
-    def backward(ctx, *gs):
+    def backward(ctx, *gs2):
         ys = ctx.saved_tensors
+        n = len(ys)
+        gs, g2 = list(gs2[:n]), gs2[n:]
+        both = [i for i in range(n) if gs[i] is not None and g2[i] is not None]
+        for i in range(n):
+            if gs[i] is None:
+                gs[i] = g2[i]
+        if both:
+            for i, t in zip(both, AddG.apply(*([gs[i] for i in both] + [g2[i] for i in both]))):
+                gs[i] = t
         live = _live(gs)
         out = [None] * len(gs)
         if live:
@@ -394,10 +419,26 @@ class ScaleG(Function):
             if ctx.needs_input_grad[0] and torch.is_grad_enabled():      # recorded backward: the gradients feed the dot and the scale
                 lg, lg2 = fork_group(lg)
             if ctx.needs_input_grad[0]:
-                d_s = DotG.apply(len(live), *(lg2 + [as_[i] for i in live]))
+                done, d_s = _dot_to_sink(s, lg2, [as_[i] for i in live])
+                if not done:
+                    d_s = DotG.apply(len(live), *(lg2 + [as_[i] for i in live]))
             for i, r in zip(live, ScaleG.apply(s, *lg)):
                 d_as[i] = r
         return (d_s,) + tuple(d_as)
+
+
+def _dot_to_sink(s, as_, bs):
+    """sum_i <as[i], bs[i]> written straight into the gradient-sink slot of the 0-d parameter `s` (the non-local block's gain),
+    accumulating when the slot already holds this step's first contribution: (handled, gradient for autograd | None). The
+    engine otherwise adds the forward graph's and the gradient penalty's contributions with an ATen launch of its own."""
+    from . import functional as TF
+    if torch.is_grad_enabled():
+        return False, None
+    as_, bs = [_c(t) for t in as_], [_c(t) for t in bs]
+
+    def compute(out, accum):
+        _mj(MJ_DOT, [dict(a=a, b=b, out=out, n=a.numel()) for a, b in zip(as_, bs)], dot_out=out, dot_accum=accum)
+    return TF._to_sink(s, compute)
 
 
 class DotG(Function):
@@ -442,15 +483,24 @@ class ScaleAddG(Function):
         s, os_ = saved[0], saved[1:]
         live = _live(gs)
         d_s, d_os = None, [None] * n
+        res = gs
         if live:
-            lg = [gs[i] for i in live]
+            gd = gsc = gs
+            if torch.is_grad_enabled() and any(gs[i].requires_grad for i in live):
+                # recorded backward: dL/dy feeds the dot (d gamma), the scale (d o) and the residual — grouped forks, see AddG
+                gsc, res = _fork_some(list(gs))
+                gd = gsc
+                if ctx.needs_input_grad[0]:
+                    gd, gsc = _fork_some(list(gsc))
             if ctx.needs_input_grad[0]:
-                d_s = DotG.apply(len(live), *(lg + [os_[i] for i in live]))
+                done, d_s = _dot_to_sink(s, [gd[i] for i in live], [os_[i] for i in live])
+                if not done:
+                    d_s = DotG.apply(len(live), *([gd[i] for i in live] + [os_[i] for i in live]))
             lo = [i for i in live if ctx.needs_input_grad[2 + i]]
             if lo:
-                for i, r in zip(lo, ScaleG.apply(s, *[gs[i] for i in lo])):
+                for i, r in zip(lo, ScaleG.apply(s, *[gsc[i] for i in lo])):
                     d_os[i] = r
-        return (d_s, None) + tuple(d_os) + tuple(gs)
+        return (d_s, None) + tuple(d_os) + tuple(res)
 
 
 class ReluMaskG(Function):
@@ -526,11 +576,17 @@ def max_pool2x2_group(xs):
 
 
 def bmm_group(As, Bs, ta, tb):
-    return list(BmmG.apply(tuple((ta, tb) for _ in As), len(As), *(list(As) + list(Bs))))
+    As, Bs = list(As), list(Bs)
+    cfgs = tuple((ta, tb) for _ in As)
+    if torch.is_grad_enabled() and all(t.requires_grad for t in As + Bs):
+        # operands + their aliases for the adjoint (see BmmG.forward): one grouped fork for all of them
+        ops, als = fork_group(As + Bs)
+        return list(BmmG.apply(cfgs, len(As), *(ops + als)))
+    return list(BmmG.apply(cfgs, len(As), *(As + Bs)))
 
 
 def softmax_lastdim_group(xs):
-    return list(SoftmaxG.apply(*xs))
+    return list(SoftmaxG.apply(*xs))[:len(xs)]
 
 
 def scale_add_group(gamma, os_, xs):
