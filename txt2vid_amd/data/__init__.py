@@ -214,7 +214,7 @@ class SyntheticMovingDigits(torch.utils.data.Dataset):
         words = ['<start>', 'digit'] + [str(d) for d in range(10)] + ['is', 'left', 'and', 'right', 'top', 'bottom', '<end>']
         ids = (C.c_int32 * len(words))(*[int(self.vocab(w)) for w in words])
         if getattr(self, '_err', None) is None or self._err.device != dev:
-            self._err = torch.zeros((1,), device=dev, dtype=torch.int32)
+            self._err = torch.zeros((1,), dtype=torch.int32).to(dev)            # (zero by copy: no fill kernel)
         check(lib().t2v_synth_clips(C.c_void_p(idx.data_ptr()), B, int(self.seed), T, Cc, S, ids, C.c_void_p(vids.data_ptr()),
                                     C.c_void_p(toks.data_ptr()), C.c_void_p(self._err.data_ptr()), _stream()), 't2v_synth_clips')
         return vids, toks, [8] * B

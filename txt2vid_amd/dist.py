@@ -76,6 +76,14 @@ def sync_replicas(modules, src=0):
     return n
 
 
+def _zeros(n, device, dtype):
+    """torch.zeros; fp32 device buffers go through the fill kernel (functional.zeros)."""
+    if torch.device(device).type == 'cuda' and dtype == torch.float32:
+        from . import functional as TF
+        return TF.zeros((n,), device, dtype)
+    return torch.zeros(n, device=device, dtype=dtype)
+
+
 def _is_tap_major_view(v):
     """True when the memory behind a conv-weight-shaped view is laid out [*k][Cout][Cin] (functional.tap_major)."""
     nd = v.dim()
@@ -111,7 +119,7 @@ class GradArena(object):
         self.numel = n
         self.numel_dense = sum(p.numel() for p in dense)
         p0 = self.params[0]
-        self.flat = torch.zeros(n, device=p0.device, dtype=p0.dtype)
+        self.flat = _zeros(n, p0.device, p0.dtype)
         self.copy_fn = copy_fn
         self.sparse = []                       # (offset in flat, rows = Cout*Cin, taps per row T, live tap list, offset in compact, tap-major?)
         m = 0
@@ -123,7 +131,7 @@ class GradArena(object):
             rows = p.numel() // T
             self.sparse.append((self.offsets[len(dense) + len(self.sparse)], rows, T, taps, m, not p.is_contiguous()))
             m += rows * len(taps)
-        self.compact = torch.zeros(m, device=p0.device, dtype=p0.dtype) if m else None
+        self.compact = _zeros(m, p0.device, p0.dtype) if m else None
         self.half = None
         if self.exchange_dtype is not None:
             self.half_dense = (self.numel_dense + 7) // 8 * 8             # (the compact part starts 16-byte aligned)

@@ -2710,6 +2710,27 @@ def _zeros_like(t):
     return out
 
 
+def zeros(shape, device, dtype=torch.float32):
+    """torch.zeros on the fill kernel for fp32 device tensors (optimiser state, gradient arenas: no ATen kernel even at set-up)."""
+    dev = torch.device(device)
+    if dev.type != 'cuda' or dtype != torch.float32:
+        return torch.zeros(shape, device=dev, dtype=dtype)
+    out = torch.empty(shape, device=dev, dtype=dtype)
+    if out.numel():
+        check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
+    return out
+
+
+def zeros_like(t):
+    """zeros in `t`'s own memory layout (dense or tap-major): the fill kernel for fp32 device tensors."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        return torch.zeros_like(t, memory_format=torch.preserve_format)
+    out = torch.empty_like(t, memory_format=torch.preserve_format)
+    if out.numel():
+        check(lib().t2v_fill(_p(out), 0.0, out.numel(), _stream()), 't2v_fill')
+    return out
+
+
 class ConvG(Function):
     """ys = [conv(relu?(x), w) + b for x in xs] in one launch. The backward only touches the members that
     actually received a gradient AND need one: members that ride along for the forward only (detached real

@@ -91,6 +91,7 @@ class TrainStep(object):
         self.gan, self.optD, self.optG, self.losses, self.params = gan, optD, optG, losses, params
         self.device, self.end2end, self.grad_sync = device, end2end, grad_sync
         self.lD = self.lG = self.fake = self.xs = self.conds = None
+        self._one = None                  # dL/dL = 1 for both backward passes: one persistent 0-d tensor (no fill launch per pass)
         # weight / bias gradients land directly in flat per-model arenas (the ones the data-parallel exchange
         # all-reduces, when there is one): no per-parameter sums, no gather copies
         self.grad_sink = None
@@ -104,6 +105,11 @@ class TrainStep(object):
                 gan.__dict__['_t2v_grad_sink'] = cached          # one pair of arenas per model, reused by every step
             self.grad_sink = cached[1]
 
+    def _root(self, loss):
+        if self._one is None or self._one.device != loss.device or self._one.shape != loss.shape:
+            self._one = TF.ones_like(loss.detach())
+        return self._one
+
     def _arm_sink(self):
         TF.set_grad_sink(self.grad_sink)
         TF.grad_sink_reset()              # the step about to run clears this model's gradients first
@@ -116,7 +122,7 @@ class TrainStep(object):
         self.fake = self.gan(z, cond=self.conds[0] if self.conds is not None else None)
         loss = self.gan.discrim_step(real=self.xs, fake=[f.detach() for f in self.fake], cond=self.conds,
                                      loss=self.losses.discrim_loss, gp_lambda=p.gp_lambda)
-        loss.backward(retain_graph=self.end2end)
+        loss.backward(gradient=self._root(loss), retain_graph=self.end2end)
         TF.grad_sink_flush()              # the weight-gradient partial sums of the whole pass, summed in one launch
         self.lD = loss.detach()
 
@@ -135,7 +141,7 @@ class TrainStep(object):
                 with torch.no_grad():
                     _, _, real_pred = self.gan.all_discrim_forward(real=self.xs, cond=self.conds, fake=None, loss=None)
             loss = self.gan.gen_step(fake=self.fake, real_pred=real_pred, cond=self.conds, loss=self.losses.gen_loss)
-        loss.backward()
+        loss.backward(gradient=self._root(loss))
         TF.grad_sink_flush()
         self.lG = loss.detach()
 
@@ -299,7 +305,7 @@ class GraphedSentenceEncoder(object):
             return self.enc.encode(tokens, lengths)[2].detach()
         ent = self.entries.get((B, L))
         if ent is None:
-            ent = [torch.zeros((B, L), dtype=torch.int32, device=self.device), torch.zeros((B,), dtype=torch.int32, device=self.device),
+            ent = [torch.zeros((B, L), dtype=torch.int32).to(self.device), torch.zeros((B,), dtype=torch.int32).to(self.device),
                    None, None]
             self.entries[(B, L)] = ent
             return self.enc.encode(tokens, lengths)[2].detach()

@@ -98,8 +98,8 @@ class Adam(torch.optim.Optimizer):
                 st = self.state[p]
                 if len(st) == 0:
                     st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg'] = TF.zeros_like(p)
+                    st['exp_avg_sq'] = TF.zeros_like(p)
                 _check_state_layout(self, p, st, ('exp_avg', 'exp_avg_sq'))
                 st['step'] = int(st['step']) + 1
                 g = p.grad
