@@ -184,6 +184,7 @@ class GradSink(object):
             self._flush(list(self.pending.values()))
 
     def _flush(self, dests):
+        _side.join()                                       # (slabs written on the side stream)
         arr = (WgradDest * len(dests))()
         blocks = 0
         sig = []
@@ -229,6 +230,40 @@ class GradSink(object):
 
 
 _grad_sink = None
+
+
+class _SideLane:
+    """A second HIP stream for the deferred weight-gradient launches of a backward pass. A layer's weight gradient depends on
+    dL/dy and the saved input only, and nothing reads it before the sink's flush: launched on the main stream it sits IN the
+    data-gradient chain, and on the deep blocks (a few hundred voxels, a handful of workgroups walking K of several thousand)
+    both kernels leave most of the chip idle. Forked after the producer of dL/dy (event on the main stream) and joined in
+    `GradSink._flush`, the same launches overlap the chain; under capture the fork / join become graph edges."""
+
+    def __init__(self):
+        self.enabled = os.environ.get('T2V_WGRAD_SIDE') is not None
+        self.stream, self.used, self.keep = None, False, []
+
+    def fork(self, *tensor_lists):
+        """The stream handle for one launch that may overlap what follows on the current stream; `tensor_lists` are its
+        operands, kept alive until the join (they were allocated on, and would be recycled by, the main stream)."""
+        if not self.enabled:
+            return _stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.used = True
+        for ts in tensor_lists:
+            self.keep.extend(ts)
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def join(self):
+        if self.used:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.used = False
+            self.keep.clear()
+
+
+_side = _SideLane()
 
 
 def set_grad_sink(sink):
@@ -2675,7 +2710,8 @@ def _wgrad_partial_launch(xs5, gys5, wshape, relu_in, want_bias, sink=None, even
     src = WgradSrc()
     flags = (FLAG_RELU_IN if relu_in else 0) | (FLAG_BF16 if CONV_PRECISION == 'bf16' else 0)
     check(lib().t2v_conv_wgrad_grouped_partial(arr, len(xs5), Cin, Cout, k[0], k[1], k[2], _p(slab), 1 if want_bias else 0, flags,
-                                               C.byref(src), _stream()), 't2v_conv_wgrad_grouped_partial')
+                                               C.byref(src), _side.fork(xs5, gys5) if sink is not None else _stream()),
+          't2v_conv_wgrad_grouped_partial')
     return src, slab
 
 

@@ -238,8 +238,8 @@ def _pool_wgrad_to_sink(w, b, rts, gzs, shapes, tmodes, need_b):
             raise RuntimeError('bad pooled weight-gradient geometry')
         slab = sink.alloc_slab(n, rts[0].device)
         src = WgradSrc()
-        check(lib().t2v_pool_conv_wgrad_partial(arr, len(rts), cin, cout, 3, _p(slab), 1 if need_b else 0, 0, C.byref(src), _stream()),
-              't2v_pool_conv_wgrad_partial')
+        check(lib().t2v_pool_conv_wgrad_partial(arr, len(rts), cin, cout, 3, _p(slab), 1 if need_b else 0, 0, C.byref(src),
+                                                TF._side.fork(rts, gzs)), 't2v_pool_conv_wgrad_partial')
         sink.add_partial(wbase, wflat.view(w.shape), wacc, b if need_b else None, bflat, bacc, src, slab, 27, cout, cout * cin)
     else:
         pool_wgrad_raw(rts, gzs, shapes, tmodes, tuple(w.shape), out=wflat.view(w.shape), accum=wacc, dbias=bflat, accum_bias=bacc)
