@@ -7,6 +7,7 @@ un-subsampled clip batch [B,1,16,64,64], fp32, and reports
   * all-in: the same flops / wall time of forward+backward (pointwise, pooling, attention and launch gaps included).
 """
 import ctypes as C
+import os
 import time
 
 import torch
@@ -42,18 +43,44 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
         TF.vec_sum(u.reshape(-1)).backward()
         TF.grad_sink_flush()
 
-    for _ in range(2):
-        fwd_bwd()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fwd_bwd()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / iters
+    # warm-up, eager timing and capture all run on ONE side stream (AccumulateGrad nodes remember their stream), as GraphedTrainStep does
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        wall_eager = (time.perf_counter() - t0) / iters
+    # the pass as the training loop runs it: captured once, replayed (no host time between launches)
+    wall, mode = wall_eager, 'eager'
+    if os.environ.get('T2V_D_ROOFLINE_EAGER') is None:
+        for p in D.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        sink.frozen += 1
+        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = max(iters, 10)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            graph.replay()
+        torch.cuda.synchronize()
+        wall, mode = (time.perf_counter() - t0) / reps, 'hip-graph replay'
+        del graph
+        sink.frozen -= 1
     lib().t2v_prof_begin(1 << 14)
-    for _ in range(iters):
-        fwd_bwd()
+    with torch.cuda.stream(side):
+        for _ in range(iters):
+            fwd_bwd()
     torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
     out = (C.c_double * 18)()
     lib().t2v_prof_end(out, 6)          # kinds: 0 igemm, 1 wgrad, 2 wgrad reduce, 3 thin convs, 4 split-K reduce, 5 bf16 igemm
     TF.set_grad_sink(old_sink)
@@ -72,7 +99,7 @@ def d_fwdbwd_roofline(batch=32, iters=5, frames=16, size=64, attn=True, device=N
                              'igemm_fwd_dgrad': {'ms': ig_ms, 'tflops': ig_fl / ig_ms / 1e9, 'launches': ig_n},
                              'wgrad': {'ms': wg_ms + red_ms, 'tflops': wg_fl / (wg_ms + red_ms) / 1e9, 'launches': wg_n}},
             'all_in': {'wall_ms': wall * 1e3, 'tflops': flops / wall / 1e12, 'frac_of_fp32_mfma_peak': flops / wall / 1e12 / P,
-                       'videos_per_s': batch / wall},
+                       'videos_per_s': batch / wall, 'launch_mode': mode, 'eager_wall_ms': wall_eager * 1e3},
             # SURVEY §8(d)'s algorithmic figure for this unit of work: 75.75 GFLOP per [1,1,16,64,64] sample forward+backward (what the
             # reference's convolutions execute; the pooled second convolutions here execute a quarter / an eighth of their share). Over
             # the wall time: the rate a reference-equivalent implementation would have to sustain to match — NOT matrix-pipe utilisation
