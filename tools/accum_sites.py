@@ -14,19 +14,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from txt2vid_amd.gan.trainer import TrainStep  # noqa: E402
 
+COND = '--cond' in sys.argv           # the text-conditioned iteration (BASELINE configs[2])
+args_ = [a for a in sys.argv[1:] if not a.startswith('--')]
 dev = torch.device('cuda', 0)
-gen, dis, optD, optG, losses, CondGan = bench.build_models(dev)
-gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'])
+gen, dis, optD, optG, losses, CondGan = bench.build_models(dev, cond=COND)
+B = int(args_[0]) if args_ else 8
+txt = codes = None
+if COND:
+    from txt2vid_amd.data import Vocab  # noqa: E402
+    from txt2vid_amd.models.txt.basic import Seq2Seq  # noqa: E402
+    from txt2vid_amd.util.torch.init import init  # noqa: E402
+    txt = Seq2Seq(vocab_size=len(Vocab()))
+    init(txt, 'xavier')
+    txt.to(dev)
+    codes = txt.encode(torch.randint(4, len(Vocab()), (B, 8)).to(dev), [8] * B)[2].detach()
+gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'])
 prm = bench.Params()
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pool = bench.synthetic_batches(B, 2, 100, dev)
 random.seed(1); np.random.seed(1); torch.manual_seed(1)
 ts = TrainStep(gan, optD, optG, losses, prm, dev)
 for i in range(2):
-    ts.run(pool[i % 2], None)
+    ts.run(pool[i % 2], codes)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
-    ts.run(pool[0], None)
+    ts.run(pool[0], codes)
     torch.cuda.synchronize()
 sites = collections.Counter()
 for ev in prof.events():

@@ -13,19 +13,33 @@ import bench  # noqa: E402
 from txt2vid_amd import dist as tdist  # noqa: E402
 from txt2vid_amd import functional as TF  # noqa: E402
 
+COND = '--cond' in sys.argv          # the text-conditioned iteration (BASELINE configs[2]; `--bf16` as there)
+if '--bf16' in sys.argv:
+    TF.set_conv_precision('bf16')
 dev = torch.device('cuda', 0)
-gen, dis, optD, optG, losses, CondGan = bench.build_models(dev)
-gan = CondGan(gen=gen, discrims=[dis], discrim_names=['video'])
+gen, dis, optD, optG, losses, CondGan = bench.build_models(dev, cond=COND)
+txt = None
+codes = None
+if COND:
+    from txt2vid_amd.data import Vocab  # noqa: E402
+    from txt2vid_amd.models.txt.basic import Seq2Seq  # noqa: E402
+    from txt2vid_amd.util.torch.init import init  # noqa: E402
+    txt = Seq2Seq(vocab_size=len(Vocab()))
+    init(txt, 'xavier')
+    txt.to(dev)
+    tokens = torch.randint(4, len(Vocab()), (8, 8)).to(dev)
+    codes = txt.encode(tokens, [8] * 8)[2].detach()
+gan = CondGan(gen=gen, discrims=[dis], cond_encoder=txt, discrim_names=['video'])
 prm = bench.Params()
 pool = bench.synthetic_batches(8, 2, 100, dev)
 random.seed(1); np.random.seed(1); torch.manual_seed(1)
 from txt2vid_amd.gan.trainer import TrainStep  # noqa: E402
 ts = TrainStep(gan, optD, optG, losses, prm, dev)
 for i in range(2):
-    ts.run(pool[i % 2], None)
+    ts.run(pool[i % 2], codes)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
-    ts.run(pool[0], None)
+    ts.run(pool[0], codes)
     torch.cuda.synchronize()
 sites = collections.Counter()
 for ev in prof.events():

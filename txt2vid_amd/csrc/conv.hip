@@ -1286,9 +1286,12 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
         if (k < tab.n && tile >= tab.tile_start[k]) gi = k;
     const t2v_conv_group& gd = tab.g[gi];
     const int tm = gd.dstride;
-    const int pair = blockIdx.y & 3, ct = pair >> 1, cy = pair & 1;
+    // blockIdx.y = pair * (channel tiles) + channel tile: the class pair (0, 0) runs 4 kernel rows, (0, 1) and (1, 0) two, (1, 1) one —
+    // the dispatcher hands out workgroups in blockIdx order, so the long ones start first and the short ones fill the tail
+    const int nct = (int)gridDim.y >> 2;
+    const int pair = (int)blockIdx.y / nct, ct = pair >> 1, cy = pair & 1;
     if (tm == 0 && ct) return;                                   // (uniform) members without a time axis have one time class
-    const int co0 = (blockIdx.y >> 2) * BN;
+    const int co0 = ((int)blockIdx.y - pair * nct) * BN;
     const int Dn = tm ? gd.D / 2 : 1, Hn = gd.H / 2, Wn = gd.W / 2;           // extents of dL/dy
     const int Dq = tm ? Dn + 1 : 1, Hq = Hn + 1, Wq = Wn + 1;                 // the padded-grid planes
     const int HWn = Hn * Wn, Vn = Dn * HWn;
@@ -2407,8 +2410,9 @@ static bool build_table(const t2v_conv_group* groups, int ngroups, int Cin, int 
     long S = 1;
     // a reduction of <= 8 chunks (the 1x1 convolutions up to 256 input channels) is not worth a split: the second launch costs
     // more than the idle CUs (measured: -26 launches, -0.07 ms per iteration)
+    static const long split_target = env_long("T2V_SPLIT_TARGET", 768);      // workgroups a split launch aims at (developer sweeps)
     if (p.tiles < 384 && min_chunks > tun().nosplit_chunks) {
-        S = (768 + p.tiles - 1) / p.tiles;
+        S = (split_target + p.tiles - 1) / p.tiles;
         long maxS = min_chunks / 2;
         if (S > maxS) S = maxS;
         if (S > 64) S = 64;
@@ -3535,7 +3539,7 @@ struct LiveRows { int8_t r[9]; int32_t n; };    // slab row slot -> original ker
 // gathers are a constant stride apart; the three shifted copies of x are written unconditionally (the two writes that
 // fall outside the tile land in dummy columns).
 template <bool BF16>
-__global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+__global__ __launch_bounds__(256, BF16 ? 4 : 0) void conv_wgrad3_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                           const int Cout, const int kD, const int kH, const int flags,
                                                           const int chunks_per_split, const LiveRows live,
                                                           float* __restrict__ bias_slab) {
@@ -3798,7 +3802,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(const WGroupTable tab,
 // reduce kernels do not know the difference), same bias side-sum. Chunks of 32 pooled voxels; members without a time axis
 // (tmode 0) contribute to the dz = 0 rows only.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_pool_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
+__global__ __launch_bounds__(256, 4) void conv_pool_wgrad_kernel(const WGroupTable tab, float* __restrict__ slab, const int Cin,
                                                               const int Cout, const int chunks_per_split, const LiveRows live,
                                                               float* __restrict__ bias_slab) {
     constexpr int PA = WG_BK + 1;
@@ -4603,7 +4607,11 @@ static bool build_pool_dgrad(const t2v_conv_group* groups, int ngroups, int K, i
     // k-split over the channel blocks when the launch cannot fill the chip: every split writes its own set of 8 planes
     long S = 1;
     const long ncb = K / 32;
-    if (p.tiles < 384 && ncb >= 4) {
+    // (tiles counts all four class pairs although the pairs of an odd time class leave at once on members without a time axis and
+    //  the class (1, 1) runs a quarter of the rounds of (0, 0): up to 576 tiles two sets still pay — 400 tiles x 64 rounds, the
+    //  full-clip discriminator's 512 -> 256 block, 192 -> us)
+    static const long split_below = env_long("T2V_POOL_DGRAD_SPLIT_BELOW", 576);
+    if (p.tiles < split_below && ncb >= 4) {
         S = (768 + p.tiles - 1) / p.tiles;
         if (S > ncb / 2) S = ncb / 2;
         if (S > 8) S = 8;
