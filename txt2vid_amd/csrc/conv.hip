@@ -4675,7 +4675,10 @@ static bool build_pool_wtable(const t2v_conv_group* groups, int ngroups, int Cin
     const long wg_env = tun().wgrad_target, s_cap = tun().wgrad_scap;
     const long wg_target = wg_env ? wg_env : 1024;
     long S = base >= 1024 ? 1 : (wg_target + base - 1) / base;
-    long maxS = (nch + 7) / 8;                    // (4 chunks per split, which pays on the un-pooled kernels, measured no better here)
+    // at least 4 chunks (128 pooled voxels) per split, as for the un-pooled kernels (8 -> 4: -0.04 ms per iteration once the kernel
+    // ran four workgroups per CU; no better before)
+    static const long pool_mincps = env_long("T2V_POOL_WGRAD_MINCPS", 4);
+    long maxS = (nch + pool_mincps - 1) / pool_mincps;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     if (S > s_cap) S = s_cap;
