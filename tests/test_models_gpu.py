@@ -406,6 +406,41 @@ def test_graph_replay_matches_eager():
     assert gs.graphs is not None
 
 
+def test_weight_gradients_on_a_second_stream_give_the_same_iteration(monkeypatch):
+    """`T2V_WGRAD_SIDE` (functional._SideLane: the deferred weight-gradient launches forked onto a second stream after the producer
+    of dL/dy and joined before the sink's reduce; fork / join become graph edges under capture): the same kernels on the same
+    operands, so eager iterations and the captured / replayed ones must give the losses of the single-stream iteration."""
+    from txt2vid_amd import functional as TF
+    from txt2vid_amd.gan.trainer import train_iteration, GraphedTrainStep
+
+    def batches():
+        g = torch.Generator()
+        g.manual_seed(11)
+        return [(torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(4)]
+
+    def run(side, graphed):
+        monkeypatch.setattr(TF._side, 'enabled', side)
+        gan, optD, optG, losses, prm = _make_uncond()
+        random.seed(5)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        out = []
+        gs = GraphedTrainStep(gan, optD, optG, losses, prm, DEV, (4, 1, 16, 64, 64), warmup=2) if graphed else None
+        for x in batches():
+            lD, lG = gs.step(x) if graphed else train_iteration(gan, x, None, optD, optG, losses, prm, DEV)[:2]
+            out.append((float(lD), float(lG)))
+        torch.cuda.synchronize()
+        assert not TF._side.used and not TF._side.keep            # joined, operands released
+        return out
+    run(False, False)                                              # burn-in (see test_graph_replay_matches_eager)
+    base = run(False, False)
+    for graphed in (False, True):
+        got = run(True, graphed)
+        for i, (g, b) in enumerate(zip(got, base)):
+            tol = 5e-6 if (i < 2 or not graphed) else 5e-4
+            assert abs(g[0] - b[0]) < tol and abs(g[1] - b[1]) < tol, (graphed, i, g, b)
+
+
 def test_adam_step_counter_survives_a_second_capture():
     """`GraphedTrainStep` is rebuilt when the batch shape changes (trainer.py). Replays advance Adam's step counter on the device
     only; the second capture must carry on from it instead of falling back to the host-side count: after

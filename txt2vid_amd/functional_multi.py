@@ -188,6 +188,43 @@ class EmbedColsG(Function):
         return (None,) + tuple(out)
 
 
+class HeadRowsG(Function):
+    """outs[i] = xs[i][:ns[i]] (views) for n dense tensors; the adjoint writes the zero-padded gradients of ALL members in one
+    launch (`EmbedColsG` on the flattened tensors) — the native slices' adjoint is a zero-fill + a copy per member."""
+
+    @staticmethod
+    def forward(ctx, ns, *xs):
+        xs = [_c(x) for x in xs]
+        ctx.cfg = (tuple(int(n) for n in ns), tuple(tuple(x.shape) for x in xs))
+        ctx.set_materialize_grads(False)
+        return tuple(x[:n] for x, n in zip(xs, ns))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ns, shapes = ctx.cfg
+        out = [None] * len(ns)
+        live = [i for i in _live(gs) if ctx.needs_input_grad[1 + i]]
+        if live:
+            cfgs = []
+            for i in live:
+                total = 1
+                for d in shapes[i]:
+                    total *= d
+                cfgs.append((total, 0, total // shapes[i][0] * ns[i]))
+            res = EmbedColsG.apply(tuple(cfgs), *[gs[i].reshape(1, -1) for i in live])
+            for i, r in zip(live, res):
+                out[i] = r.view(shapes[i])
+        return (None,) + tuple(out)
+
+
+def head_rows_group(xs, ns):
+    """[x[:n] for x, n in zip(xs, ns)] with ONE launch in the adjoint for all members (at most 8 per launch)."""
+    xs = list(xs)
+    if not torch.is_grad_enabled() or not any(x.requires_grad for x in xs) or len(xs) > 8:
+        return [x[:n] for x, n in zip(xs, ns)]
+    return list(HeadRowsG.apply(tuple(ns), *xs))
+
+
 def cat_features_group(as_, bs):
     """[torch.cat((a, b), 1) for a, b in zip(as_, bs)] in one launch (2-D tensors, at most 8 pairs per launch)."""
     as_, bs = list(as_), list(bs)

@@ -115,12 +115,13 @@ class CondGan(object):
             shared = trunk[0].module if hasattr(trunk[0], 'module') and not hasattr(trunk[0], 'cond_heads') else trunk[0]
             if all(t is trunk[0] for t in trunk) and hasattr(shared, 'cond_heads'):
                 # one shared trunk: the mismatched-caption heads of every level in two launches
-                c_ic = shared.cond_heads([TF.head_rows(both[i][2], b[i]) for i in range(n)], list(fake_cond))
+                c_ic = shared.cond_heads(TF.head_rows_group([both[i][2] for i in range(n)], b), list(fake_cond))
             else:
                 c_ic = [trunk[i](cond=fake_cond[i], computed_features=TF.head_rows(both[i][2], b[i]))[1] for i in range(n)]
             lu = _mean_over_levels(loss, u_f, u_r)
-            l1 = _mean_over_levels(loss, c_f, c_r)
-            l2 = _mean_over_levels(loss, c_ic, c_r)
+            c_r1, c_r2 = TF.fork_group(list(c_r))          # the real logits enter two loss terms: one launch sums their gradients
+            l1 = _mean_over_levels(loss, c_f, c_r1)
+            l2 = _mean_over_levels(loss, c_ic, c_r2)
             l = TF.scalar_sum([lu, l1, l2], weights=[0.5, 0.25, 0.25])
             real_pred = [(u_r[i], c_r[i], TF.head_rows(both[i][2], b[i])) for i in range(n)]
             fake_pred = None

@@ -95,9 +95,19 @@ class AvgPool3d(nn.Module):
 def _nonlocal(self, x, pooled_planes):
     """Shared body of Attention / Attention3d (layers.py:23-36, 52-68)."""
     b = x.size(0)
-    theta = self.theta(x)
-    phi = TF.max_pool2x2(self.phi(x))
-    g = TF.max_pool2x2(self.g(x))
+    x_res = x
+    if x.dim() == 4 and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
+        # the block's input feeds three projections and the residual: the projections run as ONE Function whose data gradients
+        # land in one buffer, and a grouped fork sums that with the residual's (else the autograd engine adds the four
+        # contributions with three ATen launches)
+        (xa,), (x_res,) = TF.fork_group([x])
+        w5 = [m.weight.unsqueeze(2) for m in (self.theta, self.phi, self.g)]
+        (theta,), (phi,), (g,) = TF.conv_multi_group([xa.unsqueeze(2)], [(w, None, False) for w in w5])
+        theta, phi, g = theta.squeeze(2), TF.max_pool2x2(phi.squeeze(2)), TF.max_pool2x2(g.squeeze(2))
+    else:
+        theta = self.theta(x)
+        phi = TF.max_pool2x2(self.phi(x))
+        g = TF.max_pool2x2(self.g(x))
     theta = theta.reshape(b, self.ch // 8, -1)
     phi = phi.reshape(b, self.ch // 8, -1)
     g = g.reshape(b, self.ch // 2, -1)
@@ -109,7 +119,7 @@ def _nonlocal(self, x, pooled_planes):
         o = TF.bmm(g, beta, False, True)
     o = o.reshape((b, self.ch // 2) + tuple(x.shape[2:]))
     o = self.o(o)
-    return TF.scale_add(self.gamma, o, x)
+    return TF.scale_add(self.gamma, o, x_res)
 
 
 def nonlocal_levels(att, xs):

@@ -95,9 +95,15 @@ class Resnet3D(nn.Module):
             else:
                 hs = nonlocal_levels(d, hs)
         feats = TF.sum_spatial_group(hs)                                      # torch.sum(x, [2,3,4]) of every level: one launch
+        f_u = f_c = feats
+        if conds is not None:
+            # three consumers (unconditional head, conditional head, the caller's mismatched-caption head on the returned features):
+            # two grouped forks sum their gradients for all levels in two launches instead of two ATen adds per level
+            f_u, rest = TF.fork_group(feats)
+            f_c, feats = TF.fork_group(rest)
         w5 = self.fc_uncond.weight.view(self.fc_uncond.weight.shape + (1, 1, 1))
-        us = TF.conv_group([f.view(f.shape + (1, 1, 1)) for f in feats], w5, self.fc_uncond.bias)   # all heads: one launch
-        cs = self.cond_heads(feats, conds) if conds is not None else [None] * len(feats)
+        us = TF.conv_group([f.view(f.shape + (1, 1, 1)) for f in f_u], w5, self.fc_uncond.bias)   # all heads: one launch
+        cs = self.cond_heads(f_c, conds) if conds is not None else [None] * len(feats)
         return [(u.view(u.shape[0], u.shape[1]), c, feat) for feat, u, c in zip(feats, us, cs)]
 
     def cond_heads(self, feats, conds):
