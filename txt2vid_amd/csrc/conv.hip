@@ -3326,6 +3326,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WGroupTable 
     const int ncols = live.n * Cin;
     const float relu_floor = (flags & T2V_CONV_RELU_IN) ? 0.f : -__builtin_inff();
     const int kD = T / (kH * kW);
+#ifdef T2V_ABLATION
+    // developer ablations (tools/ablate_thin.py; wrong results): 64 no dL/dy loads, 128 no input gathers, 256 no staging, 512 no MFMAs
+    const bool ab_noy = flags & 64, ab_nox = flags & 128, ab_nostage = flags & 256, ab_nomfma = flags & 512;
+#else
+    constexpr bool ab_noy = false, ab_nox = false, ab_nostage = false, ab_nomfma = false;
+#endif
     if (tid < 32) {
         int info = -1;
         if (tid < ncols) {
@@ -3390,7 +3396,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WGroupTable 
         {
             const int m = mbase + a_vq;
             const bool in_round = a_vq < R * WG_BK;
-            if ((DHW & 3) == 0) {                                   // (uniform) the four voxels share a sample and a 16-byte line
+            if (ab_noy && q != q0) {
+            } else if ((DHW & 3) == 0) {                            // (uniform) the four voxels share a sample and a 16-byte line
                 int n, sp;
                 split_m(m, n, sp);
                 const bool mv = in_round && m < gM;
@@ -3442,17 +3449,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WGroupTable 
                 w_ = r - h * W;
             }
             const uint32_t xb = (uint32_t)(n * DHW) * (uint32_t)Cin + (uint32_t)sp;
+            // validity of the voxel's neighbours, one bit per offset -1 / 0 / +1 and axis: a column's mask is three shifts
+            // (the ablations put these gathers and their index arithmetic at 45 % of the launch on full clips)
+            const uint32_t vz = ((unsigned)(d - 1) < (unsigned)D ? 1u : 0u) | 2u | ((unsigned)(d + 1) < (unsigned)D ? 4u : 0u);
+            const uint32_t vy = ((unsigned)(h - 1) < (unsigned)H ? 1u : 0u) | 2u | ((unsigned)(h + 1) < (unsigned)H ? 4u : 0u);
+            const uint32_t vx = ((unsigned)(w_ - 1) < (unsigned)W ? 1u : 0u) | 2u | ((unsigned)(w_ + 1) < (unsigned)W ? 4u : 0u);
+            if (!(ab_nox && q != q0))
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = b_cg + 2 * j;
                 const int info = s_col[c];
-                const int dz = (info & 3) - 1, dy = ((info >> 2) & 3) - 1, dx = ((info >> 4) & 3) - 1, ci = (info >> 8) & 0xffff;
-                const bool ok = mv && info >= 0 && (unsigned)(d + dz) < (unsigned)D && (unsigned)(h + dy) < (unsigned)H &&
-                                (unsigned)(w_ + dx) < (unsigned)W;
-                const uint32_t off = ok ? xb + (uint32_t)ci * uDHW + (uint32_t)(dz * HW + dy * W + dx) : 0u;
+                if (c == 31) { rb[j] = mv ? 1.f : 0.f; continue; }  // the ones column: sum of dL/dy = the bias gradient
+                if (info < 0) { rb[j] = 0.f; continue; }            // (wave-uniform) a dead column: no load
+                const int iz = info & 3, iy = (info >> 2) & 3, ix = (info >> 4) & 3, ci = (info >> 8) & 0xffff;
+                const bool ok = mv && ((vz >> iz) & (vy >> iy) & (vx >> ix) & 1u);
+                const uint32_t off = ok ? xb + (uint32_t)ci * uDHW + (uint32_t)((iz - 1) * HW + (iy - 1) * W + (ix - 1)) : 0u;
                 const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_x, off * 4u, 0, 0));
                 rb[j] = ok ? fmaxf(v, relu_floor) : 0.f;
-                if (c == 31) rb[j] = mv ? 1.f : 0.f;                // the ones column: sum of dL/dy = the bias gradient
             }
         }
     };
@@ -3462,14 +3475,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WGroupTable 
     if (q < q1) load_round(q);
     while (q < q1) {
         const int R = rnd_chunks;
+        if (!(ab_nostage && q != q0)) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(&As[(a_co + 8 * p) * WT_P + a_vq]) = ra[p];
+            for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(&As[(a_co + 8 * p) * WT_P + a_vq]) = ra[p];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Bs[(b_cg + 2 * j) * WT_P + b_v] = rb[j];
+            for (int j = 0; j < 16; ++j) Bs[(b_cg + 2 * j) * WT_P + b_v] = rb[j];
+        }
         __syncthreads();
         q += R;
         if (q < q1) load_round(q);
-        {
+        if (!ab_nomfma) {
             const float* pa = As + (wco * 32 + l31) * WT_P + wk * 64 + hi * 32;
             const float* pb = Bs + l31 * WT_P + wk * 64 + hi * 32;
             float4 a4[8], b4[8];
