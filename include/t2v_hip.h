@@ -169,7 +169,9 @@ int t2v_wgrad_reduce_multi(const void* table /* device t2v_wgrad_dest[ndest] */,
  * assert that every instantiation — the benchmark shapes' in particular — is reached by a checked case.
  * fwd  out[8]: kind (0 implicit GEMM, 1 strip implicit GEMM, 2 thin conv, 3 thin linear, 4 thin two-pass, 5 strip GEMM with
  *              all three dx taps per barrier round), BM, BN, K chunk,
- *              FAST, VECB, KS, split-K S.   (groups[].x / .y may be NULL)
+ *              FAST, VECB, KS (2: the double-buffered form of the 64-voxel three-tap tile — one barrier per round, the
+ *              next round's loads and LDS writes between the MFMAs; K chunk then = its channels per round), split-K S.
+ *              (groups[].x / .y may be NULL)
  * wgrad out[6]: kernel (0 per-tap tiles, 1 (tap,ci) column tiles, 2 three-tap rows, 3 TN product on 1x1x1 maps — fp32 in bf16-compute mode too, 4 the streaming kernel for <= 31 (tap, ci) columns), S, chunks per split, slab slots,
  *              reduce kernel (0 / 1 = many-splits small-weight form), workgroups of the main launch. */
 int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out);

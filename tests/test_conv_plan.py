@@ -23,7 +23,7 @@ def test_benchmark_shapes_select_the_big_tile_paths():
     _, cin, cout, k, members, _ = cc.GROUPED_CASES[3]
     assert sum(n * d * h * w for n, d, h, w in members) == 49152
     assert cc.fwd_plan(members, cin, cout, k)[:4] == ('strip3', 128, 64, 32)
-    assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip3', 64, 64, 32, 1, 1, 1)
+    assert cc.fwd_plan(members, cout, cin, k)[:7] == ('strip3', 64, 64, 16, 1, 1, 2)      # the double-buffered form: 16-channel rounds
 
 
 # every instantiation the launchers in conv.hip can select (launch_conv_t + the thin kernels)
@@ -36,6 +36,7 @@ for bm, bn, bk in _TILES:
             ALL_FWD.add(('strip3', bm, bn, bk, 1, vecb, 1))                  # conv_igemm_strip3_kernel<BM,VECB>: 3 dx taps per round
         elif bk == 32 or bm == 256:
             ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>
+ALL_FWD.add(('strip3', 64, 64, 16, 1, 1, 2))                                 # strip3<64>'s double-buffered form (every member three taps wide)
 for bm, bn in ((128, 32), (128, 64), (64, 64)):
     ALL_FWD.add(('igemm', bm, bn, 16, 0, 0, 1))                              # generic-K: conv_igemm_kernel<BM,BN,*,16,false,false>
 ALL_FWD |= {('stem', 256, 1, 0, 0, 0, 0), ('stem', 256, 3, 0, 0, 0, 0),          # conv_stem_kernel<1 / 3>: the clips' first convolution
@@ -140,8 +141,8 @@ def test_environment_tunables_move_the_plan():
     are what the benchmark runs on (T2V_NO_OCC_PAD acts at launch time only: the resident-workgroup padding of the 256-voxel
     tile, covered on the GPU by the benchmark-size parity cases)."""
     base = _plans_in_child({})
-    assert base['small'][:4] == ['strip3', 64, 64, 32] and base['small'][7] > 1          # 32 tiles: 64-voxel tiles, split K
-    assert base['mid'][:4] == ['strip3', 64, 64, 32] and base['mid'][7] == 1             # 384 tiles of 64: no split
+    assert base['small'][:4] == ['strip3', 64, 64, 16] and base['small'][6:] == [2, base['small'][7]] and base['small'][7] > 1   # 32 tiles: 64-voxel tiles (double-buffered form), split K
+    assert base['mid'][:4] == ['strip3', 64, 64, 16] and base['mid'][7] == 1             # 384 tiles of 64: no split
     assert base['one'][7] == 1                                                          # 1x1x1, K = 8 chunks: never split
     assert base['deep'][7] > 1
     assert base['wbig'][0] == 'rows3' and base['wbig'][1] == 113                         # one round: 113 x 9 = 1017 workgroups
@@ -156,6 +157,9 @@ def test_environment_tunables_move_the_plan():
     assert forced['small'][7] == 3 and forced['mid'][7] == 3
     # strip kernels off: the plain implicit-GEMM instantiation of the same tile
     assert _plans_in_child({'T2V_NO_STRIP': '1'})['mid'][:4] == ['igemm', 64, 64, 32]
+    # the single-stage form of the 64-voxel three-tap tile
+    assert _plans_in_child({'T2V_STRIP3_DB': '0'})['mid'][:7] == ['strip3', 64, 64, 32, 1, 1, 1]
+    assert _plans_in_child({'T2V_STRIP3_DB': '32'})['mid'][:7] == ['strip3', 64, 64, 32, 1, 1, 2]
     # weight-gradient split count
     assert _plans_in_child({'T2V_WGRAD_SCAP': '64'})['wbig'][1] == 64
     assert _plans_in_child({'T2V_WGRAD_TARGET': '512'})['wbig'][5] <= 600

@@ -76,6 +76,7 @@ static inline int launch_status() {
 // ------------------------------------------------------------------------------------------------
 #include <hip/hip_ext.h>
 #include <vector>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 struct ProfRec { hipEvent_t e0, e1; double flops; int kind; long M; int Cin, Cout, taps, groups, S; int32_t plan[8]; };
@@ -826,8 +827,11 @@ __global__ __launch_bounds__(256) void conv_igemm_strip_kernel(const GroupTable 
 // (the next round's gathers are issued right after the first and land during the MFMA loop), 4 waves as 2 (co) x 2 (m).
 // Rounds = (row tap, channel block of 32); split-K runs over rounds. Members one voxel wide (ndx = 1) run their single tap.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BKT, int WAVES_CO, bool VECB>
-__global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
+#ifndef DB_STAGE_LATE
+#define DB_STAGE_LATE 1      // double-buffered form: the LDS writes of round q + 1 sit in the LAST slots of round q (0: right after the loads)
+#endif
+template <int BM, int BKT, int WAVES_CO, bool VECB, bool DB = false>
+__global__ __launch_bounds__(256, ((BM == 256 || (DB && BKT == 32)) ? 2 : (DB ? 4 : 3))) void conv_igemm_strip3_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, float* __restrict__ slab,
                                                                 const int Cin, const int Cout, const int flags, const int nsplit) {
 #ifdef T2V_STAMPS
@@ -847,8 +851,8 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
     constexpr int KSB = 256 / BN;
     static_assert(NCO >= 1 && NM >= 1 && LA >= 1 && LBV >= 1 && 2 * BKT <= 256, "tile");
 
-    __shared__ __attribute__((aligned(16))) float As[BKT * AP];
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[(DB ? 2 : 1) * BKT * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[(DB ? 2 : 1) * 3 * BKT * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -941,6 +945,119 @@ __global__ __launch_bounds__(256, (BM == 256 ? 2 : 3)) void conv_igemm_strip3_ke
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (DB) {
+        // ---- DOUBLE-BUFFERED form (64-voxel tiles, every member three taps wide): two LDS stages and two register sets, ONE barrier
+        // per round, and the round's global loads (data of round q + 2) and LDS writes (data of round q + 1) sit BETWEEN the 48 MFMAs
+        // of round q in program order — one item per MFMA — so that a wave's own matrix chain keeps issuing while its staging runs
+        // (the single-stage form above runs stage -> barrier -> load issue -> MFMAs -> barrier and relies on the other workgroups
+        // of the CU to cover a wave's staging; profiles/r04_strip3_stamps.txt: 3.1 k of a round's 11.6 k cycles are its MFMAs).
+        // The body is branch-free: past the last round it re-loads / re-stages the last round's data into the stage nobody reads.
+        static_assert(BM == 64 && (BKT == 32 || BKT == 16) && VECB && NCO == 1 && NM == 1, "double-buffered form: 64 x 64 x {32, 16} tiles");
+        constexpr int ASZ = BKT * AP, BSZ = 3 * BKT * BN;
+        constexpr int NI = LA + 1 + 3 * LBV;         // loads (and LDS writes) per thread and round: 15 / 8
+        constexpr int HS = (NI + 1) & ~1;            // first slot of the LDS writes: 16 / 8
+        const int ncb = Cin / BKT;
+        const int nrounds = nrow * ncb;
+        const int rps = (nrounds + nsplit - 1) / nsplit;
+        const int q0 = blockIdx.z * rps;
+        int q1 = q0 + rps;
+        if (q1 > nrounds) q1 = nrounds;
+        float ra2[2][LA], rah2[2] = {0.f, 0.f};
+        float4 rb2[2][3 * LBV];
+        bool pav[2] = {false, false}, phv[2] = {false, false};
+        uint32_t l_vo[2] = {0u, 0u}, l_vh[2] = {0u, 0u};
+        int l_sx[2] = {0, 0}, l_sw[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        const uint32_t xoff_hd = halo_thread ? xoff_h : 0u;          // (threads without a halo element load element 0 and store to the pad column)
+        const int halo_col = halo_thread ? (he ? BM + 1 : 0) : BM + 2;
+        const int halo_row = halo_thread ? hk : (tid % BKT);
+        // addresses of round q's loads into set `st` (scalars + two vector offsets)
+        auto prep = [&](int st, int q) {
+            const int qq = q < q1 ? q : q1 - 1;
+            const int r_cur = qq / ncb, cb = qq - r_cur * ncb;
+            const int c0 = cb * BKT;
+            const int roff = __builtin_amdgcn_readlane(tab_roff, r_cur);
+            l_sx[st] = c0 * DHW * 4;
+            pav[st] = (rowmask >> r_cur) & 1u;
+            phv[st] = halo_thread && ((rowmask_h >> r_cur) & 1u);
+            l_vo[st] = xoff + (pav[st] ? (uint32_t)roff : 0u);
+            l_vh[st] = xoff_hd + (phv[st] ? (uint32_t)roff : 0u);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) l_sw[st][d] = (__builtin_amdgcn_readlane(tab_widx, r_cur * 3 + d) * Cin + c0) * Cout * 4;
+        };
+        // item i of a round's 15 loads / 15 LDS writes (i is a compile-time constant at every call site)
+        auto load_item = [&](int st, int i) {
+            if (i < LA) ra2[st][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, l_vo[st], l_sx[st] + i * (KSA * 4) * DHW, 0));
+            else if (i == LA) rah2[st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, l_vh[st], l_sx[st], 0));
+            else if (i < LA + 1 + 3 * LBV) {
+                const int e = i - LA - 1, d = e / LBV, j = e - d * LBV;
+                rb2[st][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, l_sw[st][d] + j * (KSBV * 4) * Cout, 0));
+            }
+        };
+        auto stage_item = [&](int st, float* A, float* B, int i) {
+            if (i < LA) A[(ka_l + i * KSA) * AP + 1 + ma_l] = pav[st] ? fmaxf(ra2[st][i], relu_floor) : 0.f;
+            else if (i == LA) A[halo_row * AP + halo_col] = phv[st] ? fmaxf(rah2[st], relu_floor) : 0.f;
+            else if (i < LA + 1 + 3 * LBV) {
+                const int e = i - LA - 1, d = e / LBV, j = e - d * LBV;
+                *reinterpret_cast<float4*>(&B[d * (BKT * BN) + (kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rb2[st][e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        const float* a_tap[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const bool keep = d == 0 ? can_l[0] : (d == 2 ? can_r[0] : true);
+            a_tap[d] = keep ? As + d + wm * WM + l31 : As + (BM + 3);          // (1 + dx, dx = d - 1)
+        }
+        // one round: MFMAs on stage `cur`; loads of round q + 2 into register set `cur`, LDS writes of set `cur ^ 1` (round q + 1)
+        // into stage `cur ^ 1`
+        auto round = [&](auto CUR, int q) {
+            constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+            prep(cur, q + 2);
+            const float* Ab = As + cur * ASZ;
+            const float* Bb = Bs + cur * BSZ + wco * WCO + l31;
+            float* An = As + nxt * ASZ;
+            float* Bn = Bs + nxt * BSZ;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                    const int krow = k2 * 2 + hi, slot = d * (BKT / 2) + k2;
+                    const float a = Bb[d * (BKT * BN) + krow * BN];
+                    const float b = (a_tap[d] + cur * ASZ)[krow * AP];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0][0], 0, 0, 0);
+                    constexpr int SS = DB_STAGE_LATE ? 3 * (BKT / 2) - HS : HS;        // first slot of the LDS writes
+                    if (slot < HS) load_item(cur, slot);
+                    else if (slot >= SS && slot < SS + HS) stage_item(nxt, An, Bn, slot - SS);
+                    // (hipcc otherwise sinks the loads to the end of the round and hoists the LDS writes to its start: the data
+                    //  would be waited for right after it was requested)
+                    if (slot == HS - 1 || slot == SS - 1 || slot == SS + HS - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            (void)Ab;
+            __syncthreads();
+        };
+        if (tid < BKT) { As[tid * AP + BM + 3] = 0.f; As[ASZ + tid * AP + BM + 3] = 0.f; }
+        if (q0 < q1) {
+            prep(0, q0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) load_item(0, i);
+            prep(1, q0 + 1);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) load_item(1, i);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) stage_item(0, As, Bs, i);
+            // (set 0 is free again: round q0 loads round q0 + 2 into it; set 1 = round q0 + 1 is staged during round q0)
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
+        for (int q = q0; q < q1; q += 2) {
+            round(std::integral_constant<int, 0>{}, q);
+            if (q + 1 < q1) round(std::integral_constant<int, 1>{}, q + 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        igemm_epilogue<NCO, NM, WCO, WM>(acc, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWo, wm, wco, l31, hi, yds, gd.yoff,
+                                         gd.Dy * HW, HW);
+        return;
+    }
     float ra[LA], rah = 0.f;
     float rb[VECB ? 1 : 3 * LB];
     float4 rbv[VECB ? 3 * LBV : 1];
@@ -2468,6 +2585,17 @@ static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM
     return v;
 }
 
+// The double-buffered form of the 64-voxel strip3 tile (conv_igemm_strip3_kernel<64, BKT, 2, true, true>): 0 = not taken, else its
+// channels per round (16: four workgroups per CU; 32: two). Every member must carry all three dx taps and Cout % 4 == 0.
+// T2V_STRIP3_DB overrides (0 / 16 / 32). Shared by the launcher and the plan query (out[3] = channels per round, out[6] = 2).
+static int strip3_db(const GroupTable& tab, const ConvPlan& p) {
+    static const long db = env_long("T2V_STRIP3_DB", 16);
+    if ((db != 16 && db != 32) || !p.vecb || p.bm != 64 || p.bn != 64) return 0;
+    for (int i = 0; i < tab.n; ++i)
+        if (tab.g[i].dx[0] >= 0) return 0;
+    return (int)db;
+}
+
 // Wave quantisation of the 256-voxel tile: the kernel fits 3 workgroups on a CU but runs no faster per CU with 3 than with 2
 // (2 x 255 us = 3 x 382 us per 256 tiles), so a launch of e.g. 1024 tiles (the generator step's D forward, M = 262144) took
 // one round of 768 and a tail of 256 = 692 us where two rounds of 512 take 510. The launcher therefore picks the resident
@@ -2510,6 +2638,19 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
             constexpr int WCO3 = BM == 256 ? 1 : 2;
             const long nwg = (long)grid.x * grid.y * grid.z;
             int pad = 0;
+            if constexpr (BM == 64) {
+                // the double-buffered form (one barrier per round, staging between the MFMAs): every member three taps wide
+                const int db = strip3_db(tab, p);
+                const bool all3 = true;
+                if (db == 32 && all3) {
+                    T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<64, 32, 2, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+                    return;
+                }
+                if (db == 16 && all3) {
+                    T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<64, 16, 2, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+                    return;
+                }
+            }
             if (p.vecb) {
                 static OccInfo oi;
                 if (BM == 256) pad = occupancy_pad(conv_igemm_strip3_kernel<BM, BKT, WCO3, true>, oi, nwg);
@@ -2561,6 +2702,10 @@ static void fill_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, in
     out[0] = v.s3 ? 5 : (v.strip ? 1 : 0);
     out[1] = p.bm; out[2] = p.bn; out[3] = p.fast ? bk : 16;
     out[4] = p.fast ? 1 : 0; out[5] = (p.fast && p.vecb) ? 1 : 0; out[6] = v.ks; out[7] = p.S;
+    if (v.s3 && bk == 32) {
+        const int db = strip3_db(tab, p);
+        if (db) { out[3] = db; out[6] = 2; }
+    }
 }
 extern "C" int t2v_conv_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, int Cout, int flags, int32_t* out) {
     GroupTable tab;
