@@ -1207,12 +1207,12 @@ __global__ __launch_bounds__(256, ((BM == 256 || (DB && BKT == 32)) ? 2 : (DB ? 
 // wave, exactly as in strip3. Members: t2v_conv_group with x = r~, y = the pooled output, (D, H, W) = the FULL-RESOLUTION extents
 // and dstride = tmode (0: D == 1; 1 / 2: time strided with / without the box sum); taps in (dz, dy, dx) product order.
 // ------------------------------------------------------------------------------------------------
-template <int BM>
+template <int BM, bool DB = false>
 __global__ __launch_bounds__(256, 3) void conv_pool_fwd_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                const float* __restrict__ bias, float* __restrict__ slab,
                                                                const int Cin, const int Cout, const int flags, const int nsplit) {
     constexpr bool VECB = true;             // (host: Cout % 4 == 0 — the pooled path takes channel counts that are multiples of 32)
-    constexpr int BN = 64, BKT = 32, WAVES_CO = 2, WAVES_M = 2;
+    constexpr int BN = 64, BKT = DB ? 16 : 32, WAVES_CO = 2, WAVES_M = 2;
     constexpr int WCO = BN / WAVES_CO, WM = BM / WAVES_M;
     constexpr int NCO = WCO / 32, NM = WM / 32;
     constexpr int AP = BM + 4;
@@ -1225,8 +1225,8 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_kernel(const GroupTable 
     constexpr int KSB = 256 / BN;
     static_assert(NCO == 1 && NM >= 1 && LA >= 1 && LBV >= 1, "tile");
 
-    __shared__ __attribute__((aligned(16))) float As[3 * BKT * AP];      // [dx][k][voxel]
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[(DB ? 2 : 1) * 3 * BKT * AP];      // [dx][k][voxel]
+    __shared__ __attribute__((aligned(16))) float Bs[(DB ? 2 : 1) * 3 * BKT * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1278,6 +1278,95 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_kernel(const GroupTable 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    if constexpr (DB) {
+        // ---- double-buffered form (see conv_igemm_strip3_kernel): 16-channel rounds, two LDS stages and register sets, one barrier
+        // per round; the loads of round q + 2 sit between the first MFMAs of round q, the LDS writes of round q + 1 between its last
+        static_assert(BM == 64 && NM == 1 && LA == 4 && LBV == 1, "double-buffered form: 64 x 64 x 16 tiles");
+        constexpr int ASZ = 3 * BKT * AP, BSZ = 3 * BKT * BN;
+        constexpr int NSLOT = 3 * (BKT / 2);          // 24 MFMAs per round
+        constexpr int NLD = 2 * LA + 3 * LBV;         // 11 loads: 4 x (8 + 4 bytes) of r~, 3 x 16 bytes of weights
+        constexpr int NST = 3 * LA + 3 * LBV;         // 15 LDS writes
+        const int ncb = Cin / BKT;
+        const int nrounds = nrow * ncb;
+        const int rps = (nrounds + nsplit - 1) / nsplit;
+        const int q0 = blockIdx.z * rps;
+        int q1 = q0 + rps;
+        if (q1 > nrounds) q1 = nrounds;
+        float2 ra2[2][LA];
+        float ra1[2][LA];
+        float4 rb2[2][3 * LBV];
+        uint32_t l_vo[2] = {0u, 0u};
+        int l_sx[2] = {0, 0}, l_sw[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        auto prep = [&](int st, int q) {
+            const int qq = q < q1 ? q : q1 - 1;
+            const int r_cur = qq / ncb, cb = qq - r_cur * ncb;
+            const int c0 = cb * BKT;
+            l_vo[st] = xoff + (uint32_t)__builtin_amdgcn_readlane(tab_roff, r_cur);
+            l_sx[st] = c0 * Vp * 4;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) l_sw[st][d] = (__builtin_amdgcn_readlane(tab_widx, r_cur * 3 + d) * Cin + c0) * Cout * 4;
+        };
+        auto load_item = [&](int st, int i) {
+            if (i < LA) ra2[st][i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rx, l_vo[st], l_sx[st] + i * (KSA * 4) * Vp, 0));
+            else if (i < 2 * LA) ra1[st][i - LA] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, l_vo[st] + 8u, l_sx[st] + (i - LA) * (KSA * 4) * Vp, 0));
+            else if (i < NLD) {
+                const int d = i - 2 * LA;
+                rb2[st][d] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, l_sw[st][d], 0));
+            }
+        };
+        auto stage_item = [&](int st, float* A, float* B, int i) {
+            if (i < 3 * LA) {
+                const int j = i / 3, d = i - j * 3;
+                A[d * (BKT * AP) + (ka_l + j * KSA) * AP + ma_l] = d == 0 ? ra2[st][j].x : (d == 1 ? ra2[st][j].y : ra1[st][j]);
+            } else if (i < NST) {
+                const int d = i - 3 * LA;
+                *reinterpret_cast<float4*>(&B[d * (BKT * BN) + kv_l * BN + cv_l]) = co_ok ? rb2[st][d] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto round = [&](auto CUR, int q) {
+            constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+            prep(cur, q + 2);
+            const float* Ab = As + cur * ASZ + wm * WM + l31;
+            const float* Bb = Bs + cur * BSZ + wco * WCO + l31;
+            float* An = As + nxt * ASZ;
+            float* Bn = Bs + nxt * BSZ;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                    const int krow = k2 * 2 + hi, slot = d * (BKT / 2) + k2;
+                    const float a = Bb[d * (BKT * BN) + krow * BN];
+                    const float b = Ab[d * (BKT * AP) + krow * AP];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+                    if (2 * slot < NLD) load_item(cur, 2 * slot);
+                    if (2 * slot + 1 < NLD) load_item(cur, 2 * slot + 1);
+                    if (slot >= NSLOT - NST) stage_item(nxt, An, Bn, slot - (NSLOT - NST));
+                    if (slot == (NLD + 1) / 2 - 1 || slot == NSLOT - NST - 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        };
+        if (q0 < q1) {
+            prep(0, q0);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) load_item(0, i);
+            prep(1, q0 + 1);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) load_item(1, i);
+#pragma unroll
+            for (int i = 0; i < NST; ++i) stage_item(0, As, Bs, i);
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
+        for (int q = q0; q < q1; q += 2) {
+            round(std::integral_constant<int, 0>{}, q);
+            if (q + 1 < q1) round(std::integral_constant<int, 1>{}, q + 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        f32x16 (&accd)[1][NM] = reinterpret_cast<f32x16 (&)[1][NM]>(acc);
+        igemm_epilogue<1, NM, WCO, WM>(accd, tab, gi, gd, bias, slab, Cout, flags, nsplit, m0, co0, M, DHWn, wm, wco, l31, hi);
+        return;
+    }
     float2 ra2[LA];
     float ra1[LA];
     float rb[VECB ? 1 : 3 * LB];
@@ -1375,10 +1464,11 @@ __global__ __launch_bounds__(256, 3) void conv_pool_fwd_kernel(const GroupTable 
 // Members: x = dL/dy [N, K, D', H', W'], y = the 8 planes, (D, H, W) full-resolution extents, dstride = tmode;
 // widx[f] = packed slot (mode 1: [K][C]) holding forward tap f's matrix, f = ((dz+1)*3 + dy+1)*3 + dx+1.
 // ------------------------------------------------------------------------------------------------
+template <bool DB>
 __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTable tab, const float* __restrict__ wp,
                                                                  const int K, const int C) {
     constexpr bool VECB = true;             // (host: C % 4 == 0)
-    constexpr int BM = 64, BN = 64, BKT = 32, WAVES_CO = 2;
+    constexpr int BM = 64, BN = 64, BKT = DB ? 16 : 32, WAVES_CO = 2;
     constexpr int WCO = 32, WM = 32;
     constexpr int AP = BM + 4;              // [left halo][BM voxels][pad][zero column]
     constexpr int LA = BKT * BM / 256;
@@ -1388,8 +1478,8 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     constexpr int LB = BKT * BN / 256;
     constexpr int KSB = 256 / BN;
 
-    __shared__ __attribute__((aligned(16))) float As[BKT * AP];
-    __shared__ __attribute__((aligned(16))) float Bs[3 * BKT * BN];
+    __shared__ __attribute__((aligned(16))) float As[(DB ? 2 : 1) * BKT * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[(DB ? 2 : 1) * 3 * BKT * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1499,6 +1589,91 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
     for (int r = 0; r < 4; ++r)
         if (r < nrow && ((rows_live >> r) & 1u)) { row_of |= (uint32_t)r << (8 * nlive_rows); ++nlive_rows; }
     const int nrounds = cbn > 0 ? nlive_rows * cbn : 0;
+    if constexpr (DB) {
+        // ---- double-buffered form (see conv_igemm_strip3_kernel): 16-channel rounds, one barrier per round; a round = 8 k-pairs of
+        // three MFMAs; the loads of round q + 2 sit behind the first four, the LDS writes of round q + 1 behind the last four
+        static_assert(LA == 4 && LBV == 1, "double-buffered form: 64 x 64 x 16 tiles");
+        constexpr int ASZ = BKT * AP, BSZ = 3 * BKT * BN;
+        constexpr int NI = LA + 1 + 3;                // loads / LDS writes per thread and round
+        float ra2[2][LA], rah2[2] = {0.f, 0.f};
+        float4 rb2[2][3];
+        bool pav[2] = {false, false}, phv[2] = {false, false};
+        uint32_t l_vo[2] = {0u, 0u}, l_vh[2] = {0u, 0u};
+        int l_sx[2] = {0, 0}, l_sw[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        const int halo_col = halo_thread ? 0 : BM + 2;         // (threads without a halo element store a zero into the pad column)
+        auto prep = [&](int st, int q) {
+            const int qq = q < nrounds ? q : nrounds - 1;
+            const int r_i = qq / cbn, cb = cb0 + (qq - r_i * cbn);
+            const int r_cur = (int)((row_of >> (8 * r_i)) & 0xffu);
+            const int c0 = cb * BKT;
+            const int rz = r_cur / ndy, ry = r_cur - rz * ndy;
+            const int dz = (tm && ct == 0) ? 2 * rz - 1 : 0, dy = cy == 0 ? 2 * ry - 1 : 0;
+            const int st_ = dz > 0 ? -1 : 0, sy = dy > 0 ? -1 : 0;
+            l_sx[st] = c0 * Vn * 4;
+            {
+                const int at = s_at + st_, a = s_a + sy;
+                pav[st] = (unsigned)at < (unsigned)Dn && (unsigned)a < (unsigned)Hn && s_b < Wn;
+                l_vo[st] = pav[st] ? ((s_n * (uint32_t)K + (uint32_t)ka_l) * (uint32_t)Vn + (uint32_t)((at * Hn + a) * Wn + s_b)) * 4u : 0u;
+            }
+            {
+                const int at = h_at + st_, a = h_a + sy;
+                phv[st] = halo_thread && (unsigned)at < (unsigned)Dn && (unsigned)a < (unsigned)Hn && h_b < Wn;
+                l_vh[st] = phv[st] ? ((h_n * (uint32_t)K + (uint32_t)hk) * (uint32_t)Vn + (uint32_t)((at * Hn + a) * Wn + h_b)) * 4u : 0u;
+            }
+            const int f0 = ((dz + 1) * 3 + dy + 1) * 3;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) l_sw[st][d] = (__builtin_amdgcn_readlane(tab_widx, f0 + d) * K + c0) * C * 4;
+        };
+        auto load_item = [&](int st, int i) {
+            if (i < LA) ra2[st][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, l_vo[st], l_sx[st] + i * (KSA * 4) * Vn, 0));
+            else if (i == LA) rah2[st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, l_vh[st], l_sx[st], 0));
+            else if (i < NI) rb2[st][i - LA - 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff, l_sw[st][i - LA - 1], 0));
+        };
+        auto stage_item = [&](int st, float* A, float* B, int i) {
+            if (i < LA) A[(ka_l + i * KSA) * AP + 1 + ma_l] = pav[st] ? ra2[st][i] : 0.f;
+            else if (i == LA) A[(tid % BKT) * AP + halo_col] = phv[st] ? rah2[st] : 0.f;
+            else if (i < NI) *reinterpret_cast<float4*>(&B[(i - LA - 1) * (BKT * BN) + kv_l * BN + cv_l]) = co_ok ? rb2[st][i - LA - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto round = [&](auto CUR, int q) {
+            constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+            prep(cur, q + 2);
+            const float* a_own = As + cur * ASZ + 1 + wm * WM + l31;
+            const float* a_left = can_l[0] ? As + cur * ASZ + wm * WM + l31 : As + cur * ASZ + (BM + 3);
+            const float* bb = Bs + cur * BSZ + wco * WCO + l31;
+            float* An = As + nxt * ASZ;
+            float* Bn = Bs + nxt * BSZ;
+#pragma unroll
+            for (int k2 = 0; k2 < BKT / 2; ++k2) {
+                const int krow = k2 * 2 + hi;
+                const float xo = a_own[krow * AP], xl = a_left[krow * AP];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[krow * BN], xo, acc0, 0, 0, 0);                      // dx = -1: source b
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[BKT * BN + krow * BN], xo, acc1, 0, 0, 0);           // dx =  0: source b
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[2 * BKT * BN + krow * BN], xl, acc0, 0, 0, 0);       // dx = +1: source b - 1
+                if (k2 < 4) { load_item(cur, 2 * k2); load_item(cur, 2 * k2 + 1); }
+                else { stage_item(nxt, An, Bn, 2 * (k2 - 4)); stage_item(nxt, An, Bn, 2 * (k2 - 4) + 1); }
+                if (k2 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        if (tid < BKT) { As[tid * AP + BM + 3] = 0.f; As[ASZ + tid * AP + BM + 3] = 0.f; }
+        if (nrounds > 0) {
+            prep(0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) load_item(0, i);
+            prep(1, 1);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) load_item(1, i);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) stage_item(0, As, Bs, i);
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
+        for (int q = 0; q < nrounds; q += 2) {
+            round(std::integral_constant<int, 0>{}, q);
+            if (q + 1 < nrounds) round(std::integral_constant<int, 1>{}, q + 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
     bool pend_av = false, pend_hv = false;
 
     auto load_round = [&](int q) {
@@ -1580,6 +1755,7 @@ __global__ __launch_bounds__(256, 3) void conv_pool_dgrad_kernel(const GroupTabl
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
+    }
     }
     // ---- epilogue: rows (registers) = channel, columns (lanes) = grid voxel; two class planes
     // Entries nobody reads are not written: an odd-parity class only lives on the first D' / H' / W' grid positions of its axis (its
@@ -4725,6 +4901,9 @@ extern "C" int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int 
         int32_t plan_[8] = {9, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
         ProfScope::set_plan(plan_, 8);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
+        static const bool pool_db = env_long("T2V_POOL_FWD_DB", 1) != 0;          // the double-buffered form (16-channel rounds); 0: single-stage
+        if (pool_db) T2V_LAUNCH_PROF((conv_pool_fwd_kernel<64, true>), grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
+        else
         T2V_LAUNCH_PROF(conv_pool_fwd_kernel<64>, grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
     }
     int st = launch_status();
@@ -4803,7 +4982,9 @@ extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, in
     int32_t plan_[8] = {10, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
     ProfScope::set_plan(plan_, 8);
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)(4 * ((C + 63) / 64)), (unsigned)p.S);
-    T2V_LAUNCH_PROF(conv_pool_dgrad_kernel, grid, dim3(256), 0, s, tab, wp, K, C);
+    static const bool dgrad_db = env_long("T2V_POOL_DGRAD_DB", 0) != 0;          // the double-buffered form (16-channel rounds)
+    if (dgrad_db) T2V_LAUNCH_PROF(conv_pool_dgrad_kernel<true>, grid, dim3(256), 0, s, tab, wp, K, C);
+    else T2V_LAUNCH_PROF(conv_pool_dgrad_kernel<false>, grid, dim3(256), 0, s, tab, wp, K, C);
     return launch_status();
 }
 
