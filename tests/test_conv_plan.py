@@ -83,13 +83,13 @@ def test_pooled_convolution_plans():
     from txt2vid_amd._lib import lib, ConvGroup
     name, cin, cout, members, stem = cc.POOL_CASES[0]
     assert sum(n * d * h * w for n, d, h, w in members) == 393216
-    assert cc.pool_plan(0, members, cin, cout, stem) == ('pool_fwd', 64, 64, 32, 1, 1, 1, 1)
+    assert cc.pool_plan(0, members, cin, cout, stem) == ('pool_fwd', 64, 64, 16, 1, 1, 2, 1)          # (the double-buffered form: 16-channel rounds)
     assert cc.pool_plan(1, members, cout, cin, stem)[0] == 'pool_dgrad'
     w = cc.pool_plan(2, members, cin, cout, stem)
     assert w[0] == 'pool_rows3' and 900 <= w[5] <= 1024                    # one round of weight-gradient workgroups
     assert cc.pool_plan(0, cc.POOL_CASES[1][3], 64, 128, False)[7] > 1     # down0: 112 tiles x 2 -> split-K
     fwd, wg = cc.all_checked_pool_variants()
-    assert set(fwd) == {('pool_fwd', 64, 64, 32, 1, 1, 1), ('pool_dgrad', 64, 64, 32, 1, 1, 1)}
+    assert set(fwd) == {('pool_fwd', 64, 64, 16, 1, 1, 2), ('pool_dgrad', 64, 64, 32, 1, 1, 1)}
     assert set(wg) == {('pool_rows3', 'reduce'), ('pool_rows3', 'reduce_small')}
     out = (C.c_int32 * 8)()
     arr = (ConvGroup * 1)()

@@ -4874,6 +4874,10 @@ static bool build_pool_fwd(const t2v_conv_group* groups, int ngroups, int Cin, i
     p.S = (int)S;
     return true;
 }
+// the double-buffered forms of the pooled GEMMs (16-channel rounds, one barrier per round; see conv_igemm_strip3_kernel): the forward
+// takes it by default (-8 %), the data gradient does not (+3 % on its 2-8 round loops). Plan queries report K chunk 16, KS 2 for them.
+static bool pool_fwd_db() { static const bool v = env_long("T2V_POOL_FWD_DB", 1) != 0; return v; }
+static bool pool_dgrad_db() { static const bool v = env_long("T2V_POOL_DGRAD_DB", 0) != 0; return v; }
 extern "C" int64_t t2v_pool_conv_fwd_ws_floats(const t2v_conv_group* groups, int ngroups, int Cin, int Cout) {
     GroupTable tab;
     PoolPlan p;
@@ -4898,11 +4902,10 @@ extern "C" int t2v_pool_conv_fwd(const t2v_conv_group* groups, int ngroups, int 
     }
     {
         ProfScope prof(0, flops, s, Mtot, Cin, Cout, taps, ngroups, p.S);
-        int32_t plan_[8] = {9, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
+        int32_t plan_[8] = {9, 64, 64, pool_fwd_db() ? 16 : 32, 1, p.vecb ? 1 : 0, pool_fwd_db() ? 2 : 1, p.S};
         ProfScope::set_plan(plan_, 8);
         dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)((Cout + 63) / 64), (unsigned)p.S);
-        static const bool pool_db = env_long("T2V_POOL_FWD_DB", 1) != 0;          // the double-buffered form (16-channel rounds); 0: single-stage
-        if (pool_db) T2V_LAUNCH_PROF((conv_pool_fwd_kernel<64, true>), grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
+        if (pool_fwd_db()) T2V_LAUNCH_PROF((conv_pool_fwd_kernel<64, true>), grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
         else
         T2V_LAUNCH_PROF(conv_pool_fwd_kernel<64>, grid, dim3(256), 0, s, tab, wp, bias, ws, Cin, Cout, flags, p.S);
     }
@@ -4979,11 +4982,10 @@ extern "C" int t2v_pool_conv_dgrad(const t2v_conv_group* groups, int ngroups, in
         Mtot += (long)groups[i].N * pool_grid(groups[i]);
     }
     ProfScope prof(0, flops, s, Mtot, K, C, 27, ngroups, p.S);
-    int32_t plan_[8] = {10, 64, 64, 32, 1, p.vecb ? 1 : 0, 1, p.S};
+    int32_t plan_[8] = {10, 64, 64, pool_dgrad_db() ? 16 : 32, 1, p.vecb ? 1 : 0, pool_dgrad_db() ? 2 : 1, p.S};
     ProfScope::set_plan(plan_, 8);
     dim3 grid((unsigned)tab.tile_start[tab.n], (unsigned)(4 * ((C + 63) / 64)), (unsigned)p.S);
-    static const bool dgrad_db = env_long("T2V_POOL_DGRAD_DB", 0) != 0;          // the double-buffered form (16-channel rounds)
-    if (dgrad_db) T2V_LAUNCH_PROF(conv_pool_dgrad_kernel<true>, grid, dim3(256), 0, s, tab, wp, K, C);
+    if (pool_dgrad_db()) T2V_LAUNCH_PROF(conv_pool_dgrad_kernel<true>, grid, dim3(256), 0, s, tab, wp, K, C);
     else T2V_LAUNCH_PROF(conv_pool_dgrad_kernel<false>, grid, dim3(256), 0, s, tab, wp, K, C);
     return launch_status();
 }
@@ -5107,7 +5109,8 @@ extern "C" int t2v_pool_conv_plan(int what, const t2v_conv_group* groups, int ng
         PoolPlan p;
         if (!(what == 0 ? build_pool_fwd(groups, ngroups, Cin, Cout, false, tab, p) : build_pool_dgrad(groups, ngroups, Cin, Cout, false, tab, p)))
             return T2V_EINVAL;
-        out[0] = what == 0 ? 9 : 10; out[1] = 64; out[2] = 64; out[3] = 32; out[4] = 1; out[5] = p.vecb ? 1 : 0; out[6] = 1; out[7] = p.S;
+        const bool db = what == 0 ? pool_fwd_db() : pool_dgrad_db();
+        out[0] = what == 0 ? 9 : 10; out[1] = 64; out[2] = 64; out[3] = db ? 16 : 32; out[4] = 1; out[5] = p.vecb ? 1 : 0; out[6] = db ? 2 : 1; out[7] = p.S;
         return T2V_OK;
     }
     if (what == 2) {
