@@ -12,6 +12,7 @@ cp $O/trace/*/*_kernel_stats.csv $O/r04_kernel_stats.csv 2>/dev/null
 python3 $R/tools/prof_summary.py $O/trace > $O/r04_kernel_trace_summary.txt 2>&1
 ms=$(grep -o '"ms_per_step": [0-9.]*' $O/trace.log | head -1 | cut -d' ' -f2)
 python3 $R/tools/gap_analysis.py $O/trace $ms > $O/r04_replay_timeline.txt 2>&1
+python3 $R/tools/phase_times.py $O/trace $ms > $O/r04_phase_times.txt 2>&1
 rm -rf $O/trace
 [ "$1" = "quick" ] && exit $rc
 cd $R
