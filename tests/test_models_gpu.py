@@ -1034,3 +1034,24 @@ def test_graphed_sentence_encoder_matches_eager():
             got = ge.encode(tokens.to(DEV), lengths).cpu()
             np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=0)
     assert all(e[2] is not None for e in ge.entries.values()) and len(ge.entries) == 2
+
+
+def test_static_draws_stage_through_a_ring_of_pinned_buffers():
+    """`StaticDraws.begin_step` uploads an iteration's host draws asynchronously while the training loop runs the host ahead of
+    the GPU: consecutive iterations must stage through DIFFERENT pinned buffers (a single one would be rewritten before its copy
+    has executed), and a slot comes back only after the copy that read it is done."""
+    from txt2vid_amd.draws import StaticDraws
+    sd = StaticDraws(DEV, batch=4, latent=16, n_levels=4, n_gen_phases=3, gp=True, subsample_input=True, n_perms=2)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    seen = []
+    for i in range(2 * sd.RING + 1):
+        sd.begin_step()
+        seen.append((sd.h_all, sd.h_all.clone()))
+        if i:
+            assert sd.h_all is not seen[i - 1][0]                       # the previous iteration's staging buffer is left alone
+            assert torch.equal(seen[i - 1][0], seen[i - 1][1]) or i >= sd.RING
+    torch.cuda.synchronize()
+    assert torch.equal(sd.d_all.cpu(), seen[-1][1])                      # the device holds the LAST iteration's draws
+    assert len({id(h) for h, _ in seen}) == sd.RING
+    assert not torch.equal(seen[-1][1], seen[-2][1])                     # (fresh draws every iteration)

@@ -49,7 +49,14 @@ class StaticDraws(object):
         # float32 z | float32 alphas | int32 caption permutations): ONE H2D copy node per replayed iteration instead of four
         # (a copy node costs ~20 us of idle time in the replayed graph)
         n_int, n_z, n_a, n_p = n_levels + n_gen_phases, batch * latent, sum(self.bs), max(1, n_perms) * batch
-        self.h_all = torch.zeros(n_int + n_z + n_a + n_p, dtype=torch.int32).pin_memory()
+        # The staging side is a RING of pinned buffers: the upload is asynchronous and the training loop runs the host ahead of
+        # the GPU (losses are read one iteration late), so a single staging buffer would be rewritten with iteration i + 1's draws
+        # before the copy of iteration i has executed. A slot is reused only after the event behind its last copy has completed.
+        self.RING = 4
+        self.h_ring = [torch.zeros(n_int + n_z + n_a + n_p, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+        self.h_events = [None] * self.RING
+        self._slot = 0
+        self.h_all = self.h_ring[0]
         self.d_all = self.h_all.to(device)               # (zeros by copy: a memcpy, no fill kernel)
 
         def carve(buf):
@@ -59,6 +66,7 @@ class StaticDraws(object):
             a_ = buf[o:o + n_a].view(torch.float32); o += n_a
             p_ = buf[o:o + n_p].view(max(1, n_perms), batch)
             return i_, z_, a_, p_
+        self._carve = carve
         self.h_int, self.h_z, self.h_a, self.h_perm = carve(self.h_all)
         self.d_int, self.d_z, self.d_a, self.d_perm = carve(self.d_all)
         self._i = self._a = 0
@@ -66,6 +74,12 @@ class StaticDraws(object):
     def begin_step(self):
         """All host draws of one iteration, reference order: n_levels Subsample phases, z, the generator's
         phases, the GP alphas per level; then one small H2D copy on the current stream."""
+        slot = self._slot
+        self._slot = (slot + 1) % self.RING
+        if self.h_events[slot] is not None:
+            self.h_events[slot].synchronize()            # (the copy that last read this slot is done; normally long ago)
+        self.h_all = self.h_ring[slot]
+        self.h_int, self.h_z, self.h_a, self.h_perm = self._carve(self.h_all)
         t0, st = 0, 1
         for l in range(self.n_levels):
             self.h_int[l] = t0
@@ -85,6 +99,10 @@ class StaticDraws(object):
             for k in range(self.n_perms):
                 self.h_perm[k].copy_(torch.from_numpy(gen_perm(self.batch).astype('int32')))
         self.d_all.copy_(self.h_all, non_blocking=True)
+        if self.d_all.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.h_events[slot] = ev
         self._i = self._a = self._p = 0
 
     def multiscale_t0(self, n):
