@@ -165,6 +165,9 @@ def train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=Fa
     return TrainStep(gan, optD, optG, losses, params, device, end2end, grad_sync).run(x, cond)
 
 
+_X_BY_MEMCPY = os.environ.get('T2V_DRAWS_MEMCPY') is not None
+
+
 class GraphedTrainStep(object):
     """HIP-graph replay of the training iteration (unconditional path): after `warmup` eager iterations
     the three parts of `TrainStep` are captured once (shared memory pool) and every later iteration is
@@ -258,7 +261,10 @@ class GraphedTrainStep(object):
         old = TF.draws
         TF.set_draws(self.draws)
         try:
-            self.x.copy_(x, non_blocking=True)
+            if x.is_cuda and x.dtype == torch.float32 and x.shape == self.x.shape and not _X_BY_MEMCPY:
+                TF.copy_into(x, self.x)                  # (a copy kernel: stays on the compute queue in front of the graph, see StaticDraws.begin_step)
+            else:
+                self.x.copy_(x, non_blocking=True)
             if self.cond is not None:
                 TF.copy_into(cond.detach(), self.cond)
             self.draws.begin_step()
@@ -431,9 +437,13 @@ def train(gan=None, num_epoch=None, dataset=None, device=None, optD=None, optG=N
                 if loss_ring is None:
                     loss_ring = [(torch.empty(2, device=lD.device), torch.empty(2).pin_memory(), torch.cuda.Event()) for _ in range(2)]
                 dbuf, hbuf, ev = loss_ring[iteration & 1]
-                TF.copy_into(lD.reshape(1), dbuf[0:1])
-                TF.copy_into(lG.reshape(1), dbuf[1:2])
-                hbuf.copy_(dbuf, non_blocking=True)
+                if _X_BY_MEMCPY:
+                    TF.copy_into(lD.reshape(1), dbuf[0:1])
+                    TF.copy_into(lG.reshape(1), dbuf[1:2])
+                    hbuf.copy_(dbuf, non_blocking=True)
+                else:                                    # copy kernels writing the pinned buffer in place: no copy-engine hop behind the graph
+                    TF._copy2d(lD.reshape(1), 0, 1, hbuf, 0, 1, 1, 1)
+                    TF._copy2d(lG.reshape(1), 0, 1, hbuf, 1, 1, 1, 1)
                 ev.record()
                 if pending is not None:
                     pending[1].synchronize()
