@@ -93,6 +93,7 @@ GROUPED_CASES = [
     ('down1_conv2_B32_8members', 128, 256, (3, 3, 3), d_step_members(32, 2), True),  # M=7680 (ragged T), 128->256
     ('small_ragged_group', 64, 64, (3, 3, 3), [(4, 2, 16, 16), (2, 4, 8, 8), (1, 1, 5, 3)], False),
     ('one_voxel_wide_member', 64, 64, (3, 3, 3), [(2, 4, 8, 8), (3, 4, 6, 1)], False),    # a W = 1 member (no dx taps): the single-stage strip3 form
+    ('one_voxel_wide_member_256', 64, 64, (3, 3, 3), [(8, 8, 64, 32), (2, 8, 8, 1)], False),   # ... of the 256-voxel tile (513 tiles)
     ('stem_conv1_B32_8members', 1, 64, (3, 3, 3), d_step_members(32, 0), False),      # M=393216, Cin=1: stem kernels, streaming weight gradient
 ]
 

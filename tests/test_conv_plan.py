@@ -12,8 +12,8 @@ def test_benchmark_shapes_select_the_big_tile_paths():
     name, cin, cout, k, members, _ = cc.GROUPED_CASES[0]
     assert name == 'stem_conv2_B32_8members'
     assert sum(n * d * h * w for n, d, h, w in members) == 393216
-    assert cc.fwd_plan(members, cin, cout, k) == ('strip3', 256, 64, 16, 1, 1, 1, 1)         # conv_igemm_strip3_kernel<256,16,1,true>
-    assert cc.fwd_plan(members, cout, cin, k) == ('strip3', 256, 64, 16, 1, 1, 1, 1)         # its data gradient
+    assert cc.fwd_plan(members, cin, cout, k) == ('strip3', 256, 64, 16, 1, 1, 2, 1)         # conv_igemm_strip3_kernel<256,16,1,true,true> (double-buffered)
+    assert cc.fwd_plan(members, cout, cin, k) == ('strip3', 256, 64, 16, 1, 1, 2, 1)         # its data gradient
     w = cc.wgrad_plan(members, cin, cout, k)
     assert w[0] == 'rows3' and w[4] == 'reduce_small' and w[1] >= 16                          # conv_wgrad3_kernel, many-splits reduce
     # the gradient-penalty members alone (M = 131072) still fill 512 tiles of 256 voxels
@@ -37,6 +37,7 @@ for bm, bn, bk in _TILES:
         elif bk == 32 or bm == 256:
             ALL_FWD.add(('strip', bm, bn, bk, 1, vecb, 1))                   # conv_igemm_strip_kernel<...,VECB,1>
 ALL_FWD.add(('strip3', 64, 64, 16, 1, 1, 2))                                 # strip3<64>'s double-buffered form (every member three taps wide)
+ALL_FWD.add(('strip3', 256, 64, 16, 1, 1, 2))                                # ... and strip3<256>'s
 for bm, bn in ((128, 32), (128, 64), (64, 64)):
     ALL_FWD.add(('igemm', bm, bn, 16, 0, 0, 1))                              # generic-K: conv_igemm_kernel<BM,BN,*,16,false,false>
 ALL_FWD |= {('stem', 256, 1, 0, 0, 0, 0), ('stem', 256, 3, 0, 0, 0, 0),          # conv_stem_kernel<1 / 3>: the clips' first convolution

@@ -952,10 +952,12 @@ __global__ __launch_bounds__(256, ((BM == 256 || (DB && BKT == 32)) ? 2 : (DB ? 
         // (the single-stage form above runs stage -> barrier -> load issue -> MFMAs -> barrier and relies on the other workgroups
         // of the CU to cover a wave's staging; profiles/r04_strip3_stamps.txt: 3.1 k of a round's 11.6 k cycles are its MFMAs).
         // The body is branch-free: past the last round it re-loads / re-stages the last round's data into the stage nobody reads.
-        static_assert(BM == 64 && (BKT == 32 || BKT == 16) && VECB && NCO == 1 && NM == 1, "double-buffered form: 64 x 64 x {32, 16} tiles");
+        static_assert(((BM == 64 && (BKT == 32 || BKT == 16)) || (BM == 256 && BKT == 16)) && VECB, "double-buffered form: 64 x 64 x {32, 16} and 256 x 64 x 16 tiles");
         constexpr int ASZ = BKT * AP, BSZ = 3 * BKT * BN;
-        constexpr int NI = LA + 1 + 3 * LBV;         // loads (and LDS writes) per thread and round: 15 / 8
-        constexpr int HS = (NI + 1) & ~1;            // first slot of the LDS writes: 16 / 8
+        constexpr int NI = LA + 1 + 3 * LBV;         // loads (and LDS writes) per thread and round: 15 / 8 / 20
+        constexpr int NSLOT = 3 * (BKT / 2);         // k-pair slots per round (NCO x NM MFMAs each): 48 / 24 / 24
+        constexpr int IPS = (2 * NI + NSLOT - 1) / NSLOT;      // items per slot: 1 / 1 / 2
+        constexpr int HS = (NI + IPS - 1) / IPS;     // slots that carry loads (and, at the other end of the round, LDS writes)
         const int ncb = Cin / BKT;
         const int nrounds = nrow * ncb;
         const int rps = (nrounds + nsplit - 1) / nsplit;
@@ -1001,12 +1003,14 @@ __global__ __launch_bounds__(256, ((BM == 256 || (DB && BKT == 32)) ? 2 : (DB ? 
                 *reinterpret_cast<float4*>(&B[d * (BKT * BN) + (kv_l + j * KSBV) * BN + cv_l]) = co_ok ? rb2[st][e] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        const float* a_tap[3];
+        const float* a_tap[3][NM];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const bool keep = d == 0 ? can_l[0] : (d == 2 ? can_r[0] : true);
-            a_tap[d] = keep ? As + d + wm * WM + l31 : As + (BM + 3);          // (1 + dx, dx = d - 1)
-        }
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const bool keep = d == 0 ? can_l[j] : (d == 2 ? can_r[j] : true);
+                a_tap[d][j] = keep ? As + d + wm * WM + j * 32 + l31 : As + (BM + 3);          // (1 + dx, dx = d - 1)
+            }
         // one round: MFMAs on stage `cur`; loads of round q + 2 into register set `cur`, LDS writes of set `cur ^ 1` (round q + 1)
         // into stage `cur ^ 1`
         auto round = [&](auto CUR, int q) {
@@ -1021,12 +1025,21 @@ __global__ __launch_bounds__(256, ((BM == 256 || (DB && BKT == 32)) ? 2 : (DB ? 
 #pragma unroll
                 for (int k2 = 0; k2 < BKT / 2; ++k2) {
                     const int krow = k2 * 2 + hi, slot = d * (BKT / 2) + k2;
-                    const float a = Bb[d * (BKT * BN) + krow * BN];
-                    const float b = (a_tap[d] + cur * ASZ)[krow * AP];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0][0], 0, 0, 0);
-                    constexpr int SS = DB_STAGE_LATE ? 3 * (BKT / 2) - HS : HS;        // first slot of the LDS writes
-                    if (slot < HS) load_item(cur, slot);
-                    else if (slot >= SS && slot < SS + HS) stage_item(nxt, An, Bn, slot - SS);
+                    float a[NCO], b[NM];
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i) a[i] = Bb[d * (BKT * BN) + krow * BN + i * 32];
+#pragma unroll
+                    for (int j = 0; j < NM; ++j) b[j] = (a_tap[d][j] + cur * ASZ)[krow * AP];
+#pragma unroll
+                    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+                        for (int j = 0; j < NM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    constexpr int SS = DB_STAGE_LATE ? NSLOT - HS : HS;        // first slot of the LDS writes
+#pragma unroll
+                    for (int e = 0; e < IPS; ++e) {
+                        if (slot < HS) load_item(cur, slot * IPS + e);
+                        else if (slot >= SS && slot < SS + HS) stage_item(nxt, An, Bn, (slot - SS) * IPS + e);
+                    }
                     // (hipcc otherwise sinks the loads to the end of the round and hoists the LDS writes to its start: the data
                     //  would be waited for right after it was requested)
                     if (slot == HS - 1 || slot == SS - 1 || slot == SS + HS - 1) __builtin_amdgcn_sched_barrier(0);
@@ -2761,15 +2774,16 @@ static ConvVariant conv_variant(const GroupTable& tab, const ConvPlan& p, int BM
     return v;
 }
 
-// The double-buffered form of the 64-voxel strip3 tile (conv_igemm_strip3_kernel<64, BKT, 2, true, true>): 0 = not taken, else its
-// channels per round (16: four workgroups per CU; 32: two). Every member must carry all three dx taps and Cout % 4 == 0.
-// T2V_STRIP3_DB overrides (0 / 16 / 32). Shared by the launcher and the plan query (out[3] = channels per round, out[6] = 2).
+// The double-buffered form of the 64- and 256-voxel strip3 tiles (conv_igemm_strip3_kernel<64, BKT, 2, true, true>, <256, 16, 1, true,
+// true>): 0 = not taken, else its channels per round (64 voxels: 16 = four workgroups per CU, 32 = two; 256 voxels: 16). Every member
+// must carry all three dx taps and Cout % 4 == 0. T2V_STRIP3_DB (0 / 16 / 32) and T2V_STRIP3_DB256 (0 / 1) override. Shared by the launcher and the plan query (out[3] = channels per round, out[6] = 2).
 static int strip3_db(const GroupTable& tab, const ConvPlan& p) {
-    static const long db = env_long("T2V_STRIP3_DB", 16);
-    if ((db != 16 && db != 32) || !p.vecb || p.bm != 64 || p.bn != 64) return 0;
+    static const long db = env_long("T2V_STRIP3_DB", 16), db256 = env_long("T2V_STRIP3_DB256", 1);
+    if (!p.vecb || p.bn != 64 || (p.bm != 64 && p.bm != 256)) return 0;
+    if (p.bm == 64 ? (db != 16 && db != 32) : db256 == 0) return 0;
     for (int i = 0; i < tab.n; ++i)
         if (tab.g[i].dx[0] >= 0) return 0;
-    return (int)db;
+    return p.bm == 64 ? (int)db : 16;              // (the 256-voxel tile: 16-channel rounds, two workgroups per CU as before)
 }
 
 // Wave quantisation of the 256-voxel tile: the kernel fits 3 workgroups on a CU but runs no faster per CU with 3 than with 2
@@ -2814,6 +2828,12 @@ static void launch_conv_t(const GroupTable& tab, const float* wp, const float* b
             constexpr int WCO3 = BM == 256 ? 1 : 2;
             const long nwg = (long)grid.x * grid.y * grid.z;
             int pad = 0;
+            if constexpr (BM == 256) {
+                if (strip3_db(tab, p)) {
+                    T2V_LAUNCH_PROF((conv_igemm_strip3_kernel<256, 16, 1, true, true>), grid, dim3(256), 0, s, tab, wp, bias, slab, Cin, Cout, flags, p.S);
+                    return;
+                }
+            }
             if constexpr (BM == 64) {
                 // the double-buffered form (one barrier per round, staging between the MFMAs): every member three taps wide
                 const int db = strip3_db(tab, p);
@@ -2878,7 +2898,7 @@ static void fill_fwd_plan(const t2v_conv_group* groups, int ngroups, int Cin, in
     out[0] = v.s3 ? 5 : (v.strip ? 1 : 0);
     out[1] = p.bm; out[2] = p.bn; out[3] = p.fast ? bk : 16;
     out[4] = p.fast ? 1 : 0; out[5] = (p.fast && p.vecb) ? 1 : 0; out[6] = v.ks; out[7] = p.S;
-    if (v.s3 && bk == 32) {
+    if (v.s3 && (bk == 32 || p.bm == 256)) {
         const int db = strip3_db(tab, p);
         if (db) { out[3] = db; out[6] = 2; }
     }
