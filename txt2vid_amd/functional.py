@@ -3066,8 +3066,9 @@ class ConvMultiG(Function):
                         res = ConvDgradMaskG.apply(ws[k], len(again), *([g_of[k][i] for i in again] + [xs[i] for i in again]))
                     else:
                         res = ConvDgradG.apply(ws[k], *[g_of[k][i] for i in again])
-                    for i, r in zip(again, res):
-                        gxs[i] = Add.apply(gxs[i], r)
+                    # (recorded backward: one grouped add for all members instead of one launch per member)
+                    for i, t in zip(again, AddG.apply(*([gxs[i] for i in again] + list(res)))):
+                        gxs[i] = t
         grads = []
         for k in range(nspec):
             gw = gb = None
