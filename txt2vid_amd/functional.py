@@ -2102,6 +2102,19 @@ def ones_like(t):
     return out
 
 
+_ones = {}
+
+
+def ones_cached(t):
+    """A constant all-ones tensor of t's shape (the roots of the gradient penalty's `autograd.grad`): filled once, never written
+    again, so every later iteration saves the fill launch."""
+    key = (tuple(t.shape), t.device)
+    o = _ones.get(key)
+    if o is None:
+        o = _ones[key] = ones_like(t.detach())
+    return o
+
+
 class ScalarCombine(Function):
     """sum_i w_i * s_i over 0-d device tensors (one kernel; torch.stack(...).mean()/sum() in the reference)."""
 

@@ -604,6 +604,12 @@ class RowBcastG(Function):
         return (None,) + tuple(out)
 
 
+def dot_group(as_, bs):
+    """sum_i <as[i], bs[i]> over n pairs of same-shaped tensors as one 0-d tensor (`DotG`: one launch + its final reduce)."""
+    as_, bs = list(as_), list(bs)
+    return DotG.apply(len(as_), *(as_ + bs))
+
+
 def sum_spatial_group(xs):
     return list(RowSumG.apply(*xs))
 

@@ -2,6 +2,8 @@
 kwargs as txt2vid/gan/cond_gan.py:7-217. Scalar combinations of the per-level losses are done by the
 `scalar_*` kernels, not by ATen."""
 import numpy as np
+import os
+
 import torch
 
 from .. import functional as TF
@@ -135,9 +137,15 @@ class CondGan(object):
                 if c is not None:
                     outs.append(c)
             with TF.input_grads_only():
-                gs = torch.autograd.grad(outputs=outs, inputs=xhs, grad_outputs=[TF.ones_like(o) for o in outs],
+                gs = torch.autograd.grad(outputs=outs, inputs=xhs, grad_outputs=[TF.ones_cached(o) for o in outs],
                                          create_graph=True, retain_graph=True, only_inputs=True)
-            gp = TF.scalar_sum([TF.vec_sum(TF.row_sqnorm(g), self.gp_scale) for g in gs])
+            if _GROUPED_GP and all(g.is_cuda for g in gs) and len(gs) <= 8:
+                # sum over levels and samples of ||dD/dx_hat||^2 as ONE grouped dot product (and one grouped scale + add in its
+                # adjoint) instead of a squared-norm / sum pair per level and their adjoints: the same sum in another order
+                ga, gb = TF.fork_group(list(gs))
+                gp = TF.scalar_sum([TF.dot_group(ga, gb)], weights=[self.gp_scale])
+            else:
+                gp = TF.scalar_sum([TF.vec_sum(TF.row_sqnorm(g), self.gp_scale) for g in gs])
             l = TF.scalar_sum([l, gp], weights=[1.0, gp_lambda])
         return l, fake_pred, real_pred
 
@@ -261,6 +269,9 @@ class CondGan(object):
 
 def _can_batch(real, fake):
     return all(r.is_cuda and r.shape == f.shape for r, f in zip(real, fake))
+
+
+_GROUPED_GP = os.environ.get('T2V_NO_GROUPED_GP') is None
 
 
 def _fusable(discrim, real, fake):
