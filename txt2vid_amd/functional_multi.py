@@ -217,6 +217,50 @@ class HeadRowsG(Function):
         return (None,) + tuple(out)
 
 
+class SplitRowsG(Function):
+    """(xs[i][:ns[i]], xs[i][ns[i]:]) as views for n dense tensors — outputs: the n heads, then the n tails. The adjoint writes
+    both gradients of ALL members into their buffers in one launch (`CatColsG` on the flattened halves) where the per-member
+    form costs two copies each (the [real; fake] logits of every pyramid level in the D step)."""
+
+    @staticmethod
+    def forward(ctx, ns, *xs):
+        xs = [_c(x) for x in xs]
+        ctx.cfg = (tuple(int(n) for n in ns), tuple(tuple(x.shape) for x in xs))
+        ctx.set_materialize_grads(False)
+        return tuple(x[:n] for x, n in zip(xs, ns)) + tuple(x[n:] for x, n in zip(xs, ns))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ns, shapes = ctx.cfg
+        n = len(ns)
+        out = [None] * n
+        both = [i for i in range(n) if gs[i] is not None and gs[n + i] is not None]
+        if both:
+            res = CatColsG.apply(len(both), *([gs[i].reshape(1, -1) for i in both] + [gs[n + i].reshape(1, -1) for i in both]))
+            for i, r in zip(both, res):
+                out[i] = r.view(shapes[i])
+        for i in range(n):
+            if i in both or (gs[i] is None and gs[n + i] is None):
+                continue
+            rows = shapes[i][0]
+            total = 1
+            for d in shapes[i]:
+                total *= d
+            per = total // rows
+            g, off, cnt = (gs[i], 0, ns[i] * per) if gs[i] is not None else (gs[n + i], ns[i] * per, (rows - ns[i]) * per)
+            out[i] = EmbedColsG.apply(((total, off, cnt),), g.reshape(1, -1))[0].view(shapes[i])
+        return (None,) + tuple(out)
+
+
+def split_rows_group(xs, ns):
+    """([x[:n] ...], [x[n:] ...]) with ONE launch in the adjoint for all members (at most 8 per launch)."""
+    xs = list(xs)
+    if not torch.is_grad_enabled() or not any(x.requires_grad for x in xs) or len(xs) > 8:
+        return [x[:n] for x, n in zip(xs, ns)], [x[n:] for x, n in zip(xs, ns)]
+    res = SplitRowsG.apply(tuple(ns), *xs)
+    return list(res[:len(xs)]), list(res[len(xs):])
+
+
 def head_rows_group(xs, ns):
     """[x[:n] for x, n in zip(xs, ns)] with ONE launch in the adjoint for all members (at most 8 per launch)."""
     xs = list(xs)

@@ -109,9 +109,9 @@ class CondGan(object):
         res = discrim(x=rf + xhs, cond=(conds + chs) if (cond and xhs) else conds, xbar=None)
         both, gp_res = res[:n], res[n:]
         b = [r.size(0) for r in real]
-        u_r, u_f = zip(*[TF.split_rows(o[0], b[i]) for i, o in enumerate(both)])
+        u_r, u_f = TF.split_rows_group([o[0] for o in both], b)
         if cond:
-            c_r, c_f = zip(*[TF.split_rows(o[1], b[i]) for i, o in enumerate(both)])
+            c_r, c_f = TF.split_rows_group([o[1] for o in both], b)
             # D(real, mismatched captions): second head on the real half's trunk features
             trunk = discrim.sub_discrims
             shared = trunk[0].module if hasattr(trunk[0], 'module') and not hasattr(trunk[0], 'cond_heads') else trunk[0]
