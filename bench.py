@@ -556,7 +556,10 @@ def main():
         # the north-star's own target line: D forward+backward on un-subsampled 16x64x64 clips
         from txt2vid_amd.util.roofline import d_fwdbwd_roofline
         log('D forward+backward roofline pass')
-        res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
+        try:
+            res['d_fwdbwd_roofline'] = d_fwdbwd_roofline(batch=args.batch, iters=3, device=dev)
+        except Exception as e:                                    # side measurements never take the headline down
+            res['d_fwdbwd_roofline'] = {'error': repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_extra and not args.cond and not bf16 and default_shape:
         log('sampling (eval-mode generator) and the CLI loop')
         try:
@@ -564,10 +567,16 @@ def main():
         except Exception as e:                                    # side measurements never take the headline down
             res['sampling'] = {'error': repr(e)[:300]}
         if not args.eager:
-            res['cli_ms_per_iter'] = cli_record(args.batch)
+            try:
+                res['cli_ms_per_iter'] = cli_record(args.batch)
+            except Exception as e:
+                res['cli_ms_per_iter'] = {'error': repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cond and default_shape:
         log('timing the CPU oracle on %d host threads' % host_threads())
-        res['cpu_baseline'] = cpu_baseline(host_threads())
+        try:
+            res['cpu_baseline'] = cpu_baseline(host_threads())
+        except Exception as e:
+            res['cpu_baseline'] = {'error': repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_extra and not args.cond and not bf16 and default_shape and not args.eager:
         # BASELINE configs[2] (text-conditioned, Bi-LSTM sentence codes, non-local blocks on, bf16 compute) as an EXTRA record of the
         # same line: measured by a child process after this one's timed region, never part of `value`
