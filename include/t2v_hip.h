@@ -230,7 +230,8 @@ int t2v_avgpool3d_bwd(const float* gy, float* gx, int NC, int D, int H, int W, i
    [NC,D,H,W]; only un-padded windows with kernel <= stride (what DownSample produces, layers.py:197-217). */
 typedef struct t2v_pool_job {
     const float* x; const float* x2; float* y;
-    const float* add;    /* fwd only, optional: y = pool(x [+ x2]) + add  (add has y's shape: the stem's skip, resnet3d.py:16-19) */
+    const float* add;    /* optional. fwd: y = pool(x [+ x2]) + add  (add has y's shape: the stem's skip, resnet3d.py:16-19);
+                            bwd: dL/dx = pool^T(dL/dy) + add  (add has dL/dx's shape: the gradient the pooled tensor's OTHER consumer sent) */
     int32_t NC, D, H, W, Do, Ho, Wo;
     int32_t k[3], s[3], p[3];
 } t2v_pool_job;

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_multi_k(const PoolBatch tb)
         const int d_o = d / q.s[0], ho = h / q.s[1], wo = w / q.s[2];
         const bool in = (d - d_o * q.s[0] < q.k[0]) && (h - ho * q.s[1] < q.k[1]) && (w - wo * q.s[2] < q.k[2]) &&
                         d_o < Do && ho < Ho && wo < Wo;
-        q.y[i] = in ? gy[((nc * Do + d_o) * Ho + ho) * (long)Wo + wo] * inv : 0.f;
+        const float v = in ? gy[((nc * Do + d_o) * Ho + ho) * (long)Wo + wo] * inv : 0.f;
+        q.y[i] = q.add ? v + q.add[i] : v;          // (add: dL/dx's other contribution, same shape as dL/dx — a forked block input)
     }
 }
 static int pool_multi(const t2v_pool_job* jobs, int njobs, bool bwd, void* st) {

@@ -1045,6 +1045,65 @@ class AvgPool3dBwdG(Function):
         return (None, None) + tuple(out)
 
 
+class ForkPoolG(Function):
+    """(xs', pool(xs)) for n tensors that feed a second consumer besides the pooling (a DownBlock's input: main path + pooled skip
+    path): outputs the n aliases, then the n pooled tensors (one launch). In the plain backward the adjoint of the pooling ADDS the
+    alias' gradient in its own launch (`t2v_pool_job.add`) — no separate grouped add, one full-resolution tensor less through HBM;
+    the recorded backward (gradient penalty) composes the differentiable pieces."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *xs):
+        xs = [_c(x) for x in xs]
+        in_sps = [tuple(x.shape[2:]) for x in xs]
+        ys = [torch.empty((x.shape[0], x.shape[1], _pool_out(x.shape[2], k[0], s_[0], p[0]), _pool_out(x.shape[3], k[1], s_[1], p[1]),
+                           _pool_out(x.shape[4], k[2], s_[2], p[2])), device=x.device, dtype=torch.float32) for x, (k, s_, p) in zip(xs, cfgs)]
+        check(lib().t2v_avgpool3d_multi(_pool_jobs(xs, None, ys, cfgs, in_sps), len(xs), _stream()), 't2v_avgpool3d_multi')
+        ctx.cfg = (cfgs, in_sps)
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs) + tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cfgs, in_sps = ctx.cfg
+        n = len(cfgs)
+        ga, gp = list(gs[:n]), list(gs[n:])
+        out = list(ga)
+        live = [i for i in range(n) if gp[i] is not None]
+        if live and torch.is_grad_enabled():
+            res = AvgPool3dBwdG.apply(tuple(cfgs[i] for i in live), tuple(in_sps[i] for i in live), *[gp[i] for i in live])
+            both = [k for k, i in enumerate(live) if ga[i] is not None]
+            for k, i in enumerate(live):
+                if ga[i] is None:
+                    out[i] = res[k]
+            if both:
+                for k, t in zip(both, AddG.apply(*([ga[live[k]] for k in both] + [res[k] for k in both]))):
+                    out[live[k]] = t
+        elif live:
+            gpl = [_c(gp[i]) for i in live]
+            adds = [(_c(ga[i]) if ga[i] is not None else None) for i in live]
+            gxs = [torch.empty((g.shape[0], g.shape[1]) + tuple(in_sps[i]), device=g.device, dtype=torch.float32) for g, i in zip(gpl, live)]
+            jobs = _pool_jobs(gpl, None, gxs, [cfgs[i] for i in live], [in_sps[i] for i in live])
+            for a, ad in zip(jobs, adds):
+                a.add = ad.data_ptr() if ad is not None else None
+            check(lib().t2v_avgpool3d_bwd_multi(jobs, len(live), _stream()), 't2v_avgpool3d_bwd_multi')
+            for i, t in zip(live, gxs):
+                out[i] = t
+        return (None,) + tuple(out)
+
+
+def fork_pool_group(xs, cfgs):
+    """(aliases of xs, [pool_i(xs[i])]) with the aliases' gradients summed INSIDE the pooling adjoint's launch. Falls back to a
+    grouped fork + `avg_pool3d_group` for padded / overlapping windows and for tensors that need no gradient."""
+    xs = list(xs)
+    cfgs = tuple((tuple(k), tuple(s_), tuple(p)) for k, s_, p in cfgs)
+    plain = any(any(p) or any(kk > ss for kk, ss in zip(k, s_)) for k, s_, p in cfgs) or len(xs) > 8
+    if plain or not torch.is_grad_enabled() or not all(x.requires_grad for x in xs):
+        xa, xb = fork_group(xs)
+        return xa, avg_pool3d_group(xb, cfgs)
+    res = ForkPoolG.apply(cfgs, *xs)
+    return list(res[:len(xs)]), list(res[len(xs):])
+
+
 def avg_pool3d_group(xs, cfgs, x2s=None, adds=None):
     """cfgs[i] = (k, s, p) per tensor; x2s: pool(xs[i] + x2s[i]); adds: ... + adds[i] (pooled shape). Falls back to
     per-tensor launches for padded / overlapping windows (their adjoint is the general gather kernel)."""

@@ -352,10 +352,10 @@ def down_block_levels(block, xs):
         # included: the mean of a constant); the convolution then runs on an EIGHTH of the voxels, its two adjoints likewise, and
         # the pooling moves C_in channels instead of C_out. The block's input feeds two consumers: a grouped fork sums their
         # gradients in one launch (as in the stem). Only where the block's tensors are big enough for the saved work to show.
-        xa, xb = TF.fork_group(xs)
+        xa, xp = TF.fork_pool_group(xs, cfgs)         # (the pooling adjoint adds the main path's gradient in its own launch)
         hs = TF.conv_group(xa, m[1].weight, m[1].bias, relu_in=True)
         zs = TF.pool_conv_group(hs, m[3].weight, m[3].bias, relu_in=True, stem=False)
-        ss = TF.conv_group(TF.avg_pool3d_group(xb, cfgs), idm[0].weight, idm[0].bias)
+        ss = TF.conv_group(xp, idm[0].weight, idm[0].bias)
         return TF.add_group(zs, ss)
     # main conv1 and the skip conv read the same tensors: one Function, so their data gradients land in one buffer
     hs, ss = TF.conv_multi_group(xs, [(m[1].weight, m[1].bias, True), (idm[0].weight, idm[0].bias, False)])
