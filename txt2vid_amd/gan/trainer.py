@@ -166,6 +166,7 @@ def train_iteration(gan, x, cond, optD, optG, losses, params, device, end2end=Fa
 
 
 _X_BY_MEMCPY = os.environ.get('T2V_DRAWS_MEMCPY') is not None
+_DRAWS_LAST = os.environ.get('T2V_DRAWS_LAST') is not None
 
 
 class GraphedTrainStep(object):
@@ -261,13 +262,16 @@ class GraphedTrainStep(object):
         old = TF.draws
         TF.set_draws(self.draws)
         try:
+            if not _DRAWS_LAST:
+                self.draws.begin_step()                  # (host RNG work first: the launches below then reach the queue back to back)
             if x.is_cuda and x.dtype == torch.float32 and x.shape == self.x.shape and not _X_BY_MEMCPY:
                 TF.copy_into(x, self.x)                  # (a copy kernel: stays on the compute queue in front of the graph, see StaticDraws.begin_step)
             else:
                 self.x.copy_(x, non_blocking=True)
             if self.cond is not None:
                 TF.copy_into(cond.detach(), self.cond)
-            self.draws.begin_step()
+            if _DRAWS_LAST:
+                self.draws.begin_step()
             if self.graphs is None and self.n >= self.warmup:
                 self._capture()          # the capture pass also executes nothing: replay right after
             if self.graphs is None:
